@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- augmented images/s of the latent-optimisation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one batch through the plugin API (set_input -> forward -> get_output): B images, `--latent-steps` Adam steps
+of StyleGAN2 synthesis forward + backward-to-w each, then the final synthesis (reference loop: backbone_latentaug.py:99-106).
+Workload (BASELINE.json configs[1]): SG2 config-f 256x256, 2 channels, random-init G, B = 8 per GPU, 20 latent steps,
+criteria w_latent=0.001 / w_pix=0.1 (banks M_w=1024, M_x=256, scanned every step), synthetic inputs.
+Inputs (latents, banks, weights) are resident in HBM when the timed region starts; the image D2H copy of get_output()
+is inside the timed region, as it is in the reference's loop.
+Weak scaling: every rank optimises its own B images; one RCCL all_gather of the augmented batch per step.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=4)
+    p.add_argument('--warmup', type=int, default=1)
+    p.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    p.add_argument('--latent-steps', type=int, default=20)
+    p.add_argument('--res', type=int, default=256)
+    p.add_argument('--channel-base', type=int, default=32768, help='32768 = config-f, 16384 = config-e')
+    p.add_argument('--criterion-mode', default='gemm', choices=['gemm', 'collapsed'])
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-roofline', action='store_true', help='skip the HIP-event leg (used under rocprofv3)')
+    return p.parse_args()
+
+
+def make_opt(args, local_rank):
+    return types.SimpleNamespace(
+        aug='latent', gpu_ids=[local_rank], gpu_ids_aug=str(local_rank), checkpoints_dir='/tmp', name='bench', phase='train',
+        img_resolution=args.res, batch_size=args.batch, modalities_aug='A,B', opt_num_epochs=args.latent_steps, opt_lr=0.01,
+        truncation_psi=1.0, w_pix=0.1, w_lpips=0.0, w_latent=0.001, w_disc=0.0, crop_size_aug=64,
+        preprocess_aug='center_random_crop', soft_aug=False, alpha=1.0, verbose_log=False, rand_aug=False,
+        lower_bound_clip=False, p_thres=0.0, init_w='inv', criterion_mode=args.criterion_mode, final_noise_mode='random')
+
+
+def cpu_baseline(sd, meta, args):
+    """The oracle (a CPU port pinned to reference goldens) on the host cores, bounded sample, scaled to images/s."""
+    import torch
+    from oracle import latent_aug_ref as lar
+    from oracle import sg2_networks as nets
+    from latentaugment_amd import synthetic
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    G = nets.Generator(z_dim=meta['w_dim'], w_dim=meta['w_dim'], img_resolution=args.res, img_channels=2,
+                       channel_base=args.channel_base)
+    G.load_state_dict(sd, strict=False)
+    G = G.eval().requires_grad_(False)
+    b = 2
+    W, X = synthetic.make_banks(G.num_ws, res=args.res, M_w=1024, M_x=256)
+    ref = lar.LatentAugRef(G, None, W=W, X=X, res=args.res, num_epochs=1, opt_lr=0.01, crop_size=64, w_latent=0.001,
+                           w_pix=0.1)
+    w0 = synthetic.make_latents(b)
+    t0 = time.time()
+    ref.forward(w0, crop_pos=(0, 0))          # 1 optimisation step (fwd + bwd) + the final synthesis
+    t_one = time.time() - t0
+    with torch.no_grad():
+        t0 = time.time()
+        G.synthesis(w0.repeat(1, G.num_ws, 1), noise_mode='const')
+        t_fwd = time.time() - t0
+    t_step = max(t_one - t_fwd, 1e-9)
+    per_batch = args.latent_steps * t_step + t_fwd
+    return {'value': b / per_batch, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle loop, B={b}: 1 latent step + final synthesis timed ({t_one:.1f}s + {t_fwd:.1f}s), '
+                      f'extrapolated to {args.latent_steps} steps'}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from latentaugment_amd import _lib, synthetic
+    from latentaugment_amd.augments import create_augment
+    from latentaugment_amd.latent_aug import InMemoryLatentCodes
+
+    sd, meta = synthetic.make_generator_state_dict(img_resolution=args.res, img_channels=2, channel_base=args.channel_base,
+                                                   seed=0)
+    W, X = synthetic.make_banks(meta['num_ws'], res=args.res, M_w=1024, M_x=256)
+    data = synthetic.make_batch(args.batch, res=args.res, seed=2 + rank)
+    w0 = synthetic.make_latents(args.batch, seed=1 + rank)
+    codes = InMemoryLatentCodes({p: w0[i, 0].numpy() for i, p in enumerate(data['A_paths'])})
+    opt = make_opt(args, local_rank)
+    # each rank owns its own B images (weak scaling); the plugin itself is run un-sharded per rank, the gather of the
+    # whole job's output is done below with the same single collective the sharded plugin path uses
+    opt.inject = dict(generator=sd, banks={'W': W, 'X': X}, latent_codes=codes, group=None)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        aug = create_augment(opt)
+    la = aug.latent_aug
+    random.seed(6)
+
+    def one_step():
+        aug.set_input(data)
+        # plugin forward without the process-group sharding (each rank has distinct samples)
+        aug.w_AB = aug.sample_from_inversion(aug.fname).to(dev)
+        img, w_aug, _ = la.run_local(aug.w_AB)
+        if world > 1:
+            flat = torch.cat([img.reshape(args.batch, -1), w_aug.reshape(args.batch, -1)], dim=1)
+            out = torch.empty([world * args.batch, flat.shape[1]], device=dev)
+            dist.all_gather_into_tensor(out, flat)          # ONE RCCL collective per batch over xGMI
+        aug.real_AB_aug, aug.w_AB_aug = img, w_aug
+        return aug.get_output()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    lib = _lib.load()
+    prof = (not args.no_roofline)
+    barrier()
+    if prof:
+        _lib.check(lib.la_prof_begin(), 'la_prof_begin')
+    t0 = time.time()
+    for _ in range(args.steps):
+        out = one_step()
+    barrier()
+    elapsed = time.time() - t0
+    roof = None
+    if prof:
+        import ctypes as C
+        ms, n, fl, by = C.c_double(), C.c_long(), C.c_double(), C.c_double()
+        rc = lib.la_prof_end(C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
+        if rc == 0 and ms.value > 0:
+            tf = fl.value / (ms.value * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'kernel': 'la_conv_igemm_kernel (fp32 MFMA 32x32x2 implicit GEMM, all launches)',
+                    'achieved': tf, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TFLOPS,
+                    'traffic': None, 'launches': n.value, 'avg_launch_ms': ms.value / max(n.value, 1),
+                    'kernel_time_frac_of_wall': ms.value * 1e-3 / elapsed,
+                    'algorithmic_gbs': by.value / (ms.value * 1e-3) / 1e9, 'hbm_peak_gbs': HBM_PEAK_GBS}
+            pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+            if os.path.isfile(pmc):
+                roof['traffic'] = json.load(open(pmc)).get('bytes_per_launch')
+    assert out['A'].shape == (args.batch, 1, args.res, args.res)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    images = args.steps * args.batch * world
+    line = {
+        'metric': 'augmented images/sec (256^2, 20 latent steps)', 'value': images / elapsed, 'unit': 'images/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'SG2 config-{"f" if args.channel_base == 32768 else "e"} {args.res}x{args.res} 2-ch, '
+                               f'random-init G, batch={args.batch}/GPU, {args.latent_steps} latent steps, '
+                               f'w_latent=0.001 w_pix=0.1 (M_w=1024, M_x=256, criterion_mode={args.criterion_mode})',
+                   'global_batch': args.batch * world, 'parallelism': f'dp{world}'},
+    }
+    if roof is not None:
+        line['roofline'] = roof
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(sd, meta, args)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,194 @@
+/* latentaug_hip.h -- C ABI of liblatentaug_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the latent-optimisation hot path of ltronchin/LatentAugment.  Every entry point names the
+ * reference interface it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is DEVICE memory (fp32, contiguous NCHW) unless its name ends
+ *     in `_host`; the caller has selected the device and owns every buffer; nothing here allocates device memory.
+ *   - all work is enqueued on `stream` (a hipStream_t, passed as void* from foreign code); no host<->device sync.
+ *   - return 0 on success, negative on failure (LA_ERR_*); la_last_error() gives the thread's last message.
+ *     This replaces the TORCH_CHECKs of the reference bindings (bias_act.cpp:35-51, upfirdn2d.cpp:19-40).
+ *   - re-entrant: no global mutable state besides the thread-local error string (cf. bias_act.cpp:54,88).
+ */
+#ifndef LATENTAUG_HIP_H
+#define LATENTAUG_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef LA_STREAM_T
+#define LA_STREAM_T
+typedef struct ihipStream_t* la_stream_t; /* == hipStream_t */
+#endif
+
+#define LA_OK 0
+#define LA_ERR_ARG (-1)
+#define LA_ERR_HIP (-2)
+#define LA_ERR_WORKSPACE (-3)
+
+/* activation ids = the reference's cuda_idx (torch_utils/ops/bias_act.py:20-30) */
+#define LA_ACT_LINEAR 1
+#define LA_ACT_RELU 2
+#define LA_ACT_LRELU 3
+
+const char* la_last_error(void);
+int la_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * L0 ops -- replace the pybind plugins of models/stylegan3/torch_utils/ops/
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* bias_act forward.  Replaces bias_act_plugin.bias_act(x,b,xref,yref,dy,grad=0,dim,act,alpha,gain,clamp)
+ * (bias_act.cpp:32-90, kernel bias_act.cu:23-147).  Element i takes b[(i / stepb) % nb]; for NCHW and dim=1:
+ * stepb = H*W, nb = C.  b may be NULL.  clamp < 0 disables clamping. */
+int la_bias_act_f32(const float* x, const float* b, float* y, long n, long stepb, int nb, int act, float alpha,
+                    float gain, float clamp, la_stream_t stream);
+
+/* bias_act first-order backward (grad=1 of the same plugin; python side bias_act.py:155-177):
+ * dx = dy * act'(.) taken from the saved OUTPUT yref (sign for lrelu, zero where |yref| >= clamp), db[c] = sum dx. */
+int la_bias_act_grad_f32(const float* dy, const float* yref, float* dx, float* db, long n, long stepb, int nb, int act,
+                         float alpha, float gain, float clamp, la_stream_t stream);
+
+/* upfirdn2d.  Replaces upfirdn2d_plugin.upfirdn2d(x,f,upx,upy,downx,downy,padx0,padx1,pady0,pady1,flip,gain)
+ * (upfirdn2d.cpp:16-98, kernels upfirdn2d.cu:29-200).  f_host: fh*fw taps in HOST memory (<= 8x8), as produced by
+ * setup_filter (upfirdn2d.py:70-114).  Output size per axis: la_upfirdn2d_out_size (upfirdn2d.cpp:35-36).
+ * The backward of the op is the same op with up<->down swapped, flip negated and the pads of upfirdn2d.py:255-266. */
+int la_upfirdn2d_out_size(int in_size, int up, int down, int pad0, int pad1, int taps);
+int la_upfirdn2d_f32(const float* x, const float* f_host, float* y, int N, int C, int H, int W, int fh, int fw, int upx,
+                     int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
+                     la_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Modulated 3x3 convolution of a SynthesisLayer (the SG2 `modulated_conv2d` + `bias_act` pair that the reference
+ * reaches through G.synthesis, util_latent_aug.py:227; resampling algebra conv2d_resample.py:82-134).
+ * Non-fused formulation: y = act((W * (x.s)) . d + noise + bias); never materialises per-sample weights.
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* W[cout][cin][ktaps] -> wf[t][cin][cout] (forward A-operand), wb[t][cout][cin] (backward), wsq[cout][cin] = sum_t W^2.
+ * Any of wf/wb/wsq may be NULL. */
+int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps,
+                             la_stream_t stream);
+
+/* same-resolution layer (conv1): x [B][cin][res][res] (x_bstride = 0 broadcasts one sample), s [B][s_stride] styles,
+ * d [B][d_stride] demodulation coefficients (NULL = no demod), noise [res][res] (noise_bstride 0) or per sample. */
+int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const float* s, int s_stride, const float* d,
+                          int d_stride, const float* noise, long noise_bstride, float noise_strength, const float* bias,
+                          int act, float alpha, float gain, float clamp, float* y, int B, int cin, int cout, int res,
+                          la_stream_t stream);
+
+/* up-sampling layer (conv0): x [B][cin][res/2][res/2] -> y [B][cout][res][res];
+ * scratch: B*cout*(res+1)^2 floats (the transposed-conv intermediate of conv2d_resample.py:125). */
+int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const float* s, int s_stride,
+                              const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
+                              const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
+                              float* scratch, float* y, int B, int cin, int cout, int res, la_stream_t stream);
+
+/* backward-data + style-gradient partials.  gz [B][cout][res][res] = gradient w.r.t. the raw contraction (already
+ * multiplied by d and by act').  gx = (W^T * gz) . s ;  ds_part[b][i][tile] = partial sums of sum_p (W^T*gz) . xin. */
+int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const float* s, int s_stride, const float* xin,
+                          long xin_bstride, float* gx, float* ds_part, int B, int cin, int cout, int res,
+                          la_stream_t stream);
+int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const float* s, int s_stride, const float* xin,
+                              long xin_bstride, const float* fir_host, float* scratch, float* gx, float* ds_part, int B,
+                              int cin, int cout, int res, la_stream_t stream);
+int la_modconv_ds_tiles(int grid_res); /* leading dimension of ds_part for a backward over a grid_res^2 grid */
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Criteria and optimiser
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* l2_loss_vectorized (augments/utils/util_latent_aug.py:315-361) on flattened rows: X [n][K], Y [m][K] ->
+ * D [m][n] = |Y_m|^2 + |X_n|^2 - 2<Y_m,X_n> (compute_mean=False); mean_out (may be NULL) = sum(D)/(m*n)/K.
+ * workspace: m + n floats. */
+int la_pairwise_l2_f32(const float* X, int n, const float* Y, long m, long K, float* D, float* mean_out,
+                       float* workspace, la_stream_t stream);
+
+/* get_center_crop (augments/utils/util_dataset.py:317-323) on [planes][R][R] -> [planes][cc][cc]. */
+int la_center_crop_f32(const float* src, float* dst, long planes, int R, int cc, int off, la_stream_t stream);
+
+/* torch.optim.Adam step as used at util_latent_aug.py:213,274-276 (step is 1-based). */
+int la_adam_step_f32(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1, float beta2,
+                     float eps, la_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Synthesis network engine: replaces  G.synthesis(ws, noise_mode=...)  (call sites util_latent_aug.py:227,488) and the
+ * autograd backward to ws that loss.backward() (:275) runs through it.  Architecture 'skip', fp32
+ * (models/stylegan3/legacy.py:122-144).
+ *
+ * params: flat list of device tensors in execution order (names as in legacy.py:171-203):
+ *   b4:            const | conv1.{affine.weight, affine.bias, weight, bias, noise_const} | torgb.{affine.weight, affine.bias, weight, bias}
+ *   b8 .. bR each: conv0.{5 tensors as above} | conv1.{5} | torgb.{4}
+ * noise_strength_host: one float per SynthesisLayer in the same order.  channels[k] = channels at resolution 4<<k.
+ * fir_host: the 4x4 resample filter (setup_filter([1,3,3,1])).  workspace: la_synth_workspace_bytes() of device memory,
+ * owned by the caller and alive as long as the handle.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct la_synth la_synth;
+int la_synth_num_ws(int img_resolution);
+int la_synth_num_params(int img_resolution);
+size_t la_synth_workspace_bytes(int img_resolution, int img_channels, int w_dim, const int* channels, int max_batch);
+int la_synth_create(int img_resolution, int img_channels, int w_dim, const int* channels, float conv_clamp,
+                    const float* const* params, int nparams, const float* noise_strength_host, int nlayers,
+                    const float* fir_host, int fir_h, int fir_w, int max_batch, void* workspace, size_t workspace_bytes,
+                    la_stream_t stream, la_synth** out);
+void la_synth_destroy(la_synth* h);
+/* ws element (b,l,j) = ws[b*ws_bstride + l*ws_lstride + j] (ws_lstride = 0: W space, one w per sample).
+ * noise_mode 0 'none', 1 'const', 2 explicit unit-variance tensors noises[layer] [B][res][res] ('random' drawn by the caller).
+ * img_out NULL: the image stays in the engine (la_synth_image). */
+int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, long ws_lstride, int B, int noise_mode,
+                     const float* const* noises, float* img_out, la_stream_t stream);
+/* d(loss)/d(ws) [B][num_ws][w_dim] from d(loss)/d(img) [B][C][R][R]; differentiates the last la_synth_forward. */
+int la_synth_backward(la_synth* h, const float* g_img, float* dws, la_stream_t stream);
+const float* la_synth_image(const la_synth* h);
+const float* la_synth_block_image(const la_synth* h, int block);
+const float* la_synth_layer_output(const la_synth* h, int layer);
+const float* la_synth_styles(const la_synth* h);
+const float* la_synth_style_grads(const la_synth* h);
+int la_synth_style_rows(const la_synth* h);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * The loop: replaces LatentAug.forward(w, fname) (augments/utils/util_latent_aug.py:207-310) for 3-D w input.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct la_opt_config {
+    int steps;              /* opt_num_epochs (latent_aug.py:81) */
+    float lr;               /* opt_lr (latent_aug.py:82) */
+    float beta1, beta2, eps;
+    float w_latent, w_pix, w_disc, w_lpips; /* latent_aug.py:88-91; w_disc / w_lpips must be 0 in this version */
+    int criterion_mode;     /* 0: scan the banks every step (reference formulation); 1: cached bank column sums */
+    int soft_aug;           /* latent_aug.py:94 */
+    float alpha;            /* latent_aug.py:95 */
+    int loop_noise_mode;    /* 1 = 'const' (util_latent_aug.py:227) */
+    int final_noise_mode;   /* util_latent_aug.py:488 uses the generator default ('random'): pass 2 + tensors */
+    int norm_batch;         /* n of the criteria's 1/(m*n); 0 = local batch (what a DataParallel replica sees) */
+    int crop, crop_off;     /* util_dataset.py:317-323: int(sqrt(R*R/2)), round((R-crop)/2) */
+} la_opt_config;
+typedef struct la_latent_opt la_latent_opt;
+size_t la_latent_opt_workspace_bytes(int img_resolution, int img_channels, int w_dim, const la_opt_config* cfg, long Mw,
+                                     long Mx, int max_batch);
+/* bankW [Mw][num_ws][w_dim] (register_buffer 'W', :148); bankXc [C][Mx][crop*crop] = centre-cropped 'X' (:158, :253),
+ * modality-major. */
+int la_latent_opt_create(la_synth* g, int img_resolution, int img_channels, int w_dim, const la_opt_config* cfg,
+                         const float* bankW, long Mw, const float* bankXc, long Mx, int max_batch, void* workspace,
+                         size_t workspace_bytes, la_latent_opt** out);
+void la_latent_opt_destroy(la_latent_opt* h);
+/* w0 [B][w_dim] -> img_out [B][C][R][R], w_aug_out [B][num_ws][w_dim]; losses_out (may be NULL) [steps][4] =
+ * weighted {latent, pix, disc, lpips} per step. */
+int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const float* const* final_noises, float* img_out,
+                      float* w_aug_out, float* losses_out, la_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Opt-in profiler for the contraction launches (HIP events on the launch stream).  No reference counterpart: the
+ * reference's only timing hook is wall-clock stats_time (augments/latent_aug.py:276).
+ * la_prof_end: summed device ms, launch count, algorithmic FLOPs (2*MACs) and algorithmic bytes (input + output +
+ * weights, each once) of every la_conv launch since la_prof_begin.
+ * ------------------------------------------------------------------------------------------------------------- */
+int la_prof_begin(void);
+int la_prof_end(double* total_ms, long* launches, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LATENTAUG_HIP_H */

@@ -1,0 +1,112 @@
+"""ctypes binding of liblatentaug_hip.so (the C ABI declared in include/latentaug_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If it is missing, or a call fails, this module
+raises (`LatentAugHipError`) -- it never silently computes elsewhere.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblatentaug_hip.so')
+
+
+class LatentAugHipError(RuntimeError):
+    pass
+
+
+class OptConfig(C.Structure):
+    """Mirror of `la_opt_config` (include/latentaug_hip.h)."""
+    _fields_ = [
+        ('steps', C.c_int), ('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
+        ('w_latent', C.c_float), ('w_pix', C.c_float), ('w_disc', C.c_float), ('w_lpips', C.c_float),
+        ('criterion_mode', C.c_int), ('soft_aug', C.c_int), ('alpha', C.c_float),
+        ('loop_noise_mode', C.c_int), ('final_noise_mode', C.c_int), ('norm_batch', C.c_int),
+        ('crop', C.c_int), ('crop_off', C.c_int),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_long
+_F = C.c_float
+_Z = C.c_size_t
+
+# name -> (restype, argtypes); kept in one table so tests can check every header symbol is exported
+SIGNATURES = {
+    'la_last_error': (C.c_char_p, []),
+    'la_abi_version': (_I, []),
+    'la_bias_act_f32': (_I, [_P, _P, _P, _L, _L, _I, _I, _F, _F, _F, _P]),
+    'la_bias_act_grad_f32': (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _F, _F, _F, _P]),
+    'la_upfirdn2d_out_size': (_I, [_I] * 6),
+    'la_upfirdn2d_f32': (_I, [_P, _P, _P] + [_I] * 15 + [_F, _P]),
+    'la_pack_conv_weights_f32': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'la_modconv3x3_fwd_f32': (_I, [_P, _L, _P, _P, _I, _P, _I, _P, _L, _F, _P, _I, _F, _F, _F, _P, _I, _I, _I, _I, _P]),
+    'la_modconv3x3_up2_fwd_f32': (_I, [_P, _L, _P, _P, _I, _P, _I, _P, _L, _F, _P, _I, _F, _F, _F, _P, _P, _P, _I, _I, _I,
+                                       _I, _P]),
+    'la_modconv3x3_bwd_f32': (_I, [_P, _P, _P, _I, _P, _L, _P, _P, _I, _I, _I, _I, _P]),
+    'la_modconv3x3_up2_bwd_f32': (_I, [_P, _P, _P, _I, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'la_modconv_ds_tiles': (_I, [_I]),
+    'la_pairwise_l2_f32': (_I, [_P, _I, _P, _L, _L, _P, _P, _P, _P]),
+    'la_center_crop_f32': (_I, [_P, _P, _L, _I, _I, _I, _P]),
+    'la_adam_step_f32': (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _P]),
+    'la_synth_num_ws': (_I, [_I]),
+    'la_synth_num_params': (_I, [_I]),
+    'la_synth_workspace_bytes': (_Z, [_I, _I, _I, _P, _I]),
+    'la_synth_create': (_I, [_I, _I, _I, _P, _F, _P, _I, _P, _I, _P, _I, _I, _I, _P, _Z, _P, _P]),
+    'la_synth_destroy': (None, [_P]),
+    'la_synth_forward': (_I, [_P, _P, _L, _L, _I, _I, _P, _P, _P]),
+    'la_synth_backward': (_I, [_P, _P, _P, _P]),
+    'la_synth_image': (_P, [_P]),
+    'la_synth_block_image': (_P, [_P, _I]),
+    'la_synth_layer_output': (_P, [_P, _I]),
+    'la_synth_styles': (_P, [_P]),
+    'la_synth_style_grads': (_P, [_P]),
+    'la_synth_style_rows': (_I, [_P]),
+    'la_latent_opt_workspace_bytes': (_Z, [_I, _I, _I, _P, _L, _L, _I]),
+    'la_latent_opt_create': (_I, [_P, _I, _I, _I, _P, _P, _L, _P, _L, _I, _P, _Z, _P]),
+    'la_latent_opt_destroy': (None, [_P]),
+    'la_latent_opt_run': (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
+    'la_prof_begin': (_I, []),
+    'la_prof_end': (_I, [_P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise LatentAugHipError(
+            f'{LIB_PATH} not found: build it with `make -C latentaugment_amd/csrc` (or __graft_entry__.build()). '
+            'There is no CPU fallback for the latent-augmentation hot path.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().la_last_error()
+        raise LatentAugHipError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
+
+
+def require_gpu(t):
+    """Product tensors must live on the GPU: this path has no host implementation."""
+    if not t.is_cuda:
+        raise LatentAugHipError('latentaugment_amd needs a ROCm device tensor (no CPU fallback); got ' + str(t.device))
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

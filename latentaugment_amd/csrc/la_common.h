@@ -1,0 +1,89 @@
+// Shared definitions for the latentaug HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LA_OK 0
+#define LA_ERR_ARG (-1)        // bad argument / unsupported configuration
+#define LA_ERR_HIP (-2)        // a HIP runtime call failed (see la_last_error)
+#define LA_ERR_WORKSPACE (-3)  // caller-provided workspace too small
+
+#define LA_WAVE 64
+
+void la_set_error(const char* msg);
+
+#define LA_CHECK_ARG(cond, msg)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            la_set_error(msg);             \
+            return LA_ERR_ARG;             \
+        }                                  \
+    } while (0)
+
+#define LA_CHECK_LAUNCH()                              \
+    do {                                               \
+        hipError_t e__ = hipGetLastError();            \
+        if (e__ != hipSuccess) {                       \
+            la_set_error(hipGetErrorString(e__));      \
+            return LA_ERR_HIP;                         \
+        }                                              \
+    } while (0)
+
+#define LA_HIP(call)                                   \
+    do {                                               \
+        hipError_t e__ = (call);                       \
+        if (e__ != hipSuccess) {                       \
+            la_set_error(hipGetErrorString(e__));      \
+            return LA_ERR_HIP;                         \
+        }                                              \
+    } while (0)
+
+static inline int la_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float la_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves).  `red` is >= 4 floats of LDS.  All threads get the result.
+__device__ __forceinline__ float la_block_sum_256(float v, float* red) {
+    v = la_wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// activation ids follow the reference's cuda_idx (bias_act.py:20-30): 1 linear, 2 relu, 3 lrelu
+#define LA_ACT_LINEAR 1
+#define LA_ACT_RELU 2
+#define LA_ACT_LRELU 3
+
+// y = clamp(act(v) * gain)  (bias_act.cu:23-147 semantics, grad=0)
+__device__ __forceinline__ float la_act_fwd(float v, int act, float alpha, float gain, float clamp) {
+    if (act == LA_ACT_LRELU) v = v > 0.f ? v : v * alpha;
+    else if (act == LA_ACT_RELU) v = v > 0.f ? v : 0.f;
+    v *= gain;
+    if (clamp >= 0.f) v = fminf(fmaxf(v, -clamp), clamp);
+    return v;
+}
+
+// d(y)/d(v) expressed through the saved OUTPUT y, as the reference's kernel does (bias_act.cu:46-48,71-72,141):
+// slope from the sign of y, zero where the clamp is active.
+__device__ __forceinline__ float la_act_bwd_from_y(float y, int act, float alpha, float gain, float clamp) {
+    float s = gain;
+    if (act == LA_ACT_LRELU) s = y > 0.f ? gain : gain * alpha;
+    else if (act == LA_ACT_RELU) s = y > 0.f ? gain : 0.f;
+    if (clamp >= 0.f && fabsf(y) >= clamp) s = 0.f;
+    return s;
+}
+
+// pre-activation value (x + b) recovered from the saved output (only meaningful where the clamp is inactive)
+__device__ __forceinline__ float la_act_inv(float y, int act, float alpha, float gain) {
+    float v = y / gain;
+    if (act == LA_ACT_LRELU && v < 0.f) v = v / alpha;
+    return v;
+}

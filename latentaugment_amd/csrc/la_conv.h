@@ -1,0 +1,51 @@
+// Implicit-GEMM convolution on the fp32 MFMA path (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// One kernel family serves every dense contraction of the synthesis pass (DESIGN.md "conv_igemm"):
+//   F1  forward 3x3 same-resolution conv          (conv2d_resample.py:132-134)
+//   F2  forward transposed stride-2 conv, one launch per output phase (conv2d_resample.py:112-125)
+//   B1  backward-data of F1 (flipped taps, transposed weight slab)
+//   B2  backward-data of F2 (stride-2 gather over the (2h+1)^2 gradient)
+// expressed as  out[b, m, g*os+oo] = sum_{t, c} wgt[tap_w[t]][c][m] * scale[b][c] * in[b, c, g*is + tap_d[t]]
+#pragma once
+#include "la_common.h"
+
+#define LA_EPI_RAW 0
+#define LA_EPI_FWD 1
+#define LA_EPI_BWD 2
+#define LA_CONV_MAX_TAPS 9
+
+struct LaConvArgs {
+    const float* in;         // [B][C][Hin][Win]; in_bstride == 0 broadcasts one sample over the batch
+    const float* wgt;        // [slabs][C][M]
+    float* out;              // [B][M][Hout][Wout]
+    const float* in_scale;   // [B][scale_stride] or null: modulate-on-load  x * s[b][c]
+    long in_bstride;
+    int scale_stride;
+    int B, C, M, Hin, Win, Hout, Wout;
+    int Gy, Gx;              // output grid per sample handled by this launch
+    int in_sy, in_sx;
+    int out_sy, out_sx, out_oy, out_ox;
+    int ntaps;
+    int tap_dy[LA_CONV_MAX_TAPS], tap_dx[LA_CONV_MAX_TAPS], tap_w[LA_CONV_MAX_TAPS];
+    int epi;
+    // LA_EPI_FWD:  y = clamp(act(acc*demod[b][m] + noise*strength + bias[m]) * gain)
+    const float* demod;
+    int demod_stride;
+    const float* noise;      // [Hout][Wout] (noise_bstride 0) or [B][Hout][Wout]
+    long noise_bstride;
+    float noise_strength;
+    const float* bias;
+    int act;
+    float alpha, gain, clamp;
+    // LA_EPI_BWD:  out = acc * out_scale[b][m];  ds_part[b][m][tile] = sum_pixels acc * xin[b][m][pixel]
+    const float* out_scale;
+    int oscale_stride;
+    const float* xin;
+    long xin_bstride;
+    float* ds_part;          // [B][M][tiles_per_sample]
+    int tiles_per_sample;
+};
+
+// number of pixel tiles per sample for a launch (the ds_part leading dimension)
+int la_conv_tiles_per_sample(int Gy, int Gx);
+int la_conv_launch(const LaConvArgs& a, hipStream_t stream);

@@ -1,0 +1,280 @@
+// Implicit-GEMM convolution, fp32 MFMA 32x32x2 (see la_conv.h).  Written for gfx950 only.
+//
+// Tiling: workgroup = 256 threads = 4 waves in a 2(m) x 2(n) grid; block tile MT(out channels) x 128(pixels);
+// each wave owns (MT/2) x 64 as TM x 2 MFMA tiles of 32x32.  K is walked in chunks of (one tap, 16 input
+// channels): the A slab [16][MT] comes straight from the tap-major packed weights (float4, coalesced), the B
+// slab [16][128] is gathered from the NCHW input (lanes = consecutive pixels, coalesced) with the per-(b,c)
+// modulation multiplied in on the way to LDS.  The next chunk's global loads are issued before the current
+// chunk's MFMAs (register-staged prefetch); fp32 MFMA takes 64 cycles per instruction so the loader has slack.
+#include "la_conv.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NT 128
+#define KC 16
+
+int la_conv_tiles_per_sample(int Gy, int Gx) { return la_cdiv((long)Gy * Gx, NT); }
+
+template <int MT>
+__global__ __launch_bounds__(256) void la_conv_igemm_kernel(LaConvArgs a) {
+    constexpr int TM = MT / 64;            // 32-row MFMA tiles per wave along m
+    constexpr int A_F4 = (KC * MT / 4) / 256;  // float4 loads of the A slab per thread (2 for MT=128, 1 for MT=64)
+    __shared__ __attribute__((aligned(16))) float As[KC][MT];
+    __shared__ __attribute__((aligned(16))) float Bs[KC][NT];
+    __shared__ float red[2][MT];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int ntile = blockIdx.x;
+    const int m0 = blockIdx.y * MT;
+    const int b = blockIdx.z;
+
+    // ---- loader roles
+    const int n_l = tid & (NT - 1);
+    const int khalf = tid >> 7;
+    const int G = a.Gy * a.Gx;
+    const int g_l = ntile * NT + n_l;
+    const bool nvalid = g_l < G;
+    const int gy_l = nvalid ? g_l / a.Gx : 0;
+    const int gx_l = nvalid ? g_l - gy_l * a.Gx : 0;
+    const int iy0 = gy_l * a.in_sy, ix0 = gx_l * a.in_sx;
+    const long HWin = (long)a.Hin * a.Win;
+    const float* in_b = a.in + (long)b * a.in_bstride;
+    const float* sc_b = a.in_scale ? a.in_scale + (long)b * a.scale_stride : nullptr;
+
+    const int nck = (a.C + KC - 1) / KC;
+    const int nchunks = nck * a.ntaps;
+
+    float breg[KC / 2];
+    float4 areg[A_F4];
+
+    auto prefetch = [&](int ci) {
+        const int cc = ci / a.ntaps;
+        const int t = ci - cc * a.ntaps;
+        const int c0 = cc * KC;
+        const int iy = iy0 + a.tap_dy[t], ix = ix0 + a.tap_dx[t];
+        const bool ok = nvalid && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const long off = (long)iy * a.Win + ix;
+#pragma unroll
+        for (int j = 0; j < KC / 2; ++j) {
+            const int c = c0 + khalf + 2 * j;
+            float v = 0.f;
+            if (ok && c < a.C) {
+                v = in_b[(long)c * HWin + off];
+                if (sc_b) v *= sc_b[c];
+            }
+            breg[j] = v;
+        }
+        const float* wslab = a.wgt + (long)a.tap_w[t] * a.C * a.M;
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) {
+            const int idx = tid + 256 * j;
+            const int row = idx / (MT / 4), col = (idx - row * (MT / 4)) * 4;
+            const int c = c0 + row, m = m0 + col;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < a.C && m < a.M) v = *reinterpret_cast<const float4*>(wslab + (long)c * a.M + m);
+            areg[j] = v;
+        }
+    };
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    prefetch(0);
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int ci = 0; ci < nchunks; ++ci) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KC / 2; ++j) Bs[khalf + 2 * j][n_l] = breg[j];
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) {
+            const int idx = tid + 256 * j;
+            const int row = idx / (MT / 4), col = (idx - row * (MT / 4)) * 4;
+            *reinterpret_cast<float4*>(&As[row][col]) = areg[j];
+        }
+        __syncthreads();
+        if (ci + 1 < nchunks) prefetch(ci + 1);
+#pragma unroll
+        for (int kp = 0; kp < KC / 2; ++kp) {
+            float av[TM], bv[2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = As[2 * kp + lh][wm * (MT / 2) + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = Bs[2 * kp + lh][wn * 64 + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue.  acc[i][j][r]: m = m0 + wm*(MT/2) + i*32 + (r&3) + 8*(r>>2) + 4*lh ; pixel = ntile*NT + wn*64 + j*32 + l31
+    int pix_off[2];
+    bool pix_ok[2];
+    long npos[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g = ntile * NT + wn * 64 + j * 32 + l31;
+        pix_ok[j] = g < G;
+        const int gy = pix_ok[j] ? g / a.Gx : 0;
+        const int gx = pix_ok[j] ? g - gy * a.Gx : 0;
+        const int oy = gy * a.out_sy + a.out_oy, ox = gx * a.out_sx + a.out_ox;
+        pix_off[j] = oy * a.Wout + ox;
+        npos[j] = (long)pix_off[j];
+    }
+    const long HWout = (long)a.Hout * a.Wout;
+    float* out_b = a.out + (long)b * a.M * HWout;
+
+    if (a.epi == LA_EPI_BWD) {
+        const float* xin_b = a.xin ? a.xin + (long)b * a.xin_bstride : nullptr;
+        const float* os_b = a.out_scale ? a.out_scale + (long)b * a.oscale_stride : nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * (MT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + ml;
+                const bool mok = m < a.M;
+                const float sc = (os_b && mok) ? os_b[m] : 1.f;
+                float part = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float v = acc[i][j][r];
+                    if (mok && pix_ok[j]) {
+                        out_b[(long)m * HWout + npos[j]] = v * sc;
+                        if (xin_b) part += v * xin_b[(long)m * HWout + npos[j]];
+                    }
+                }
+                if (a.ds_part) {
+                    // sum over the 32 lanes of this half-wave (they share m)
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                    if (l31 == 0) red[wn][ml] = part;
+                }
+            }
+        }
+        if (a.ds_part) {
+            __syncthreads();
+            if (tid < MT && m0 + tid < a.M)
+                a.ds_part[((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile] = red[0][tid] + red[1][tid];
+        }
+        return;
+    }
+
+    const bool fwd = a.epi == LA_EPI_FWD;
+    const float* dm_b = (fwd && a.demod) ? a.demod + (long)b * a.demod_stride : nullptr;
+    float nz[2] = {0.f, 0.f};
+    if (fwd && a.noise) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (pix_ok[j]) nz[j] = a.noise[(long)b * a.noise_bstride + npos[j]] * a.noise_strength;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * (MT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= a.M) continue;
+            float dmv = 1.f, bv = 0.f;
+            if (fwd) {
+                if (dm_b) dmv = dm_b[m];
+                if (a.bias) bv = a.bias[m];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (!pix_ok[j]) continue;
+                float v = acc[i][j][r];
+                if (fwd) v = la_act_fwd(v * dmv + nz[j] + bv, a.act, a.alpha, a.gain, a.clamp);
+                out_b[(long)m * HWout + npos[j]] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Opt-in launch profiler (bench.py's roofline leg): HIP events bracket every contraction launch on the launch stream.
+// Off by default; the only process-global state in the library.
+#define LA_PROF_MAX 8192
+static struct {
+    int enabled, count, overflow;
+    hipEvent_t ev0[LA_PROF_MAX], ev1[LA_PROF_MAX];
+    int created;
+    double flops, bytes;
+} g_prof;
+
+extern "C" int la_prof_begin(void) {
+    if (g_prof.created < LA_PROF_MAX) {
+        for (int i = g_prof.created; i < LA_PROF_MAX; ++i) {
+            LA_HIP(hipEventCreate(&g_prof.ev0[i]));
+            LA_HIP(hipEventCreate(&g_prof.ev1[i]));
+            g_prof.created = i + 1;
+        }
+    }
+    g_prof.count = 0; g_prof.overflow = 0; g_prof.flops = 0; g_prof.bytes = 0; g_prof.enabled = 1;
+    return LA_OK;
+}
+
+// total device time (ms), launches, algorithmic FLOPs and algorithmic bytes of the contraction launches since la_prof_begin
+extern "C" int la_prof_end(double* total_ms, long* launches, double* flops, double* bytes) {
+    g_prof.enabled = 0;
+    double ms = 0;
+    for (int i = 0; i < g_prof.count; ++i) {
+        LA_HIP(hipEventSynchronize(g_prof.ev1[i]));
+        float t = 0.f;
+        LA_HIP(hipEventElapsedTime(&t, g_prof.ev0[i], g_prof.ev1[i]));
+        ms += t;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = g_prof.count;
+    if (flops) *flops = g_prof.flops;
+    if (bytes) *bytes = g_prof.bytes;
+    return g_prof.overflow ? LA_ERR_WORKSPACE : LA_OK;
+}
+
+int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
+    LA_CHECK_ARG(a.in && a.wgt && a.out, "conv: null pointer");
+    LA_CHECK_ARG(a.B > 0 && a.C > 0 && a.M > 0 && a.Gy > 0 && a.Gx > 0, "conv: empty shape");
+    LA_CHECK_ARG(a.M % 4 == 0, "conv: M must be a multiple of 4");
+    LA_CHECK_ARG(a.ntaps >= 1 && a.ntaps <= LA_CONV_MAX_TAPS, "conv: bad tap count");
+    LA_CHECK_ARG(a.in_sy >= 1 && a.in_sx >= 1 && a.out_sy >= 1 && a.out_sx >= 1, "conv: bad strides");
+    // last grid point must land inside the output
+    LA_CHECK_ARG((a.Gy - 1) * a.out_sy + a.out_oy < a.Hout && (a.Gx - 1) * a.out_sx + a.out_ox < a.Wout &&
+                     a.out_oy >= 0 && a.out_ox >= 0,
+                 "conv: output grid exceeds output tensor");
+    LA_CHECK_ARG((long)a.Hout * a.Wout < (1L << 31) && (long)a.Hin * a.Win < (1L << 31), "conv: plane too large");
+    if (a.epi == LA_EPI_BWD && a.ds_part) {
+        LA_CHECK_ARG(a.tiles_per_sample == la_conv_tiles_per_sample(a.Gy, a.Gx), "conv: tiles_per_sample mismatch");
+        LA_CHECK_ARG(a.out_sy == 1 && a.out_sx == 1 && a.out_oy == 0 && a.out_ox == 0, "conv: bwd epilogue needs dense output");
+    }
+    const int tiles = la_conv_tiles_per_sample(a.Gy, a.Gx);
+    int pslot = -1;
+    if (g_prof.enabled) {
+        if (g_prof.count < LA_PROF_MAX) {
+            pslot = g_prof.count++;
+            // algorithmic work of this launch: 2*MACs; bytes = input read once + output written once (+ weights once)
+            g_prof.flops += 2.0 * a.B * (double)a.Gy * a.Gx * a.M * (double)a.C * a.ntaps;
+            g_prof.bytes += 4.0 * ((double)a.B * a.C * a.Hin * a.Win * (a.in_bstride ? 1.0 : 1.0 / a.B) +
+                                   (double)a.B * a.M * a.Gy * a.Gx + (double)a.ntaps * a.C * a.M);
+            LA_HIP(hipEventRecord(g_prof.ev0[pslot], stream));
+        } else {
+            g_prof.overflow = 1;
+        }
+    }
+    if (a.M >= 128) {
+        dim3 grid(tiles, la_cdiv(a.M, 128), a.B);
+        hipLaunchKernelGGL(la_conv_igemm_kernel<128>, grid, dim3(256), 0, stream, a);
+    } else {
+        dim3 grid(tiles, la_cdiv(a.M, 64), a.B);
+        hipLaunchKernelGGL(la_conv_igemm_kernel<64>, grid, dim3(256), 0, stream, a);
+    }
+    LA_CHECK_LAUNCH();
+    if (pslot >= 0) LA_HIP(hipEventRecord(g_prof.ev1[pslot], stream));
+    return LA_OK;
+}

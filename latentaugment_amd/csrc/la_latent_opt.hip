@@ -1,0 +1,147 @@
+// The latent-optimisation loop: LatentAug.forward (augments/utils/util_latent_aug.py:207-310) as one host-driven
+// launch sequence with no host<->device synchronisation inside the loop (the reference syncs 5x per step through
+// `.item()`, :234-271).  W-space optimisation: ws = w repeated num_ws times (:226, :493-494).
+#include "la_latent_opt.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "la_criteria.h"
+
+struct la_latent_opt {
+    la_synth* g;
+    la_opt_config cfg;
+    int R, imgc, wdim, num_ws, maxB;
+    const float* bankW; long Mw;
+    const float* bankX; long Mx;     // [imgc][Mx][cc*cc]
+    float *w_opt, *m, *v, *dw, *dws, *g_img, *colsumW, *colsumX, *yx, *yy, *xx, *xc, *losses;
+    int colsums_valid;
+};
+
+static size_t al(size_t n) { return ((n * sizeof(float)) + 63) & ~(size_t)63; }
+
+static size_t carve(la_latent_opt* h, char* base) {
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? (float*)(base + off) : nullptr; off += al(n); return p; };
+    const size_t B = h->maxB, wd = h->wdim, cc2 = (size_t)h->cfg.crop * h->cfg.crop;
+    h->w_opt = take(B * wd); h->m = take(B * wd); h->v = take(B * wd); h->dw = take(B * wd);
+    h->dws = take(B * h->num_ws * wd);
+    h->g_img = take(B * h->imgc * (size_t)h->R * h->R);
+    h->colsumW = take((size_t)h->num_ws * wd);
+    h->colsumX = take((size_t)h->imgc * cc2);
+    const size_t mm = (size_t)(h->Mw > h->Mx ? h->Mw : h->Mx);
+    h->yx = take((mm ? mm : 1) * B); h->yy = take(mm ? mm : 1); h->xx = take(B);
+    h->xc = take(B * h->imgc * cc2);
+    h->losses = take((size_t)(h->cfg.steps > 0 ? h->cfg.steps : 1) * 4);
+    return off;
+}
+
+extern "C" size_t la_latent_opt_workspace_bytes(int img_resolution, int img_channels, int w_dim, const la_opt_config* cfg,
+                                                long Mw, long Mx, int max_batch) {
+    if (!cfg) return 0;
+    la_latent_opt h; memset(&h, 0, sizeof(h));
+    h.cfg = *cfg; h.R = img_resolution; h.imgc = img_channels; h.wdim = w_dim; h.num_ws = la_synth_num_ws(img_resolution);
+    h.maxB = max_batch; h.Mw = Mw; h.Mx = Mx;
+    return carve(&h, nullptr);
+}
+
+extern "C" int la_latent_opt_create(la_synth* g, int img_resolution, int img_channels, int w_dim, const la_opt_config* cfg,
+                                    const float* bankW, long Mw, const float* bankXc, long Mx, int max_batch,
+                                    void* workspace, size_t workspace_bytes, la_latent_opt** out) {
+    LA_CHECK_ARG(g && cfg && workspace && out, "latent_opt_create: null pointer");
+    LA_CHECK_ARG(cfg->steps >= 0, "latent_opt_create: negative step count");
+    LA_CHECK_ARG(cfg->w_disc == 0.f && cfg->w_lpips == 0.f,
+                 "latent_opt_create: discriminator / LPIPS criteria are not part of this library yet (w_disc, w_lpips must be 0)");
+    LA_CHECK_ARG(cfg->w_latent == 0.f || (bankW && Mw >= 1), "latent_opt_create: w_latent > 0 needs the latent bank W");
+    LA_CHECK_ARG(cfg->w_pix == 0.f || (bankXc && Mx >= 1), "latent_opt_create: w_pix > 0 needs the cropped image bank X");
+    LA_CHECK_ARG(cfg->crop >= 1 && cfg->crop_off >= 0 && cfg->crop + cfg->crop_off <= img_resolution,
+                 "latent_opt_create: centre crop does not fit the image");
+    LA_CHECK_ARG(cfg->criterion_mode == 0 || cfg->criterion_mode == 1, "latent_opt_create: criterion_mode must be 0 or 1");
+    la_latent_opt* h = (la_latent_opt*)malloc(sizeof(la_latent_opt));
+    LA_CHECK_ARG(h, "latent_opt_create: out of host memory");
+    memset(h, 0, sizeof(*h));
+    h->g = g; h->cfg = *cfg; h->R = img_resolution; h->imgc = img_channels; h->wdim = w_dim;
+    h->num_ws = la_synth_num_ws(img_resolution); h->maxB = max_batch;
+    h->bankW = bankW; h->Mw = cfg->w_latent != 0.f ? Mw : 0; h->bankX = bankXc; h->Mx = cfg->w_pix != 0.f ? Mx : 0;
+    const size_t need = carve(h, (char*)workspace);
+    if (need > workspace_bytes) { free(h); la_set_error("latent_opt_create: workspace too small"); return LA_ERR_WORKSPACE; }
+    *out = h;
+    return LA_OK;
+}
+
+extern "C" void la_latent_opt_destroy(la_latent_opt* h) { free(h); }
+
+static int refresh_colsums(la_latent_opt* h, hipStream_t stream) {
+    int rc;
+    const long cc2 = (long)h->cfg.crop * h->cfg.crop;
+    if (h->Mw && (rc = la_bank_colsum(h->bankW, h->Mw, (long)h->num_ws * h->wdim, h->colsumW, stream))) return rc;
+    if (h->Mx)
+        for (int c = 0; c < h->imgc; ++c)
+            if ((rc = la_bank_colsum(h->bankX + (long)c * h->Mx * cc2, h->Mx, cc2, h->colsumX + (long)c * cc2, stream)))
+                return rc;
+    return LA_OK;
+}
+
+extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const float* const* final_noises,
+                                 float* img_out, float* w_aug_out, float* losses_out, hipStream_t stream) {
+    LA_CHECK_ARG(h && w0 && img_out && w_aug_out, "latent_opt_run: null pointer");
+    LA_CHECK_ARG(B >= 1 && B <= h->maxB, "latent_opt_run: batch exceeds max_batch");
+    const la_opt_config& c = h->cfg;
+    LA_CHECK_ARG(c.final_noise_mode != 2 || final_noises, "latent_opt_run: explicit final noise requested but not given");
+    const int wd = h->wdim, cc = c.crop, off = c.crop_off;
+    const long cc2 = (long)cc * cc;
+    const long nw = (long)B * wd;
+    const float nb = (float)(c.norm_batch > 0 ? c.norm_batch : B);
+    int rc;
+    LA_HIP(hipMemcpyAsync(h->w_opt, w0, nw * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    LA_HIP(hipMemsetAsync(h->m, 0, nw * sizeof(float), stream));
+    LA_HIP(hipMemsetAsync(h->v, 0, nw * sizeof(float), stream));
+    const bool img_crit = c.w_pix != 0.f;
+    const bool want_losses = (c.criterion_mode == 0) || losses_out;
+    if (c.criterion_mode == 1 && !h->colsums_valid) {
+        if ((rc = refresh_colsums(h, stream))) return rc;
+        h->colsums_valid = 1;
+    }
+    if (want_losses && c.steps > 0) LA_HIP(hipMemsetAsync(h->losses, 0, (size_t)c.steps * 4 * sizeof(float), stream));
+    // loss = -loss_latent - loss_pix - loss_lpips + loss_disc  (:270): the diversity terms enter with a minus sign
+    const float lat_coef = h->Mw ? c.w_latent / ((float)h->Mw * nb * (float)h->num_ws * (float)wd) : 0.f;
+    const float pix_coef = h->Mx ? c.w_pix / ((float)h->imgc * (float)h->Mx * nb * (float)cc2) : 0.f;
+
+    for (int step = 1; step <= c.steps; ++step) {
+        if ((rc = la_synth_forward(h->g, h->w_opt, wd, 0, B, c.loop_noise_mode, nullptr, nullptr, stream))) return rc;
+        const float* img = la_synth_image(h->g);
+        if (c.criterion_mode == 0 && (rc = refresh_colsums(h, stream))) return rc;
+        if (want_losses) {
+            float* L = h->losses + (size_t)(step - 1) * 4;
+            if (h->Mw && (rc = la_l2_mean_from_bank(h->bankW, h->Mw, (long)h->num_ws * wd, h->w_opt, B, wd, wd, h->yx, h->yy,
+                                                    h->xx, lat_coef, L + 0, 0, stream)))
+                return rc;
+            if (h->Mx) {
+                if ((rc = la_center_crop_f32(img, h->xc, (long)B * h->imgc, h->R, cc, off, stream))) return rc;
+                for (int ch = 0; ch < h->imgc; ++ch)
+                    if ((rc = la_l2_mean_from_bank(h->bankX + (long)ch * h->Mx * cc2, h->Mx, cc2, h->xc + (long)ch * cc2, B,
+                                                   (long)h->imgc * cc2, 0, h->yx, h->yy, h->xx, pix_coef, L + 1, ch > 0,
+                                                   stream)))
+                        return rc;
+            }
+        }
+        const float* dws = nullptr;
+        if (img_crit) {
+            if ((rc = la_pix_grad(img, h->colsumX, h->g_img, B, h->imgc, h->R, cc, off, -2.f * pix_coef, (float)h->Mx, stream)))
+                return rc;
+            if ((rc = la_synth_backward(h->g, h->g_img, h->dws, stream))) return rc;
+            dws = h->dws;
+        }
+        if ((rc = la_latent_combine(dws, h->w_opt, h->Mw ? h->colsumW : nullptr, h->dw, B, h->num_ws, wd, -2.f * lat_coef,
+                                    (float)h->Mw, stream)))
+            return rc;
+        if ((rc = la_adam_step_f32(h->w_opt, h->dw, h->m, h->v, nw, step, c.lr, c.beta1, c.beta2, c.eps, stream))) return rc;
+    }
+    if ((rc = la_broadcast_mix(h->w_opt, w0, w_aug_out, B, h->num_ws, wd, c.alpha, c.soft_aug, stream))) return rc;
+    if ((rc = la_synth_forward(h->g, w_aug_out, (long)h->num_ws * wd, wd, B, c.final_noise_mode, final_noises, img_out, stream)))
+        return rc;
+    if (losses_out && c.steps > 0)
+        LA_HIP(hipMemcpyAsync(losses_out, h->losses, (size_t)c.steps * 4 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    return LA_OK;
+}

@@ -1,0 +1,110 @@
+// Modulated 3x3 convolution of a SynthesisLayer, forward and backward-to-(input, style), composed from the
+// implicit-GEMM contraction (la_conv.hip) and the FIR kernels (la_upfirdn2d.hip).
+// Reference semantics: SG2 `modulated_conv2d` + `bias_act` inside SynthesisLayer.forward, with the
+// resampling algebra of models/stylegan3/torch_utils/ops/conv2d_resample.py:82-86,112-134 (Appendix B).
+#include "la_modconv.h"
+
+#include <math.h>
+#include <string.h>
+
+#include "la_conv.h"
+#include "la_upfirdn2d.h"
+
+static void base_args(LaConvArgs& a) {
+    memset(&a, 0, sizeof(a));
+    a.in_sy = a.in_sx = a.out_sy = a.out_sx = 1;
+    a.clamp = -1.f; a.gain = 1.f; a.act = LA_ACT_LINEAR;
+}
+
+extern "C" int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps,
+                                        hipStream_t stream) {
+    return la_pack_conv_weights(w, wf, wb, wsq, cout, cin, ktaps, stream);
+}
+
+extern "C" int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const float* s, int s_stride,
+                                     const float* d, int d_stride, const float* noise, long noise_bstride,
+                                     float noise_strength, const float* bias, int act, float alpha, float gain,
+                                     float clamp, float* y, int B, int cin, int cout, int res, hipStream_t stream) {
+    LA_CHECK_ARG(x && wf && y, "modconv_fwd: null pointer");
+    LaConvArgs a; base_args(a);
+    a.in = x; a.in_bstride = x_bstride; a.wgt = wf; a.out = y;
+    a.in_scale = s; a.scale_stride = s_stride;
+    a.B = B; a.C = cin; a.M = cout; a.Hin = a.Win = a.Hout = a.Wout = a.Gy = a.Gx = res;
+    a.ntaps = 9;
+    for (int t = 0; t < 9; ++t) { a.tap_dy[t] = t / 3 - 1; a.tap_dx[t] = t % 3 - 1; a.tap_w[t] = t; }
+    a.epi = LA_EPI_FWD;
+    a.demod = d; a.demod_stride = d_stride;
+    a.noise = noise; a.noise_bstride = noise_bstride; a.noise_strength = noise_strength;
+    a.bias = bias; a.act = act; a.alpha = alpha; a.gain = gain; a.clamp = clamp;
+    return la_conv_launch(a, stream);
+}
+
+extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const float* s, int s_stride,
+                                         const float* d, int d_stride, const float* noise, long noise_bstride,
+                                         float noise_strength, const float* bias, int act, float alpha, float gain,
+                                         float clamp, const float* fir_host, float* scratch, float* y, int B, int cin,
+                                         int cout, int res, hipStream_t stream) {
+    LA_CHECK_ARG(x && wf && y && scratch && fir_host, "modconv_up2_fwd: null pointer");
+    LA_CHECK_ARG(res >= 2 && res % 2 == 0, "modconv_up2_fwd: output resolution must be even");
+    // transposed stride-2 conv as 4 output phases: row Y = 2*qy + py receives taps ky with (Y - ky) even
+    const int hin = res / 2;
+    LaConvArgs a; base_args(a);
+    a.in = x; a.in_bstride = x_bstride; a.wgt = wf; a.out = scratch;
+    a.in_scale = s; a.scale_stride = s_stride;
+    a.B = B; a.C = cin; a.M = cout; a.Hin = a.Win = hin; a.Hout = a.Wout = res + 1;
+    a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            a.out_oy = py; a.out_ox = px;
+            a.Gy = py ? hin : hin + 1; a.Gx = px ? hin : hin + 1;
+            int nt = 0;
+            for (int ky = py; ky < 3; ky += 2)
+                for (int kx = px; kx < 3; kx += 2) {
+                    a.tap_dy[nt] = -(ky / 2); a.tap_dx[nt] = -(kx / 2); a.tap_w[nt] = ky * 3 + kx; ++nt;
+                }
+            a.ntaps = nt;
+            int rc = la_conv_launch(a, stream);
+            if (rc) return rc;
+        }
+    // FIR with pad (1,1,1,1) and gain up^2 = 4 (conv2d_resample.py:119-126), then the layer epilogue
+    return la_upfirdn2d_modconv_epilogue(scratch, y, B, cout, res + 1, res + 1, fir_host, 4, 4, 1, 1, 1, 1, 4.f, d, d_stride,
+                                         noise, noise_bstride, noise_strength, bias, act, alpha, gain, clamp, stream);
+}
+
+extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const float* s, int s_stride, const float* xin,
+                                     long xin_bstride, float* gx, float* ds_part, int B, int cin, int cout, int res,
+                                     hipStream_t stream) {
+    LA_CHECK_ARG(gz && wb && gx, "modconv_bwd: null pointer");
+    LaConvArgs a; base_args(a);
+    a.in = gz; a.in_bstride = (long)cout * res * res; a.wgt = wb; a.out = gx;
+    a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = a.Hout = a.Wout = a.Gy = a.Gx = res;
+    a.ntaps = 9;
+    for (int t = 0; t < 9; ++t) { a.tap_dy[t] = 1 - t / 3; a.tap_dx[t] = 1 - t % 3; a.tap_w[t] = t; }
+    a.epi = LA_EPI_BWD;
+    a.out_scale = s; a.oscale_stride = s_stride;
+    a.xin = xin; a.xin_bstride = xin_bstride;
+    a.ds_part = ds_part; a.tiles_per_sample = la_conv_tiles_per_sample(res, res);
+    return la_conv_launch(a, stream);
+}
+
+extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const float* s, int s_stride, const float* xin,
+                                         long xin_bstride, const float* fir_host, float* scratch, float* gx,
+                                         float* ds_part, int B, int cin, int cout, int res, hipStream_t stream) {
+    LA_CHECK_ARG(gz && wb && gx && scratch && fir_host, "modconv_up2_bwd: null pointer");
+    const int hin = res / 2;
+    // adjoint of [pad (1,1,1,1) -> FIR]: pad fw-1-pad = 2 per side, flipped filter, same gain (upfirdn2d.py:255-266)
+    int rc = la_upfirdn2d_ex(gz, scratch, B, cout, res, res, fir_host, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, 1, 4.f, nullptr, stream);
+    if (rc) return rc;
+    LaConvArgs a; base_args(a);
+    a.in = scratch; a.in_bstride = (long)cout * (res + 1) * (res + 1); a.wgt = wb; a.out = gx;
+    a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = res + 1; a.Hout = a.Wout = a.Gy = a.Gx = hin;
+    a.in_sy = a.in_sx = 2; a.ntaps = 9;
+    for (int t = 0; t < 9; ++t) { a.tap_dy[t] = t / 3; a.tap_dx[t] = t % 3; a.tap_w[t] = t; }
+    a.epi = LA_EPI_BWD;
+    a.out_scale = s; a.oscale_stride = s_stride;
+    a.xin = xin; a.xin_bstride = xin_bstride;
+    a.ds_part = ds_part; a.tiles_per_sample = la_conv_tiles_per_sample(hin, hin);
+    return la_conv_launch(a, stream);
+}
+
+extern "C" int la_modconv_ds_tiles(int grid_res) { return la_conv_tiles_per_sample(grid_res, grid_res); }

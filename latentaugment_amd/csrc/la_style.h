@@ -1,0 +1,62 @@
+// Internal (C++) interface of la_style.hip.
+#pragma once
+#include "la_common.h"
+
+#define LA_MAX_STYLE_LAYERS 40
+
+// One row block per affine layer (conv layers first, then ToRGB layers); rows = that layer's in_channels.
+struct LaStyleTable {
+    int nlayers;
+    int total_rows;
+    int row_start[LA_MAX_STYLE_LAYERS + 1];   // row_start[nlayers] == total_rows
+    int widx[LA_MAX_STYLE_LAYERS];            // which w of ws[b][.] feeds the layer
+    float post_gain[LA_MAX_STYLE_LAYERS];     // 1 for conv layers, 1/sqrt(cin) for ToRGB (weight_gain folded into the style)
+    const float* aw[LA_MAX_STYLE_LAYERS];     // affine.weight [cin][wdim]
+    const float* ab[LA_MAX_STYLE_LAYERS];     // affine.bias   [cin]
+};
+
+struct LaDemodTable {
+    int nlayers;
+    int total_rows;
+    int row_start[LA_MAX_STYLE_LAYERS + 1];
+    int cin[LA_MAX_STYLE_LAYERS];
+    int s_off[LA_MAX_STYLE_LAYERS];           // offset of the layer's styles inside a row of s_all
+    const float* wsq[LA_MAX_STYLE_LAYERS];    // [cout][cin]
+};
+
+struct LaSeamArgs {
+    const float* y;          // [B][C][HW] saved post-activation output of the layer
+    const float* gx_next;    // [B][C][HW] or null
+    float* gz;               // [B][C][HW] (may alias gx_next)
+    long HW;
+    int C;
+    const float* demod; int demod_stride;
+    const float* bias;
+    const float* noise; long noise_bstride; float noise_strength;
+    int act; float alpha, gain, clamp;
+    float* ddn_part;         // [B][C][slabs]
+    // ToRGB part (imgc > 0)
+    const float* g_img;      // [B][imgc][HW] gradient w.r.t. the image at this resolution
+    const float* rgb_pre;    // [B][imgc][HW] ToRGB output before its clamp
+    float rgb_clamp;
+    const float* wrgb;       // [imgc][C]
+    const float* s_rgb; int s_stride;   // styles of the ToRGB layer (already * weight_gain)
+    float* dweff_part;       // [B][imgc][C][slabs]
+};
+
+int la_pack_conv_weights(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps, hipStream_t);
+int la_affine_forward(const LaStyleTable& t, const float* ws, long ws_bstride, long ws_lstride, int B, int wdim,
+                      float* s_all, hipStream_t);
+int la_demod_forward(const LaDemodTable& t, const float* s_all, int s_stride, int B, float* d_all, hipStream_t);
+int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_stride, const float* bias,
+                     const float* skip, float* rgb_pre, float* img, int B, int C, int imgc, int H, int W, float clamp,
+                     hipStream_t);
+int la_seam_slabs(long HW);
+int la_seam_backward(const LaSeamArgs& a, int B, int imgc, hipStream_t);
+int la_style_backward_conv(const float* ds_part, int ntiles, const float* ddn_part, int nslabs, const float* d,
+                           int d_stride, const float* s, int s_stride, const float* wsq, int cin, int cout, int B,
+                           float* ds_out, int ds_stride, hipStream_t);
+int la_style_backward_rgb(const float* dweff_part, int nslabs, const float* wrgb, int C, int imgc, int B,
+                          float* ds_out, int ds_stride, hipStream_t);
+int la_affine_backward(const LaStyleTable& t, const float* ds_all, int B, int wdim, float* dws, int num_ws,
+                       hipStream_t);

@@ -1,0 +1,365 @@
+// Small kernels around the modulated convolutions of the SG2 synthesis pass:
+//   weight packing (once per generator), affine (style) FC forward/backward over all layers in one launch,
+//   demodulation coefficients, ToRGB forward (+skip add), the backward "seam" kernel that fuses
+//   ToRGB-backward + bias_act-backward + demod-gradient reductions, and the style-gradient finish.
+// All are HBM- or latency-bound; the contraction work lives in la_conv.hip.
+#include "la_style.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// weight packing:  W[o][i][ky][kx]  ->  wf[t][i][o], wb[t][o][i], wsq[o][i] = sum_t W^2      (t = ky*3+kx)
+__global__ void la_pack_conv_kernel(const float* __restrict__ w, float* wf, float* wb, float* wsq, int cout, int cin,
+                                    int ktaps) {
+    const long n = (long)cout * cin;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(idx / cin), i = (int)(idx - (long)o * cin);
+        float sq = 0.f;
+        for (int t = 0; t < ktaps; ++t) {
+            const float v = w[idx * ktaps + t];
+            sq += v * v;
+            if (wf) wf[((long)t * cin + i) * cout + o] = v;
+            if (wb) wb[((long)t * cout + o) * cin + i] = v;
+        }
+        if (wsq) wsq[idx] = sq;
+    }
+}
+
+int la_pack_conv_weights(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps,
+                         hipStream_t stream) {
+    LA_CHECK_ARG(w && cout > 0 && cin > 0 && ktaps > 0, "pack: bad args");
+    const long n = (long)cout * cin;
+    hipLaunchKernelGGL(la_pack_conv_kernel, dim3(la_cdiv(n, 256) < 4096 ? la_cdiv(n, 256) : 4096), dim3(256), 0, stream,
+                       w, wf, wb, wsq, cout, cin, ktaps);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// affine forward: s[b][row] = (dot(ws[b][widx_l], A_l[i]) * wgain + ab_l[i]) * post_gain_l      one wave per row
+#define BCH 8
+__global__ __launch_bounds__(256) void la_affine_fwd_kernel(LaStyleTable t, const float* __restrict__ ws,
+                                                           long ws_bstride, long ws_lstride, int B, int wdim,
+                                                           float wgain, float* __restrict__ s_all) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= t.total_rows) return;
+    int l = 0;
+    while (l + 1 < t.nlayers && row >= t.row_start[l + 1]) ++l;
+    const int i = row - t.row_start[l];
+    const float* arow = t.aw[l] + (long)i * wdim;
+    const float ab = t.ab[l][i];
+    for (int b0 = 0; b0 < B; b0 += BCH) {
+        float acc[BCH];
+#pragma unroll
+        for (int q = 0; q < BCH; ++q) acc[q] = 0.f;
+        for (int j = lane; j < wdim; j += 64) {
+            const float av = arow[j];
+#pragma unroll
+            for (int q = 0; q < BCH; ++q)
+                if (b0 + q < B) acc[q] += av * ws[(long)(b0 + q) * ws_bstride + (long)t.widx[l] * ws_lstride + j];
+        }
+#pragma unroll
+        for (int q = 0; q < BCH; ++q) {
+            const float v = la_wave_sum(acc[q]);
+            if (lane == 0 && b0 + q < B) s_all[(long)(b0 + q) * t.total_rows + row] = (v * wgain + ab) * t.post_gain[l];
+        }
+    }
+}
+
+int la_affine_forward(const LaStyleTable& t, const float* ws, long ws_bstride, long ws_lstride, int B, int wdim,
+                      float* s_all, hipStream_t stream) {
+    hipLaunchKernelGGL(la_affine_fwd_kernel, dim3(la_cdiv(t.total_rows, 4)), dim3(256), 0, stream, t, ws, ws_bstride,
+                       ws_lstride, B, wdim, 1.0f / sqrtf((float)wdim), s_all);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// demod: d[b][doff_l + o] = rsqrt(sum_i s[b][soff_l+i]^2 * wsq_l[o][i] + 1e-8)          one wave per (l, o)
+__global__ __launch_bounds__(256) void la_demod_kernel(LaDemodTable t, const float* __restrict__ s_all, int s_stride,
+                                                      int B, float* __restrict__ d_all) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= t.total_rows) return;
+    int l = 0;
+    while (l + 1 < t.nlayers && row >= t.row_start[l + 1]) ++l;
+    const int o = row - t.row_start[l];
+    const int cin = t.cin[l];
+    const float* wrow = t.wsq[l] + (long)o * cin;
+    for (int b0 = 0; b0 < B; b0 += BCH) {
+        float acc[BCH];
+#pragma unroll
+        for (int q = 0; q < BCH; ++q) acc[q] = 0.f;
+        for (int i = lane; i < cin; i += 64) {
+            const float wv = wrow[i];
+#pragma unroll
+            for (int q = 0; q < BCH; ++q)
+                if (b0 + q < B) {
+                    const float sv = s_all[(long)(b0 + q) * s_stride + t.s_off[l] + i];
+                    acc[q] += sv * sv * wv;
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < BCH; ++q) {
+            const float v = la_wave_sum(acc[q]);
+            if (lane == 0 && b0 + q < B) d_all[(long)(b0 + q) * t.total_rows + row] = rsqrtf(v + 1e-8f);
+        }
+    }
+}
+
+int la_demod_forward(const LaDemodTable& t, const float* s_all, int s_stride, int B, float* d_all,
+                     hipStream_t stream) {
+    hipLaunchKernelGGL(la_demod_kernel, dim3(la_cdiv(t.total_rows, 4)), dim3(256), 0, stream, t, s_all, s_stride, B,
+                       d_all);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// ToRGB forward (+ skip add):  rgb_pre[b][c][p] = sum_i wrgb[c][i] * s[b][i] * x[b][i][p] + bias[c]
+//                              img[b][c][p]     = clamp(rgb_pre) + (skip ? skip[b][c][p] : 0)
+// Streams x once (HBM-bound); lanes = consecutive pixels, 4 pixels per thread (float4).
+template <int IMGC>
+__global__ __launch_bounds__(256) void la_torgb_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wrgb,
+                                                          const float* __restrict__ s, int s_stride,
+                                                          const float* __restrict__ bias, const float* __restrict__ skip,
+                                                          float* __restrict__ rgb_pre, float* __restrict__ img, int C,
+                                                          long HW, float clamp) {
+    extern __shared__ float weff[];   // [IMGC][C]
+    const int b = blockIdx.y;
+    for (int k = threadIdx.x; k < IMGC * C; k += blockDim.x) {
+        const int i = k % C;
+        weff[k] = wrgb[k] * s[(long)b * s_stride + i];
+    }
+    __syncthreads();
+    const long p4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (p4 >= HW) return;
+    const float* xb = x + (long)b * C * HW + p4;
+    float4 acc[IMGC];
+#pragma unroll
+    for (int c = 0; c < IMGC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int i = 0; i < C; ++i) {
+        const float4 xv = *reinterpret_cast<const float4*>(xb + (long)i * HW);
+#pragma unroll
+        for (int c = 0; c < IMGC; ++c) {
+            const float wv = weff[c * C + i];
+            acc[c].x += wv * xv.x; acc[c].y += wv * xv.y; acc[c].z += wv * xv.z; acc[c].w += wv * xv.w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < IMGC; ++c) {
+        const float bv = bias ? bias[c] : 0.f;
+        float4 v = make_float4(acc[c].x + bv, acc[c].y + bv, acc[c].z + bv, acc[c].w + bv);
+        const long o = ((long)b * IMGC + c) * HW + p4;
+        if (rgb_pre) *reinterpret_cast<float4*>(rgb_pre + o) = v;
+        if (clamp >= 0.f) {
+            v.x = fminf(fmaxf(v.x, -clamp), clamp); v.y = fminf(fmaxf(v.y, -clamp), clamp);
+            v.z = fminf(fmaxf(v.z, -clamp), clamp); v.w = fminf(fmaxf(v.w, -clamp), clamp);
+        }
+        if (skip) {
+            const float4 sv = *reinterpret_cast<const float4*>(skip + o);
+            v.x += sv.x; v.y += sv.y; v.z += sv.z; v.w += sv.w;
+        }
+        *reinterpret_cast<float4*>(img + o) = v;
+    }
+}
+
+int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_stride, const float* bias,
+                     const float* skip, float* rgb_pre, float* img, int B, int C, int imgc, int H, int W, float clamp,
+                     hipStream_t stream) {
+    const long HW = (long)H * W;
+    LA_CHECK_ARG(HW % 4 == 0, "torgb: H*W must be a multiple of 4");
+    LA_CHECK_ARG(imgc >= 1 && imgc <= 4, "torgb: img_channels must be 1..4");
+    dim3 grid(la_cdiv(HW / 4, 256), B);
+    const size_t lds = (size_t)imgc * C * sizeof(float);
+#define LAUNCH(N) hipLaunchKernelGGL(la_torgb_fwd_kernel<N>, grid, dim3(256), lds, stream, x, wrgb, s, s_stride, bias, skip, rgb_pre, img, C, HW, clamp)
+    switch (imgc) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
+#undef LAUNCH
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Backward seam for one SynthesisLayer output y[b][c][p] (post-activation, saved by the forward):
+//   g      = gx_next (gradient from the consumer conv, optional)  +  sum_k weff[b][k][c] * g_rgb[b][k][p]   (ToRGB, optional)
+//   dweff[b][k][c] += sum_p g_rgb[b][k][p] * y                                            (ToRGB weight/style gradient)
+//   g1     = g * act'(y)                                                                  (bias_act backward from the saved output)
+//   ddn[b][c]      += sum_p g1 * (act^-1(y) - bias[c] - noise[p]*ns)                      (= dL/d(demod) * demod)
+//   gz     = g1 * demod[b][c]                                                             (gradient w.r.t. the raw contraction)
+// One workgroup per (slab, c, b); partial sums go to [.. ][slab] buffers (deterministic, no atomics).
+template <int IMGC>
+__global__ __launch_bounds__(256) void la_seam_bwd_kernel(LaSeamArgs a) {
+    __shared__ float red[4];
+    const int c = blockIdx.y, b = blockIdx.z, slab = blockIdx.x;
+    const long HW = a.HW;
+    const long per = (HW / 4 + gridDim.x - 1) / gridDim.x;   // float4 groups per slab
+    const long q0 = slab * per, q1 = (q0 + per < HW / 4) ? q0 + per : HW / 4;
+    const long plane = ((long)b * a.C + c) * HW;
+    const float dm = a.demod ? a.demod[(long)b * a.demod_stride + c] : 1.f;
+    const float bv = a.bias ? a.bias[c] : 0.f;
+    float weff[IMGC > 0 ? IMGC : 1];
+#pragma unroll
+    for (int k = 0; k < IMGC; ++k) weff[k] = a.wrgb[k * a.C + c] * a.s_rgb[(long)b * a.s_stride + c];
+    float ddn = 0.f;
+    float dwe[IMGC > 0 ? IMGC : 1];
+#pragma unroll
+    for (int k = 0; k < IMGC; ++k) dwe[k] = 0.f;
+
+    for (long q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
+        const long p = q * 4;
+        const float4 yv = *reinterpret_cast<const float4*>(a.y + plane + p);
+        float4 g = a.gx_next ? *reinterpret_cast<const float4*>(a.gx_next + plane + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < IMGC; ++k) {
+            const long o = ((long)b * IMGC + k) * HW + p;
+            float4 gr = *reinterpret_cast<const float4*>(a.g_img + o);
+            if (a.rgb_clamp >= 0.f) {
+                const float4 rp = *reinterpret_cast<const float4*>(a.rgb_pre + o);
+                // torch clamp backward passes the gradient where -c <= v <= c
+                if (fabsf(rp.x) > a.rgb_clamp) gr.x = 0.f;
+                if (fabsf(rp.y) > a.rgb_clamp) gr.y = 0.f;
+                if (fabsf(rp.z) > a.rgb_clamp) gr.z = 0.f;
+                if (fabsf(rp.w) > a.rgb_clamp) gr.w = 0.f;
+            }
+            g.x += weff[k] * gr.x; g.y += weff[k] * gr.y; g.z += weff[k] * gr.z; g.w += weff[k] * gr.w;
+            dwe[k] += gr.x * yv.x + gr.y * yv.y + gr.z * yv.z + gr.w * yv.w;
+        }
+        float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.noise) {
+            nz = *reinterpret_cast<const float4*>(a.noise + (long)b * a.noise_bstride + p);
+            nz.x *= a.noise_strength; nz.y *= a.noise_strength; nz.z *= a.noise_strength; nz.w *= a.noise_strength;
+        }
+        float4 gz;
+#define ONE(f)                                                                               \
+        {                                                                                    \
+            const float g1 = g.f * la_act_bwd_from_y(yv.f, a.act, a.alpha, a.gain, a.clamp); \
+            ddn += g1 * (la_act_inv(yv.f, a.act, a.alpha, a.gain) - bv - nz.f);              \
+            gz.f = g1 * dm;                                                                  \
+        }
+        ONE(x) ONE(y) ONE(z) ONE(w)
+#undef ONE
+        *reinterpret_cast<float4*>(a.gz + plane + p) = gz;
+    }
+    const float ddn_t = la_block_sum_256(ddn, red);
+    if (threadIdx.x == 0 && a.ddn_part) a.ddn_part[((long)b * a.C + c) * gridDim.x + slab] = ddn_t;
+#pragma unroll
+    for (int k = 0; k < IMGC; ++k) {
+        const float t = la_block_sum_256(dwe[k], red);
+        if (threadIdx.x == 0) a.dweff_part[(((long)b * IMGC + k) * a.C + c) * gridDim.x + slab] = t;
+    }
+}
+
+int la_seam_slabs(long HW) {
+    long s = HW / 16384;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+
+int la_seam_backward(const LaSeamArgs& a, int B, int imgc, hipStream_t stream) {
+    LA_CHECK_ARG(a.HW % 4 == 0, "seam: H*W must be a multiple of 4");
+    LA_CHECK_ARG(imgc >= 0 && imgc <= 4, "seam: img_channels must be 0..4");
+    dim3 grid(la_seam_slabs(a.HW), a.C, B);
+#define LAUNCH(N) hipLaunchKernelGGL(la_seam_bwd_kernel<N>, grid, dim3(256), 0, stream, a)
+    switch (imgc) { case 0: LAUNCH(0); break; case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
+#undef LAUNCH
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// style-gradient finish for one conv layer:
+//   ds[b][i] = sum_tiles ds_part[b][i][.]  -  s[b][i] * sum_o (sum_slabs ddn_part[b][o][.]) * d[b][o]^2 * wsq[o][i]
+// one thread per i (coalesced wsq reads over i), loop over o; q[b][o] staged in LDS.
+__global__ __launch_bounds__(256) void la_style_bwd_conv_kernel(const float* __restrict__ ds_part, int ntiles,
+                                                               const float* __restrict__ ddn_part, int nslabs,
+                                                               const float* __restrict__ d, int d_stride,
+                                                               const float* __restrict__ s, int s_stride,
+                                                               const float* __restrict__ wsq, int cin, int cout,
+                                                               float* __restrict__ ds_out, int ds_stride) {
+    extern __shared__ float q[];   // [cout]
+    const int b = blockIdx.y;
+    for (int o = threadIdx.x; o < cout; o += blockDim.x) {
+        float v = 0.f;
+        for (int k = 0; k < nslabs; ++k) v += ddn_part[((long)b * cout + o) * nslabs + k];
+        const float dv = d[(long)b * d_stride + o];
+        q[o] = v * dv * dv;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cin) return;
+    float acc = 0.f;
+    for (int o = 0; o < cout; ++o) acc += q[o] * wsq[(long)o * cin + i];
+    float dsm = 0.f;
+    for (int k = 0; k < ntiles; ++k) dsm += ds_part[((long)b * cin + i) * ntiles + k];
+    ds_out[(long)b * ds_stride + i] = dsm - s[(long)b * s_stride + i] * acc;
+}
+
+int la_style_backward_conv(const float* ds_part, int ntiles, const float* ddn_part, int nslabs, const float* d,
+                           int d_stride, const float* s, int s_stride, const float* wsq, int cin, int cout, int B,
+                           float* ds_out, int ds_stride, hipStream_t stream) {
+    hipLaunchKernelGGL(la_style_bwd_conv_kernel, dim3(la_cdiv(cin, 256), B), dim3(256), cout * sizeof(float), stream,
+                       ds_part, ntiles, ddn_part, nslabs, d, d_stride, s, s_stride, wsq, cin, cout, ds_out, ds_stride);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
+// ToRGB style gradient: ds[b][i] = sum_k wrgb[k][i] * sum_slabs dweff_part[b][k][i][.]
+__global__ void la_style_bwd_rgb_kernel(const float* __restrict__ dweff_part, int nslabs, const float* __restrict__ wrgb,
+                                        int C, int imgc, float* __restrict__ ds_out, int ds_stride) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    float acc = 0.f;
+    for (int k = 0; k < imgc; ++k) {
+        float v = 0.f;
+        for (int t = 0; t < nslabs; ++t) v += dweff_part[(((long)b * imgc + k) * C + i) * nslabs + t];
+        acc += v * wrgb[k * C + i];
+    }
+    ds_out[(long)b * ds_stride + i] = acc;
+}
+
+int la_style_backward_rgb(const float* dweff_part, int nslabs, const float* wrgb, int C, int imgc, int B,
+                          float* ds_out, int ds_stride, hipStream_t stream) {
+    hipLaunchKernelGGL(la_style_bwd_rgb_kernel, dim3(la_cdiv(C, 256), B), dim3(256), 0, stream, dweff_part, nslabs,
+                       wrgb, C, imgc, ds_out, ds_stride);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// affine backward: dws[b][slot][j] = wgain * sum_{l: widx_l == slot} post_gain_l * sum_i ds[b][row_l + i] * A_l[i][j]
+// one thread per j; grid (wdim/256, num_ws, ceil(B/BCH)).
+__global__ __launch_bounds__(256) void la_affine_bwd_kernel(LaStyleTable t, const float* __restrict__ ds_all, int B,
+                                                           int wdim, float wgain, float* __restrict__ dws, int num_ws) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = blockIdx.y;
+    const int b0 = blockIdx.z * BCH;
+    if (j >= wdim) return;
+    float acc[BCH];
+#pragma unroll
+    for (int q = 0; q < BCH; ++q) acc[q] = 0.f;
+    for (int l = 0; l < t.nlayers; ++l) {
+        if (t.widx[l] != slot) continue;
+        const int rows = t.row_start[l + 1] - t.row_start[l];
+        const float pg = t.post_gain[l];
+        const float* A = t.aw[l];
+        for (int i = 0; i < rows; ++i) {
+            const float av = A[(long)i * wdim + j] * pg;
+#pragma unroll
+            for (int q = 0; q < BCH; ++q)
+                if (b0 + q < B) acc[q] += av * ds_all[(long)(b0 + q) * t.total_rows + t.row_start[l] + i];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < BCH; ++q)
+        if (b0 + q < B) dws[((long)(b0 + q) * num_ws + slot) * wdim + j] = acc[q] * wgain;
+}
+
+int la_affine_backward(const LaStyleTable& t, const float* ds_all, int B, int wdim, float* dws, int num_ws,
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(la_affine_bwd_kernel, dim3(la_cdiv(wdim, 256), num_ws, la_cdiv(B, BCH)), dim3(256), 0, stream, t,
+                       ds_all, B, wdim, 1.0f / sqrtf((float)wdim), dws, num_ws);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}

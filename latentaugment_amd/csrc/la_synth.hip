@@ -1,0 +1,359 @@
+// StyleGAN2 synthesis network (architecture 'skip') forward + backward-to-latent as a sequence of HIP launches.
+// Mirrors the call  G.synthesis(ws, noise_mode=...)  at augments/utils/util_latent_aug.py:227,488 and the autograd
+// backward of it that loss.backward() at :275 performs, restricted to d/d(ws) (G is frozen: :480).
+// Formulation: non-fused modulated conv (x*s -> shared-weight contraction -> *demod), see DESIGN.md.
+#include "la_synth.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "la_conv.h"
+#include "la_modconv.h"
+#include "la_style.h"
+#include "la_upfirdn2d.h"
+
+#define MAX_BLOCKS 12
+
+struct ConvLayer {
+    int cin, cout, res, up, widx;
+    const float *affine_w, *affine_b, *weight, *bias, *noise_const;
+    float noise_strength;
+    float *wf, *wb, *wsq;   // packed
+    float* y;               // saved output [maxB][cout][res*res]
+    int s_off, d_off, style_idx;
+    const float* noise_used;   // set by forward (null when the term vanishes)
+    long noise_bstride;
+};
+
+struct RgbLayer {
+    int cin, res, widx;
+    const float *affine_w, *affine_b, *weight, *bias;
+    int s_off, style_idx;
+    float *rgb_pre, *img, *g_img;
+};
+
+struct la_synth {
+    int R, imgc, wdim, nblocks, num_ws, maxB;
+    int channels[MAX_BLOCKS];
+    float clamp;
+    const float* cst;   // b4.const [C4][4][4]
+    int nconv;
+    ConvLayer conv[2 * MAX_BLOCKS];
+    RgbLayer rgb[MAX_BLOCKS];
+    float fir[16];
+    LaStyleTable st;
+    LaDemodTable dt;
+    int S, Dt;
+    float *s_all, *d_all, *ds_all;
+    float *zT, *G0, *G1, *ds_part, *ddn_part, *dweff_part;
+    int lastB;
+    float* final_img;   // where the last forward put the full-resolution image
+};
+
+static size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }
+
+struct Carver {
+    char* base; size_t off; size_t cap;
+    float* take(size_t nfloats) {
+        size_t bytes = align_up(nfloats * sizeof(float));
+        float* p = base ? (float*)(base + off) : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
+    Carver c{(char*)workspace, 0, cap};
+    const size_t mb = h->maxB;
+    size_t gmax = 0, ztmax = 0, dsp = 0, ddn = 0, dwe = 0;
+    for (int k = 0; k < h->nconv; ++k) {
+        ConvLayer& L = h->conv[k];
+        const size_t wn = (size_t)L.cin * L.cout;
+        L.wf = c.take(9 * wn); L.wb = c.take(9 * wn); L.wsq = c.take(wn);
+        const size_t hw = (size_t)L.res * L.res;
+        L.y = c.take(mb * L.cout * hw);
+        if (mb * L.cout * hw > gmax) gmax = mb * L.cout * hw;
+        if (mb * L.cin * hw > gmax && !L.up) gmax = mb * L.cin * hw;
+        if (L.up) {
+            const size_t z = mb * L.cout * (size_t)(L.res + 1) * (L.res + 1);
+            if (z > ztmax) ztmax = z;
+        }
+        const int gin = L.up ? L.res / 2 : L.res;   // grid of the backward-data conv
+        const size_t t = mb * L.cin * (size_t)la_conv_tiles_per_sample(gin, gin);
+        if (t > dsp) dsp = t;
+        const size_t sl = mb * L.cout * (size_t)la_seam_slabs((long)hw);
+        if (sl > ddn) ddn = sl;
+    }
+    for (int k = 0; k < h->nblocks; ++k) {
+        RgbLayer& T = h->rgb[k];
+        const size_t hw = (size_t)T.res * T.res;
+        T.rgb_pre = c.take(mb * h->imgc * hw);
+        T.img = c.take(mb * h->imgc * hw);
+        T.g_img = c.take(mb * h->imgc * hw);
+        const size_t sl = mb * h->imgc * T.cin * (size_t)la_seam_slabs((long)hw);
+        if (sl > dwe) dwe = sl;
+    }
+    h->s_all = c.take(mb * h->S);
+    h->ds_all = c.take(mb * h->S);
+    h->d_all = c.take(mb * h->Dt);
+    h->zT = c.take(ztmax);
+    h->G0 = c.take(gmax);
+    h->G1 = c.take(gmax);
+    h->ds_part = c.take(dsp);
+    h->ddn_part = c.take(ddn);
+    h->dweff_part = c.take(dwe);
+    *need = c.off;
+    return LA_OK;
+}
+
+static int describe(la_synth* h, int R, int imgc, int wdim, const int* channels, int maxB) {
+    LA_CHECK_ARG(R >= 4 && (R & (R - 1)) == 0 && R <= 4096, "synth: resolution must be a power of two >= 4");
+    LA_CHECK_ARG(imgc >= 1 && imgc <= 4, "synth: img_channels must be 1..4");
+    LA_CHECK_ARG(wdim >= 1 && maxB >= 1, "synth: bad w_dim / batch");
+    memset(h, 0, sizeof(*h));
+    h->R = R; h->imgc = imgc; h->wdim = wdim; h->maxB = maxB;
+    int nb = 0;
+    for (int r = 4; r <= R; r *= 2) ++nb;
+    LA_CHECK_ARG(nb <= MAX_BLOCKS, "synth: too many blocks");
+    h->nblocks = nb;
+    int nconv = 0, widx = 0, S = 0, Dt = 0, nst = 0;
+    for (int k = 0; k < nb; ++k) {
+        const int res = 4 << k;
+        const int co = channels[k];
+        LA_CHECK_ARG(co >= 4 && co % 4 == 0, "synth: channel counts must be multiples of 4");
+        h->channels[k] = co;
+        if (k > 0) {
+            ConvLayer& L = h->conv[nconv++];
+            L.cin = channels[k - 1]; L.cout = co; L.res = res; L.up = 1; L.widx = widx++;
+        }
+        ConvLayer& L1 = h->conv[nconv++];
+        L1.cin = co; L1.cout = co; L1.res = res; L1.up = 0; L1.widx = widx++;
+        RgbLayer& T = h->rgb[k];
+        T.cin = co; T.res = res; T.widx = widx;   // shares its w with the next block's conv0
+    }
+    h->nconv = nconv;
+    h->num_ws = widx + 1;
+    LA_CHECK_ARG(nconv + nb <= LA_MAX_STYLE_LAYERS, "synth: too many style layers");
+    // style rows: conv layers then rgb layers
+    for (int k = 0; k < nconv; ++k) {
+        ConvLayer& L = h->conv[k];
+        L.s_off = S; L.d_off = Dt; L.style_idx = nst;
+        h->st.row_start[nst] = S; h->st.widx[nst] = L.widx; h->st.post_gain[nst] = 1.f;
+        h->dt.row_start[k] = Dt; h->dt.cin[k] = L.cin; h->dt.s_off[k] = S;
+        S += L.cin; Dt += L.cout; ++nst;
+    }
+    for (int k = 0; k < nb; ++k) {
+        RgbLayer& T = h->rgb[k];
+        T.s_off = S; T.style_idx = nst;
+        h->st.row_start[nst] = S; h->st.widx[nst] = T.widx; h->st.post_gain[nst] = 1.f / sqrtf((float)T.cin);
+        S += T.cin; ++nst;
+    }
+    h->st.nlayers = nst; h->st.total_rows = S; h->st.row_start[nst] = S;
+    h->dt.nlayers = nconv; h->dt.total_rows = Dt; h->dt.row_start[nconv] = Dt;
+    h->S = S; h->Dt = Dt;
+    return LA_OK;
+}
+
+extern "C" int la_synth_num_ws(int img_resolution) {
+    int nb = 0;
+    for (int r = 4; r <= img_resolution; r *= 2) ++nb;
+    return 2 * nb;   // 2*log2(R) - 2
+}
+
+extern "C" int la_synth_num_params(int img_resolution) {
+    int nb = 0;
+    for (int r = 4; r <= img_resolution; r *= 2) ++nb;
+    return 1 + 5 + 4 + (nb - 1) * 14;
+}
+
+extern "C" size_t la_synth_workspace_bytes(int img_resolution, int img_channels, int w_dim, const int* channels,
+                                           int max_batch) {
+    la_synth* h = (la_synth*)malloc(sizeof(la_synth));
+    if (!h) return 0;
+    size_t need = 0;
+    if (describe(h, img_resolution, img_channels, w_dim, channels, max_batch) == LA_OK) layout(h, nullptr, 0, &need);
+    free(h);
+    return need;
+}
+
+extern "C" int la_synth_create(int img_resolution, int img_channels, int w_dim, const int* channels, float conv_clamp,
+                               const float* const* params, int nparams, const float* noise_strength, int nlayers,
+                               const float* fir_host, int fir_h, int fir_w, int max_batch, void* workspace,
+                               size_t workspace_bytes, hipStream_t stream, la_synth** out) {
+    LA_CHECK_ARG(params && noise_strength && fir_host && workspace && out, "synth_create: null pointer");
+    LA_CHECK_ARG(fir_h == 4 && fir_w == 4, "synth_create: resample filter must be 4x4 (setup_filter([1,3,3,1]))");
+    la_synth* h = (la_synth*)malloc(sizeof(la_synth));
+    LA_CHECK_ARG(h, "synth_create: out of host memory");
+    int rc = describe(h, img_resolution, img_channels, w_dim, channels, max_batch);
+    if (rc) { free(h); return rc; }
+    if (nparams != la_synth_num_params(img_resolution) || nlayers != h->nconv) {
+        free(h); la_set_error("synth_create: parameter list length mismatch"); return LA_ERR_ARG;
+    }
+    for (int i = 0; i < nparams; ++i)
+        if (!params[i]) { free(h); la_set_error("synth_create: null parameter tensor"); return LA_ERR_ARG; }
+    size_t need = 0;
+    layout(h, workspace, workspace_bytes, &need);
+    if (need > workspace_bytes) { free(h); la_set_error("synth_create: workspace too small"); return LA_ERR_WORKSPACE; }
+    h->clamp = conv_clamp;
+    memcpy(h->fir, fir_host, sizeof(float) * 16);
+    int p = 0, ci = 0;
+    for (int k = 0; k < h->nblocks; ++k) {
+        if (k == 0) h->cst = params[p++];
+        const int nl = (k == 0) ? 1 : 2;
+        for (int q = 0; q < nl; ++q) {
+            ConvLayer& L = h->conv[ci];
+            L.affine_w = params[p++]; L.affine_b = params[p++]; L.weight = params[p++]; L.bias = params[p++];
+            L.noise_const = params[p++];
+            L.noise_strength = noise_strength[ci];
+            h->st.aw[L.style_idx] = L.affine_w; h->st.ab[L.style_idx] = L.affine_b;
+            h->dt.wsq[ci] = L.wsq;
+            rc = la_pack_conv_weights(L.weight, L.wf, L.wb, L.wsq, L.cout, L.cin, 9, stream);
+            if (rc) { free(h); return rc; }
+            ++ci;
+        }
+        RgbLayer& T = h->rgb[k];
+        T.affine_w = params[p++]; T.affine_b = params[p++]; T.weight = params[p++]; T.bias = params[p++];
+        h->st.aw[T.style_idx] = T.affine_w; h->st.ab[T.style_idx] = T.affine_b;
+    }
+    h->lastB = 0;
+    *out = h;
+    return LA_OK;
+}
+
+extern "C" void la_synth_destroy(la_synth* h) { free(h); }
+
+extern "C" const float* la_synth_image(const la_synth* h) { return h ? h->final_img : nullptr; }
+extern "C" const float* la_synth_block_image(const la_synth* h, int k) { return (h && k >= 0 && k < h->nblocks) ? h->rgb[k].img : nullptr; }
+extern "C" const float* la_synth_layer_output(const la_synth* h, int k) { return (h && k >= 0 && k < h->nconv) ? h->conv[k].y : nullptr; }
+extern "C" const float* la_synth_styles(const la_synth* h) { return h ? h->s_all : nullptr; }
+extern "C" const float* la_synth_style_grads(const la_synth* h) { return h ? h->ds_all : nullptr; }
+extern "C" int la_synth_style_rows(const la_synth* h) { return h ? h->S : 0; }
+
+extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, long ws_lstride, int B, int noise_mode,
+                                const float* const* noises, float* img_out, hipStream_t stream) {
+    LA_CHECK_ARG(h && ws, "synth_forward: null pointer");
+    LA_CHECK_ARG(B >= 1 && B <= h->maxB, "synth_forward: batch exceeds the max_batch the workspace was sized for");
+    LA_CHECK_ARG(noise_mode >= 0 && noise_mode <= 2, "synth_forward: noise_mode must be 0 (none), 1 (const), 2 (explicit)");
+    LA_CHECK_ARG(noise_mode != 2 || noises, "synth_forward: explicit noise requested but no noise tensors given");
+    int rc;
+    if ((rc = la_affine_forward(h->st, ws, ws_bstride, ws_lstride, B, h->wdim, h->s_all, stream))) return rc;
+    if ((rc = la_demod_forward(h->dt, h->s_all, h->S, B, h->d_all, stream))) return rc;
+    h->lastB = B;
+    int ci = 0;
+    const float* x = h->cst;
+    long x_bstride = 0;
+    for (int k = 0; k < h->nblocks; ++k) {
+        const int res = 4 << k;
+        const int nl = (k == 0) ? 1 : 2;
+        for (int q = 0; q < nl; ++q, ++ci) {
+            ConvLayer& L = h->conv[ci];
+            L.noise_used = nullptr; L.noise_bstride = 0;
+            if (L.noise_strength != 0.f) {
+                if (noise_mode == 1) L.noise_used = L.noise_const;
+                else if (noise_mode == 2) { L.noise_used = noises[ci]; L.noise_bstride = (long)res * res; LA_CHECK_ARG(L.noise_used, "synth_forward: missing noise tensor"); }
+            }
+            const float sq2 = sqrtf(2.f);
+            if (!L.up)
+                rc = la_modconv3x3_fwd_f32(x, x_bstride, L.wf, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
+                                           L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f, sq2,
+                                           h->clamp, L.y, B, L.cin, L.cout, res, stream);
+            else
+                rc = la_modconv3x3_up2_fwd_f32(x, x_bstride, L.wf, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
+                                               L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f,
+                                               sq2, h->clamp, h->fir, h->zT, L.y, B, L.cin, L.cout, res, stream);
+            if (rc) return rc;
+            x = L.y; x_bstride = (long)L.cout * res * res;
+        }
+        RgbLayer& T = h->rgb[k];
+        const float* skip = nullptr;
+        if (k > 0) {
+            // img = upsample2d(img_prev, f): up 2, pad (2,1,2,1), gain 4 (upfirdn2d.py:342-348); result parked in g_img scratch
+            RgbLayer& P = h->rgb[k - 1];
+            if ((rc = la_upfirdn2d_ex(P.img, T.g_img, B, h->imgc, res / 2, res / 2, h->fir, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1, 0,
+                                      4.f, nullptr, stream)))
+                return rc;
+            skip = T.g_img;
+        }
+        float* dst = (k == h->nblocks - 1 && img_out) ? img_out : T.img;
+        if ((rc = la_torgb_forward(x, T.weight, h->s_all + T.s_off, h->S, T.bias, skip, T.rgb_pre, dst, B, T.cin, h->imgc,
+                                   res, res, h->clamp, stream)))
+            return rc;
+        if (k == h->nblocks - 1) h->final_img = dst;
+    }
+    return LA_OK;
+}
+
+extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hipStream_t stream) {
+    LA_CHECK_ARG(h && g_img && dws, "synth_backward: null pointer");
+    LA_CHECK_ARG(h->lastB >= 1, "synth_backward: no forward pass to differentiate");
+    const int B = h->lastB;
+    int rc;
+    const float* gi = g_img;   // gradient w.r.t. the image at the current resolution
+    int ci = h->nconv - 1;
+    const float* gx_next = nullptr;   // gradient w.r.t. this block's conv1 output coming from the block above
+    for (int k = h->nblocks - 1; k >= 0; --k) {
+        const int res = 4 << k;
+        const long HW = (long)res * res;
+        RgbLayer& T = h->rgb[k];
+        ConvLayer& L1 = h->conv[ci];
+        // ---- seam at conv1 output: ToRGB backward + act backward
+        LaSeamArgs s; memset(&s, 0, sizeof(s));
+        s.y = L1.y; s.gx_next = gx_next; s.gz = h->G0; s.HW = HW; s.C = L1.cout;
+        s.demod = h->d_all + L1.d_off; s.demod_stride = h->Dt; s.bias = L1.bias;
+        s.noise = L1.noise_used; s.noise_bstride = L1.noise_bstride; s.noise_strength = L1.noise_strength;
+        s.act = LA_ACT_LRELU; s.alpha = 0.2f; s.gain = sqrtf(2.f); s.clamp = h->clamp;
+        s.ddn_part = h->ddn_part;
+        s.g_img = gi; s.rgb_pre = T.rgb_pre; s.rgb_clamp = h->clamp; s.wrgb = T.weight;
+        s.s_rgb = h->s_all + T.s_off; s.s_stride = h->S; s.dweff_part = h->dweff_part;
+        if ((rc = la_seam_backward(s, B, h->imgc, stream))) return rc;
+        const int slabs = la_seam_slabs(HW);
+        if ((rc = la_style_backward_rgb(h->dweff_part, slabs, T.weight, T.cin, h->imgc, B, h->ds_all + T.s_off, h->S, stream)))
+            return rc;
+        // ---- conv1 backward-data (+ style-gradient partials)
+        {
+            const float* xin = (k == 0) ? h->cst : h->conv[ci - 1].y;
+            const long xin_bs = (k == 0) ? 0 : (long)L1.cin * HW;
+            const int tiles = la_modconv_ds_tiles(res);
+            if ((rc = la_modconv3x3_bwd_f32(h->G0, L1.wb, h->s_all + L1.s_off, h->S, xin, xin_bs, h->G1, h->ds_part, B, L1.cin,
+                                            L1.cout, res, stream)))
+                return rc;
+            if ((rc = la_style_backward_conv(h->ds_part, tiles, h->ddn_part, slabs, h->d_all + L1.d_off, h->Dt,
+                                             h->s_all + L1.s_off, h->S, L1.wsq, L1.cin, L1.cout, B,
+                                             h->ds_all + L1.s_off, h->S, stream)))
+                return rc;
+        }
+        --ci;
+        if (k == 0) break;
+        // ---- conv0 (up-sampling layer): act backward -> FIR adjoint -> stride-2 backward-data
+        ConvLayer& L0 = h->conv[ci];
+        memset(&s, 0, sizeof(s));
+        s.y = L0.y; s.gx_next = h->G1; s.gz = h->G1; s.HW = HW; s.C = L0.cout;
+        s.demod = h->d_all + L0.d_off; s.demod_stride = h->Dt; s.bias = L0.bias;
+        s.noise = L0.noise_used; s.noise_bstride = L0.noise_bstride; s.noise_strength = L0.noise_strength;
+        s.act = LA_ACT_LRELU; s.alpha = 0.2f; s.gain = sqrtf(2.f); s.clamp = h->clamp;
+        s.ddn_part = h->ddn_part;
+        if ((rc = la_seam_backward(s, B, 0, stream))) return rc;
+        {
+            const int hin = res / 2;
+            const int tiles = la_modconv_ds_tiles(hin);
+            if ((rc = la_modconv3x3_up2_bwd_f32(h->G1, L0.wb, h->s_all + L0.s_off, h->S, h->conv[ci - 1].y,
+                                                (long)L0.cin * hin * hin, h->fir, h->zT, h->G0, h->ds_part, B, L0.cin, L0.cout,
+                                                res, stream)))
+                return rc;
+            if ((rc = la_style_backward_conv(h->ds_part, tiles, h->ddn_part, slabs, h->d_all + L0.d_off, h->Dt,
+                                             h->s_all + L0.s_off, h->S, L0.wsq, L0.cin, L0.cout, B,
+                                             h->ds_all + L0.s_off, h->S, stream)))
+                return rc;
+        }
+        --ci;
+        gx_next = h->G0;
+        // ---- image gradient one level down: adjoint of upsample2d = FIR (flipped) + decimate 2, pad (1,1,1,1), gain 4
+        RgbLayer& P = h->rgb[k - 1];
+        if ((rc = la_upfirdn2d_ex(gi, P.g_img, B, h->imgc, res, res, h->fir, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1, 1, 4.f, nullptr,
+                                  stream)))
+            return rc;
+        gi = P.g_img;
+    }
+    return la_affine_backward(h->st, h->ds_all, B, h->wdim, dws, h->num_ws, stream);
+}

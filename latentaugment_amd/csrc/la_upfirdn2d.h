@@ -1,0 +1,16 @@
+// Internal (C++) entry points of the FIR resampling kernels; the public C ABI is in include/latentaug_hip.h.
+#pragma once
+#include "la_common.h"
+
+// generic op, optional same-shape addend (skip connection add fused into the store)
+int la_upfirdn2d_ex(const float* in, float* out, int B, int C, int Hin, int Win, const float* f_host, int fh, int fw,
+                    int upx, int upy, int dnx, int dny, int padx0, int padx1, int pady0, int pady1, int flip_filter,
+                    float gain, const float* addend, hipStream_t stream);
+
+// FIR (up=down=1) followed by the modulated-conv epilogue: *demod[b][c] + noise*strength + bias[c] -> act -> clamp.
+// Used after the transposed stride-2 conv of an up-sampling SynthesisLayer (conv2d_resample.py:126).
+int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int Hin, int Win, const float* f_host,
+                                  int fh, int fw, int padx0, int padx1, int pady0, int pady1, float fir_gain,
+                                  const float* demod, int demod_stride, const float* noise, long noise_bstride,
+                                  float noise_strength, const float* bias, int act, float alpha, float gain,
+                                  float clamp, hipStream_t stream);

@@ -1,0 +1,127 @@
+// upfirdn2d: zero-insert, pad/crop, 2-D FIR, decimate, gain  (+ optional fused modconv epilogue).
+// Semantics follow models/stylegan3/torch_utils/ops/upfirdn2d.py:167-211 (ref) / upfirdn2d.cu:29-92.
+// HBM-bound: each output reads <= ceil(fh/up)*ceil(fw/up) inputs (L1/L2 hits), one coalesced store.
+#include "la_upfirdn2d.h"
+
+#define FIR_MAX 8
+
+struct FirArgs {
+    const float* in;
+    float* out;
+    int P, C;          // planes = B*C
+    int Hin, Win, Hout, Wout;
+    int upx, upy, dnx, dny, padx0, pady0;
+    int fw, fh;
+    float f[FIR_MAX * FIR_MAX];  // effective correlation kernel (already flipped as needed, gain folded in)
+    int epi;                     // 0 plain, 1 modconv epilogue
+    const float* demod; int demod_stride;   // [B][stride]
+    const float* noise; long noise_bstride; float noise_strength;
+    const float* bias;
+    int act; float alpha, gain, clamp;
+    const float* addend;         // optional same-shape tensor added to the result (skip connection), epi 0 only
+};
+
+__global__ __launch_bounds__(256) void la_upfirdn2d_kernel(FirArgs a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.Wout || y >= a.Hout) return;
+    // contributing input rows: iy*upy = y*dny + ta - pady0, ta in [0, fh)
+    const int by = y * a.dny - a.pady0, bx = x * a.dnx - a.padx0;
+    // smallest iy with iy*up >= by  (floor division that is safe for negatives)
+    int iy_lo = (by >= 0) ? (by + a.upy - 1) / a.upy : -((-by) / a.upy);
+    int ix_lo = (bx >= 0) ? (bx + a.upx - 1) / a.upx : -((-bx) / a.upx);
+    const long HWin = (long)a.Hin * a.Win, HWout = (long)a.Hout * a.Wout;
+    for (int p = blockIdx.z; p < a.P; p += gridDim.z) {
+        const float* ip = a.in + (long)p * HWin;
+        float v = 0.f;
+        for (int iy = iy_lo; iy * a.upy - by < a.fh; ++iy) {
+            if (iy < 0 || iy >= a.Hin) continue;
+            const int ta = iy * a.upy - by;
+            for (int ix = ix_lo; ix * a.upx - bx < a.fw; ++ix) {
+                if (ix < 0 || ix >= a.Win) continue;
+                const int tb = ix * a.upx - bx;
+                v += ip[(long)iy * a.Win + ix] * a.f[ta * a.fw + tb];
+            }
+        }
+        const long o = (long)p * HWout + (long)y * a.Wout + x;
+        if (a.epi == 1) {
+            const int b = p / a.C, c = p - b * a.C;
+            if (a.demod) v *= a.demod[(long)b * a.demod_stride + c];
+            if (a.noise) v += a.noise[(long)b * a.noise_bstride + (long)y * a.Wout + x] * a.noise_strength;
+            if (a.bias) v += a.bias[c];
+            v = la_act_fwd(v, a.act, a.alpha, a.gain, a.clamp);
+        } else if (a.addend) {
+            v += a.addend[o];
+        }
+        a.out[o] = v;
+    }
+}
+
+static int fir_fill(FirArgs& a, const float* in, float* out, int B, int C, int Hin, int Win, const float* f_host,
+                    int fh, int fw, int upx, int upy, int dnx, int dny, int padx0, int padx1, int pady0, int pady1,
+                    int flip_filter, float gain, int* Hout, int* Wout) {
+    LA_CHECK_ARG(in && out && f_host, "upfirdn2d: null pointer");
+    LA_CHECK_ARG(fh >= 1 && fw >= 1 && fh <= FIR_MAX && fw <= FIR_MAX, "upfirdn2d: filter larger than 8x8");
+    LA_CHECK_ARG(upx >= 1 && upy >= 1 && dnx >= 1 && dny >= 1, "upfirdn2d: bad up/down factor");
+    LA_CHECK_ARG(B >= 1 && C >= 1 && Hin >= 1 && Win >= 1, "upfirdn2d: empty input");
+    const int upW = Win * upx + padx0 + padx1, upH = Hin * upy + pady0 + pady1;
+    LA_CHECK_ARG(upW >= fw && upH >= fh, "upfirdn2d: upsampled image smaller than the filter");
+    *Wout = (upW - fw + dnx) / dnx;   // upfirdn2d.cpp:35-36
+    *Hout = (upH - fh + dny) / dny;
+    a.in = in; a.out = out; a.P = B * C; a.C = C;
+    a.Hin = Hin; a.Win = Win; a.Hout = *Hout; a.Wout = *Wout;
+    a.upx = upx; a.upy = upy; a.dnx = dnx; a.dny = dny; a.padx0 = padx0; a.pady0 = pady0;
+    a.fw = fw; a.fh = fh;
+    // the op is a true convolution unless flip_filter: correlation kernel = flipped filter (upfirdn2d.py:198-199)
+    for (int i = 0; i < fh; ++i)
+        for (int j = 0; j < fw; ++j)
+            a.f[i * fw + j] = gain * (flip_filter ? f_host[i * fw + j] : f_host[(fh - 1 - i) * fw + (fw - 1 - j)]);
+    a.epi = 0; a.demod = nullptr; a.noise = nullptr; a.bias = nullptr; a.addend = nullptr;
+    a.demod_stride = 0; a.noise_bstride = 0; a.noise_strength = 0.f;
+    a.act = LA_ACT_LINEAR; a.alpha = 0.f; a.gain = 1.f; a.clamp = -1.f;
+    return LA_OK;
+}
+
+static int fir_launch(const FirArgs& a, hipStream_t stream) {
+    dim3 grid(la_cdiv(a.Wout, 64), la_cdiv(a.Hout, 4), a.P < 1024 ? a.P : 1024);
+    LA_CHECK_ARG(grid.y <= 65535, "upfirdn2d: output too tall");
+    hipLaunchKernelGGL(la_upfirdn2d_kernel, grid, dim3(256), 0, stream, a);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
+int la_upfirdn2d_ex(const float* in, float* out, int B, int C, int Hin, int Win, const float* f_host, int fh, int fw,
+                    int upx, int upy, int dnx, int dny, int padx0, int padx1, int pady0, int pady1, int flip_filter,
+                    float gain, const float* addend, hipStream_t stream) {
+    FirArgs a; int ho, wo;
+    int rc = fir_fill(a, in, out, B, C, Hin, Win, f_host, fh, fw, upx, upy, dnx, dny, padx0, padx1, pady0, pady1,
+                      flip_filter, gain, &ho, &wo);
+    if (rc) return rc;
+    a.addend = addend;
+    return fir_launch(a, stream);
+}
+
+int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int Hin, int Win, const float* f_host,
+                                  int fh, int fw, int padx0, int padx1, int pady0, int pady1, float fir_gain,
+                                  const float* demod, int demod_stride, const float* noise, long noise_bstride,
+                                  float noise_strength, const float* bias, int act, float alpha, float gain,
+                                  float clamp, hipStream_t stream) {
+    FirArgs a; int ho, wo;
+    int rc = fir_fill(a, in, out, B, C, Hin, Win, f_host, fh, fw, 1, 1, 1, 1, padx0, padx1, pady0, pady1, 0, fir_gain,
+                      &ho, &wo);
+    if (rc) return rc;
+    a.epi = 1; a.demod = demod; a.demod_stride = demod_stride; a.noise = noise; a.noise_bstride = noise_bstride;
+    a.noise_strength = noise_strength; a.bias = bias; a.act = act; a.alpha = alpha; a.gain = gain; a.clamp = clamp;
+    return fir_launch(a, stream);
+}
+
+extern "C" int la_upfirdn2d_out_size(int in_size, int up, int down, int pad0, int pad1, int taps) {
+    return (in_size * up + pad0 + pad1 - taps + down) / down;
+}
+
+extern "C" int la_upfirdn2d_f32(const float* x, const float* f_host, float* y, int N, int C, int H, int W, int fh,
+                                int fw, int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0,
+                                int pady1, int flip, float gain, hipStream_t stream) {
+    return la_upfirdn2d_ex(x, y, N, C, H, W, f_host, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip,
+                           gain, nullptr, stream);
+}

@@ -1,0 +1,233 @@
+"""Host-side mirror of augments/utils/util_latent_aug.py::LatentAug for the MI355X path.
+
+Same constructor fields (read from `opt`), same `forward(w, fname) -> (img, w_aug)` contract, same attributes
+(`num_ws, w_dim, z_dim, stats_dataset_w`).  The N-step optimisation itself is one call into the C ABI
+(`la_latent_opt_run`); this file only moves tensors to the device, draws the crop position on the host and -- when a
+process group is active -- shards independent samples over ranks and gathers the result with ONE collective.
+
+Differences from the reference, all deliberate:
+  * one process per GPU + torch.distributed (RCCL) instead of single-process nn.DataParallel (:28-33);
+  * works with `gpu_ids=[k]` only on a ROCm device: there is no CPU path here (the reference's CPU path is the oracle);
+  * G / banks can be injected (no pickle / zip needed for synthetic runs); on-disk formats are the next scope row;
+  * the final synthesis uses explicit noise tensors drawn on the host RNG when noise_strength != 0 (defect g).
+"""
+import ctypes as C
+import math
+import random
+
+import numpy as np
+import torch
+
+from . import _lib
+from .synthesis import SynthesisEngine
+
+
+def center_crop_geometry(load_size):
+    """(crop, offset) of util_dataset.get_center_crop: CenterCrop(int(sqrt(res^2/2))), torchvision offset."""
+    crop = int(np.sqrt((load_size * load_size) / 2))
+    return crop, int(round((load_size - crop) / 2.0))
+
+
+def get_params(load_size, crop_size, preprocess='center_random_crop'):
+    """Random-crop position, drawn ONCE per forward on the host (util_dataset.py:284-296)."""
+    assert preprocess in ['center_random_crop', 'random_crop']
+    new = load_size
+    if preprocess == 'center_random_crop':
+        new = int(np.sqrt((load_size * load_size) / 2))
+    x = random.randint(0, max(0, new - crop_size))
+    y = random.randint(0, max(0, new - crop_size))
+    return {'crop_pos': (x, y)}
+
+
+def shard_bounds(batch, world_size, rank):
+    """Contiguous sample range of a rank: [rank*b, (rank+1)*b) with b = ceil(batch / world_size)."""
+    per = (batch + world_size - 1) // world_size
+    lo = min(rank * per, batch)
+    hi = min(lo + per, batch)
+    return lo, hi, per
+
+
+def gather_shards(local, per, batch, group=None):
+    """ONE all_gather of equally padded shards -> the full batch on every rank (the reference gathers to gpu_ids[0])."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    pad = torch.zeros([per] + list(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty([world * per] + list(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return out[:batch]
+
+
+class InMemoryLatentCodes:
+    """Minimal stand-in for util_dataset.LatentCodeDataset: fname -> inverted latent [num_ws, w_dim] (or [w_dim])."""
+
+    def __init__(self, codes):
+        self.codes = dict(codes)
+
+    def lookup(self, fname):
+        return np.asarray(self.codes[fname], dtype=np.float32)
+
+
+class LatentAug:
+    def __init__(self, phase, opt, save_dir, gpu_ids, generator=None, banks=None, latent_codes=None, group=None):
+        self.save_dir = save_dir
+        self.phase = phase
+        self.group = group
+        if not gpu_ids:
+            raise _lib.LatentAugHipError(
+                'LatentAug (MI355X path) needs a GPU id in gpu_ids_aug; the CPU restatement lives in oracle/ and is '
+                'test infrastructure only')
+        if len(gpu_ids) > 1:
+            raise _lib.LatentAugHipError(
+                'one process drives one GPU: launch one rank per GPU (torch.distributed / RCCL) instead of passing '
+                'several gpu_ids to a single process')
+        self.device = torch.device('cuda', gpu_ids[0])
+        self.res = opt.img_resolution
+        self.batch_size = opt.batch_size
+        self.modalities = [m for m in str(opt.modalities_aug).split(',') if m]
+        self.num_epochs = opt.opt_num_epochs
+        self.opt_lr = opt.opt_lr
+        self.truncation_psi = opt.truncation_psi
+        self.w_pix, self.w_lpips, self.w_latent, self.w_disc = opt.w_pix, opt.w_lpips, opt.w_latent, opt.w_disc
+        self.crop_size = opt.crop_size_aug
+        self.preprocess = opt.preprocess_aug
+        self.soft_aug, self.alpha = bool(opt.soft_aug), opt.alpha
+        self.verbose_log = opt.verbose_log
+        self.criterion_mode = getattr(opt, 'criterion_mode', 'gemm')
+        self.final_noise_mode = getattr(opt, 'final_noise_mode', 'random')
+        if self.w_disc > 0 or self.w_lpips > 0:
+            raise NotImplementedError(
+                'w_disc / w_lpips > 0: the discriminator and LPIPS criteria are the next rows of the scope table '
+                '(SURVEY.md 8f) and are not in this build yet')
+        if generator is None:
+            raise NotImplementedError(
+                'loading G/D from a network pickle (util_latent_aug.py:466-484) is the next scope row; pass '
+                '`generator=` (a module or state_dict with the reference parameter names)')
+        max_local = self.batch_size
+        self.engine = SynthesisEngine.from_generator(generator, self.device, max_local)
+        assert self.engine.img_resolution == self.res, 'opt.img_resolution does not match the generator'
+        assert self.engine.img_channels == len(self.modalities), 'one image channel per modality expected'
+        self.num_ws, self.w_dim = self.engine.num_ws, self.engine.w_dim
+        self.z_dim = getattr(generator, 'z_dim', self.w_dim)
+        self.stats_dataset_w = latent_codes
+        self.stats_loss = {}
+
+        banks = banks or {}
+        lib = _lib.load()
+        self._lib = lib
+        crop, off = center_crop_geometry(self.res)
+        self.center_crop, self.center_off = crop, off
+        self.W = None
+        self.Xc = None
+        Mw = Mx = 0
+        if self.w_latent > 0:
+            W = banks['W'].to(device=self.device, dtype=torch.float32).contiguous()
+            assert W.shape[1:] == (self.num_ws, self.w_dim)
+            self.W, Mw = W, W.shape[0]
+        if self.w_pix > 0:
+            X = banks['X'].to(device=self.device, dtype=torch.float32).contiguous()     # [M, C, R, R] in [-1, 1]
+            assert X.shape[1:] == (len(self.modalities), self.res, self.res)
+            Mx = X.shape[0]
+            xc = torch.empty([Mx, X.shape[1], crop, crop], device=self.device, dtype=torch.float32)
+            with torch.cuda.device(self.device):
+                _lib.check(lib.la_center_crop_f32(_lib.ptr(X), _lib.ptr(xc), Mx * X.shape[1], self.res, crop, off,
+                                                  _lib.stream_ptr()), 'la_center_crop')
+            self.Xc = xc.permute(1, 0, 2, 3).contiguous()      # modality-major [C][M][crop*crop]
+            del X, xc
+        cfg = _lib.OptConfig(steps=int(self.num_epochs), lr=float(self.opt_lr), beta1=0.9, beta2=0.999, eps=1e-8,
+                             w_latent=float(self.w_latent), w_pix=float(self.w_pix), w_disc=0.0, w_lpips=0.0,
+                             criterion_mode={'gemm': 0, 'collapsed': 1}[self.criterion_mode],
+                             soft_aug=int(self.soft_aug), alpha=float(self.alpha), loop_noise_mode=1,
+                             final_noise_mode={'none': 0, 'const': 1, 'random': 2}[self.final_noise_mode],
+                             norm_batch=0, crop=crop, crop_off=off)
+        self._cfg = cfg
+        nbytes = lib.la_latent_opt_workspace_bytes(self.res, self.engine.img_channels, self.w_dim, C.byref(cfg), Mw, Mx,
+                                                   max_local)
+        self._workspace = torch.empty([max(nbytes, 64)], dtype=torch.uint8, device=self.device)
+        h = C.c_void_p()
+        _lib.check(lib.la_latent_opt_create(self.engine.handle, self.res, self.engine.img_channels, self.w_dim,
+                                            C.byref(cfg), _lib.ptr(self.W), Mw, _lib.ptr(self.Xc), Mx, max_local,
+                                            _lib.ptr(self._workspace), self._workspace.numel(), C.byref(h)),
+                   'la_latent_opt_create')
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            self._lib.la_latent_opt_destroy(h)
+            self._h = None
+
+    # ------------------------------------------------------------------ helpers (reference :493-498)
+    def broadcasting(self, latent):
+        return latent.repeat([1, self.num_ws, 1])
+
+    @staticmethod
+    def reverse_broadcasting(latent):
+        return latent[:, :1, :]
+
+    # ------------------------------------------------------------------ the hot path
+    def run_local(self, w, final_noises=None, want_losses=False):
+        """w [b,1,w_dim] on this device -> (img [b,C,R,R], w_aug [b,num_ws,w_dim], losses or None)."""
+        w = w.to(device=self.device, dtype=torch.float32).contiguous()
+        b = w.shape[0]
+        assert w.ndim == 3 and w.shape[1:] == (1, self.w_dim)
+        img = torch.empty([b, self.engine.img_channels, self.res, self.res], device=self.device, dtype=torch.float32)
+        w_aug = torch.empty([b, self.num_ws, self.w_dim], device=self.device, dtype=torch.float32)
+        losses = torch.zeros([max(self.num_epochs, 1), 4], device=self.device) if want_losses else None
+        fn = None
+        if self._cfg.final_noise_mode == 2:
+            if final_noises is None:
+                final_noises = self.engine.make_noises(b)
+            fn = self.engine.noise_pointer_array(final_noises)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.la_latent_opt_run(self._h, _lib.ptr(w), b, fn, _lib.ptr(img), _lib.ptr(w_aug),
+                                                   _lib.ptr(losses), _lib.stream_ptr()), 'la_latent_opt_run')
+        self._keep = final_noises
+        return img, w_aug, losses
+
+    def forward(self, w, fname=None, final_noises=None):
+        """LatentAug.forward(w, fname) (reference :207-310): returns (imgAB_aug, w_aug) for the FULL batch.
+
+        With an initialised process group every rank passes the same full-batch `w`; rank k optimises samples
+        [k*b, (k+1)*b) and a single all_gather returns the whole batch everywhere."""
+        if w.ndim == 2:
+            raise NotImplementedError('z input (mapping network) is the rand_aug scope row; pass w [B,1,w_dim]')
+        # crop position: drawn once per forward on the host as the reference does (:216); only the (future) LPIPS
+        # criterion consumes it, but the draw is kept so the python RNG stream matches the reference's.
+        self.crop_params = get_params(self.res, self.crop_size, self.preprocess)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            B = w.shape[0]
+            lo, hi, per = shard_bounds(B, dist.get_world_size(self.group), dist.get_rank(self.group))
+            if hi > lo:
+                fn = [t[lo:hi].contiguous() for t in final_noises] if final_noises is not None else None
+                img, w_aug, _ = self.run_local(w[lo:hi], fn)
+            else:
+                img = torch.empty([0, self.engine.img_channels, self.res, self.res], device=self.device)
+                w_aug = torch.empty([0, self.num_ws, self.w_dim], device=self.device)
+            # one collective per batch: image and latent packed into a single buffer
+            flat = torch.cat([img.reshape(img.shape[0], -1), w_aug.reshape(w_aug.shape[0], -1)], dim=1)
+            full = gather_shards(flat, per, B, self.group)
+            n_img = self.engine.img_channels * self.res * self.res
+            img = full[:, :n_img].reshape(B, self.engine.img_channels, self.res, self.res)
+            w_aug = full[:, n_img:].reshape(B, self.num_ws, self.w_dim)
+            return img, w_aug
+        img, w_aug, losses = self.run_local(w, final_noises, want_losses=bool(self.verbose_log))
+        if self.verbose_log and losses is not None:
+            L = losses.cpu().numpy()
+            for e in range(self.num_epochs):
+                self.stats_loss[f'epoch_{e}'] = dict(loss_latent=float(L[e, 0]), loss_pix=float(L[e, 1]),
+                                                     loss=float(-L[e, 0] - L[e, 1] - L[e, 3] + L[e, 2]))
+        return img, w_aug
+
+    __call__ = forward
+
+    def forward_ganrand(self, z):
+        raise NotImplementedError('rand_aug / forward_ganrand needs the mapping network: next scope row (SURVEY 8f rank 4)')
+
+
+def define_latentaugment(module_name, phase, opt, save_dir, gpu_ids=[], **inject):
+    """util_latent_aug.define_latentaugment (reference :45-64) -- returns the module itself (no DataParallel)."""
+    if module_name == 'latent_aug':
+        return LatentAug(phase, opt, save_dir, gpu_ids, **inject)
+    raise NotImplementedError('Module name [%s] is not recognized' % module_name)

@@ -1,0 +1,200 @@
+"""Host wrapper of the HIP synthesis engine: the `G.synthesis(ws, noise_mode=...)` the reference calls at
+augments/utils/util_latent_aug.py:227,488, plus its backward to ws.
+
+`SynthesisEngine.from_generator(G)` accepts any module (or state_dict) that carries the reference's parameter names
+(models/stylegan3/legacy.py:171-203: synthesis.b{res}.{const, conv0.*, conv1.*, torgb.*}) -- i.e. the G_ema of a
+network pickle -- copies the tensors to the device once and hands their pointers to the C ABI.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_CONV_KEYS = ('affine.weight', 'affine.bias', 'weight', 'bias', 'noise_const')
+_RGB_KEYS = ('affine.weight', 'affine.bias', 'weight', 'bias')
+NOISE_MODES = {'none': 0, 'const': 1, 'random': 2}
+
+
+def _state_dict_of(G):
+    sd = G if isinstance(G, dict) else G.state_dict()
+    if any(k.startswith('synthesis.') for k in sd):
+        sd = {k[len('synthesis.'):]: v for k, v in sd.items() if k.startswith('synthesis.')}
+    return sd
+
+
+class SynthesisEngine:
+    def __init__(self, state_dict, device, max_batch, conv_clamp=256.0):
+        lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.LatentAugHipError('SynthesisEngine needs a ROCm device (no CPU fallback)')
+        sd = state_dict
+        res_list = sorted({int(k.split('.')[0][1:]) for k in sd if k.startswith('b')})
+        assert res_list and res_list[0] == 4, 'expected synthesis blocks b4..bR'
+        self.img_resolution = res_list[-1]
+        self.block_resolutions = res_list
+        self.channels = [int(sd[f'b{r}.conv1.weight'].shape[0]) for r in res_list]
+        self.img_channels = int(sd[f'b{res_list[-1]}.torgb.weight'].shape[0])
+        self.w_dim = int(sd['b4.conv1.affine.weight'].shape[1])
+        self.num_ws = lib.la_synth_num_ws(self.img_resolution)
+        self.max_batch = int(max_batch)
+        self.conv_clamp = float(-1.0 if conv_clamp is None else conv_clamp)
+
+        def dev(name):
+            t = sd[name].detach().to(device=self.device, dtype=torch.float32).contiguous()
+            self._keep.append(t)
+            return t
+
+        self._keep = []
+        params = []
+        strengths = []
+        self.layer_resolutions = []
+        for r in res_list:
+            if r == 4:
+                params.append(dev('b4.const'))
+            layers = ('conv1',) if r == 4 else ('conv0', 'conv1')
+            for ln in layers:
+                for k in _CONV_KEYS:
+                    params.append(dev(f'b{r}.{ln}.{k}'))
+                strengths.append(float(sd[f'b{r}.{ln}.noise_strength']))
+                self.layer_resolutions.append(r)
+            for k in _RGB_KEYS:
+                t = dev(f'b{r}.torgb.{k}')
+                if k == 'weight':
+                    t = t.reshape(t.shape[0], t.shape[1]).contiguous()   # [imgc][cin][1][1] -> [imgc][cin]
+                    self._keep.append(t)
+                params.append(t)
+        fkey = f'b{res_list[-1]}.resample_filter'
+        fir = sd[fkey].detach().cpu().float().numpy() if fkey in sd else None
+        if fir is None:
+            f1 = np.array([1, 3, 3, 1], dtype=np.float32)
+            fir = np.outer(f1, f1) / 64.0
+        assert fir.shape == (4, 4), 'resample filter must be the 4x4 setup_filter([1,3,3,1])'
+        self._fir = np.ascontiguousarray(fir, dtype=np.float32)
+        self.noise_strengths = strengths
+        self.num_layers = len(strengths)
+
+        chan = (C.c_int * len(self.channels))(*self.channels)
+        nbytes = lib.la_synth_workspace_bytes(self.img_resolution, self.img_channels, self.w_dim, chan, self.max_batch)
+        assert nbytes > 0
+        self._workspace = torch.empty([nbytes], dtype=torch.uint8, device=self.device)
+        self.workspace_bytes = nbytes
+        pp = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        ns = (C.c_float * len(strengths))(*strengths)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.la_synth_create(self.img_resolution, self.img_channels, self.w_dim, chan, self.conv_clamp, pp,
+                                           len(params), ns, len(strengths), self._fir.ctypes.data, 4, 4, self.max_batch,
+                                           _lib.ptr(self._workspace), nbytes, _lib.stream_ptr(), C.byref(h)),
+                       'la_synth_create')
+        self._h = h
+        self._lib = lib
+
+    @classmethod
+    def from_generator(cls, G, device, max_batch, conv_clamp=None):
+        if conv_clamp is None and not isinstance(G, dict):
+            try:
+                conv_clamp = getattr(G.synthesis, f'b{G.img_resolution}').conv1.conv_clamp
+            except AttributeError:
+                conv_clamp = 256.0
+        return cls(_state_dict_of(G), device, max_batch, conv_clamp=256.0 if conv_clamp is None else conv_clamp)
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            self._lib.la_synth_destroy(h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def make_noises(self, batch, generator=None):
+        """Unit-variance noise tensors for noise_mode='random' (one [B,res,res] per SynthesisLayer)."""
+        return [torch.randn([batch, r, r], device=self.device, generator=generator) for r in self.layer_resolutions]
+
+    def noise_pointer_array(self, noises):
+        if noises is None:
+            return None
+        assert len(noises) == self.num_layers
+        for t, r in zip(noises, self.layer_resolutions):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape[-2:] == (r, r)
+        return (C.c_void_p * len(noises))(*[t.data_ptr() for t in noises])
+
+    def forward(self, ws, noise_mode='const', noises=None, out=None):
+        """ws [B,num_ws,w_dim] (or [B,1,w_dim] / [B,w_dim]: W space) -> img [B,C,R,R]."""
+        _lib.require_gpu(ws)
+        ws = ws.contiguous().float()
+        if ws.ndim == 2:
+            ws = ws[:, None]
+        B = ws.shape[0]
+        assert ws.shape[2] == self.w_dim and ws.shape[1] in (1, self.num_ws)
+        lstride = 0 if ws.shape[1] == 1 else self.w_dim
+        mode = NOISE_MODES[noise_mode]
+        if mode == 2 and noises is None:
+            noises = self.make_noises(B)
+        np_arr = self.noise_pointer_array(noises) if mode == 2 else None
+        img = out if out is not None else torch.empty([B, self.img_channels, self.img_resolution, self.img_resolution],
+                                                      device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.la_synth_forward(self._h, _lib.ptr(ws), ws.shape[1] * self.w_dim, lstride, B, mode, np_arr,
+                                                  _lib.ptr(img), _lib.stream_ptr()), 'la_synth_forward')
+        self._last_noises = noises   # keep alive until the matching backward
+        return img
+
+    def backward(self, g_img):
+        """d(loss)/d(img) [B,C,R,R] -> d(loss)/d(ws) [B,num_ws,w_dim] for the last forward."""
+        g_img = g_img.contiguous().float()
+        B = g_img.shape[0]
+        dws = torch.empty([B, self.num_ws, self.w_dim], device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.la_synth_backward(self._h, _lib.ptr(g_img), _lib.ptr(dws), _lib.stream_ptr()),
+                       'la_synth_backward')
+        return dws
+
+    # debugging / test taps -------------------------------------------------------------------
+    def _view(self, p, shape):
+        n = int(np.prod(shape))
+        base = self._workspace.data_ptr()
+        off = p - base
+        assert 0 <= off and off + 4 * n <= self.workspace_bytes
+        return self._workspace[off:off + 4 * n].view(torch.float32).reshape(shape)
+
+    def layer_output(self, k, batch):
+        r = self.layer_resolutions[k]
+        block = self.block_resolutions.index(r)
+        return self._view(self._lib.la_synth_layer_output(self._h, k), [batch, self.channels[block], r, r])
+
+    def styles(self, batch):
+        rows = self._lib.la_synth_style_rows(self._h)
+        return self._view(self._lib.la_synth_styles(self._h), [batch, rows])
+
+    def style_grads(self, batch):
+        rows = self._lib.la_synth_style_rows(self._h)
+        return self._view(self._lib.la_synth_style_grads(self._h), [batch, rows])
+
+
+class _SynthesisFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ws, engine, noise_mode, noises):
+        ctx.engine = engine
+        ctx.ws_shape = ws.shape
+        return engine.forward(ws, noise_mode=noise_mode, noises=noises)
+
+    @staticmethod
+    def backward(ctx, g_img):
+        dws = ctx.engine.backward(g_img)
+        shape = ctx.ws_shape
+        if len(shape) == 2:
+            dws = dws.sum(dim=1)
+        elif shape[1] == 1:
+            dws = dws.sum(dim=1, keepdim=True)
+        return dws, None, None, None
+
+
+def synthesis(engine, ws, noise_mode='const', noises=None):
+    """Differentiable (w.r.t. ws) call of the HIP synthesis engine, autograd-compatible."""
+    return _SynthesisFn.apply(ws, engine, noise_mode, noises)

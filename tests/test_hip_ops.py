@@ -1,0 +1,185 @@
+"""GPU parity tests, op level: HIP kernels (through the C ABI) vs the oracle and the reference-generated goldens.
+
+Tolerances: the HIP path computes in fp32 (fp32 MFMA = exact fp32 FMA chains) but sums in a different order from
+torch-CPU, so comparisons are rtol 1e-4 / atol scaled to the output magnitude (stated per test).
+"""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sg2_ops as ref_ops  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a ROCm device')
+    return torch.device('cuda', 0)
+
+
+@pytest.fixture(scope='module')
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, 'l0_ops.npz'))
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_library_loaded_is_in_tree():
+    from latentaugment_amd import _lib
+    lib = _lib.load()
+    assert lib.la_abi_version() == 1
+    assert os.path.dirname(_lib.LIB_PATH).endswith('latentaugment_amd')
+
+
+def test_bias_act_golden(dev, g):
+    from latentaugment_amd import ops
+    for k in range(int(g['G2_count'])):
+        act, gain, clamp = [str(s) for s in g[f'G2_{k}_meta']]
+        gain = None if gain == 'None' else float(gain)
+        clamp = None if clamp == 'None' else float(clamp)
+        x = torch.tensor(g[f'G2_{k}_x'], device=dev, requires_grad=True)
+        b = torch.tensor(g[f'G2_{k}_b'], device=dev, requires_grad=True)
+        y = ops.bias_act(x, b, act=act, gain=gain, clamp=clamp)
+        gx, gb = torch.autograd.grad(y, [x, b], torch.tensor(g[f'G2_{k}_dy'], device=dev))
+        close(y, g[f'G2_{k}_y'])
+        close(gx, g[f'G2_{k}_gx'])
+        close(gb, g[f'G2_{k}_gb'], rtol=1e-4, atol=1e-4)
+    y = ops.bias_act(torch.tensor(g['G2_fc_x'], device=dev), torch.tensor(g['G2_fc_b'], device=dev), act='lrelu')
+    close(y, g['G2_fc_y'])
+
+
+def test_bias_act_ragged_and_empty(dev):
+    from latentaugment_amd import ops
+    x = torch.randn([3, 5, 7, 3], device=dev)          # H*W = 21: not a multiple of 4
+    b = torch.randn([5], device=dev)
+    close(ops.bias_act(x, b, act='lrelu', clamp=0.5), ref_ops.bias_act(x.cpu(), b.cpu(), act='lrelu', clamp=0.5))
+    e = torch.empty([0, 5, 4, 4], device=dev)
+    assert ops.bias_act(e, b).shape == (0, 5, 4, 4)
+    with pytest.raises(NotImplementedError):
+        ops.bias_act(x, b, act='tanh')
+
+
+def test_upfirdn2d_golden(dev, g):
+    from latentaugment_amd import ops
+    f = ops.setup_filter([1, 3, 3, 1])
+    close(f, g['G1_filter_1331'])
+    for k in range(int(g['G3_count'])):
+        name, kw = [str(s) for s in g[f'G3_{k}_meta']]
+        kw = ast.literal_eval(kw)
+        x = torch.tensor(g[f'G3_{k}_x'], device=dev, requires_grad=True)
+        y = getattr(ops, name)(x, f, **kw)
+        assert tuple(y.shape) == g[f'G3_{k}_y'].shape, (name, kw)
+        (gx,) = torch.autograd.grad(y, [x], torch.tensor(g[f'G3_{k}_dy'], device=dev))
+        close(y, g[f'G3_{k}_y'])
+        close(gx, g[f'G3_{k}_gx'])
+
+
+def test_upfirdn2d_large_roundtrip_property(dev):
+    """<upfirdn(x), y> == <x, upfirdn^T(y)> at a BASELINE-size plane (adjoint identity, size independent)."""
+    from latentaugment_amd import ops
+    f = ops.setup_filter([1, 3, 3, 1])
+    x = torch.randn([2, 3, 256, 256], device=dev, requires_grad=True)
+    y = ops.upsample2d(x, f)
+    assert y.shape == (2, 3, 512, 512)
+    r = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, [x], r)
+    lhs = float((y.double() * r.double()).sum())
+    rhs = float((x.double() * gx.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+def test_pairwise_l2_golden(dev, golden_dir):
+    from latentaugment_amd import ops
+    gc = np.load(os.path.join(golden_dir, 'criteria.npz'))
+    for tag in ('2d', '3d', '4d'):
+        X, Y = torch.tensor(gc[f'G5_{tag}_X'], device=dev), torch.tensor(gc[f'G5_{tag}_Y'], device=dev)
+        close(ops.l2_loss_vectorized(X, Y), gc[f'G5_{tag}_mean'], rtol=1e-5, atol=1e-6)
+        close(ops.l2_loss_vectorized(X, Y, compute_mean=False), gc[f'G5_{tag}_full'], rtol=1e-5, atol=1e-3)
+
+
+def _modconv_case(dev, B, cin, cout, res, up, noise_strength, seed):
+    """Run the HIP modconv fwd + bwd for one layer and compare with autograd through the oracle."""
+    import ctypes as C
+    from latentaugment_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(seed)
+    rin = res // 2 if up else res
+    x = torch.randn([B, cin, rin, rin], generator=gen)
+    w = torch.randn([cout, cin, 3, 3], generator=gen)
+    s = torch.randn([B, cin], generator=gen) * 0.5 + 1.0
+    bias = torch.randn([cout], generator=gen) * 0.1
+    noise = torch.randn([res, res], generator=gen)
+    gy = torch.randn([B, cout, res, res], generator=gen)
+    f = ref_ops.setup_filter([1, 3, 3, 1])
+    clamp = 256.0
+    # ---- oracle
+    xr, sr = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    yr = ref_ops.modulated_conv2d(xr, w, sr, noise=noise * noise_strength, up=2 if up else 1, padding=1,
+                                  resample_filter=f, flip_weight=not up, fused_modconv=True)
+    yr = ref_ops.bias_act(yr, bias, act='lrelu', clamp=clamp)
+    gxr, gsr = torch.autograd.grad(yr, [xr, sr], gy)
+    # ---- HIP
+    st = _lib.stream_ptr()
+    xd, wd_, sd, bd, nd, gyd = [t.to(dev).contiguous() for t in (x, w, s, bias, noise, gy)]
+    wf = torch.empty([9, cin, cout], device=dev)
+    wb = torch.empty([9, cout, cin], device=dev)
+    wsq = torch.empty([cout, cin], device=dev)
+    _lib.check(lib.la_pack_conv_weights_f32(_lib.ptr(wd_), _lib.ptr(wf), _lib.ptr(wb), _lib.ptr(wsq), cout, cin, 9, st))
+    d = torch.rsqrt((sd.square() @ wsq.t()) + 1e-8).contiguous()     # test-side demod (the engine has its own kernel)
+    y = torch.empty([B, cout, res, res], device=dev)
+    fir = np.ascontiguousarray(f.numpy())
+    scratch = torch.empty([B * cout * (res + 1) * (res + 1)], device=dev)
+    sq2 = float(np.sqrt(2))
+    if up:
+        _lib.check(lib.la_modconv3x3_up2_fwd_f32(_lib.ptr(xd), cin * rin * rin, _lib.ptr(wf), _lib.ptr(sd), cin, _lib.ptr(d),
+                                                 cout, _lib.ptr(nd), 0, noise_strength, _lib.ptr(bd), 3, 0.2, sq2, clamp,
+                                                 fir.ctypes.data, _lib.ptr(scratch), _lib.ptr(y), B, cin, cout, res, st))
+    else:
+        _lib.check(lib.la_modconv3x3_fwd_f32(_lib.ptr(xd), cin * rin * rin, _lib.ptr(wf), _lib.ptr(sd), cin, _lib.ptr(d), cout,
+                                             _lib.ptr(nd), 0, noise_strength, _lib.ptr(bd), 3, 0.2, sq2, clamp, _lib.ptr(y),
+                                             B, cin, cout, res, st))
+    scale = float(yr.abs().max())
+    close(y, yr, rtol=1e-4, atol=1e-5 * scale)
+    # backward: act' and demod applied on the test side (the engine's seam kernel does this), then the HIP contraction
+    slope = torch.where(y > 0, sq2, 0.2 * sq2) * (y.abs() < clamp)
+    g1 = gyd * slope
+    gz = (g1 * d[:, :, None, None]).contiguous()
+    tiles = lib.la_modconv_ds_tiles(rin)
+    gx = torch.empty([B, cin, rin, rin], device=dev)
+    dsp = torch.zeros([B, cin, tiles], device=dev)
+    if up:
+        _lib.check(lib.la_modconv3x3_up2_bwd_f32(_lib.ptr(gz), _lib.ptr(wb), _lib.ptr(sd), cin, _lib.ptr(xd), cin * rin * rin,
+                                                 fir.ctypes.data, _lib.ptr(scratch), _lib.ptr(gx), _lib.ptr(dsp), B, cin, cout,
+                                                 res, st))
+    else:
+        _lib.check(lib.la_modconv3x3_bwd_f32(_lib.ptr(gz), _lib.ptr(wb), _lib.ptr(sd), cin, _lib.ptr(xd), cin * rin * rin,
+                                             _lib.ptr(gx), _lib.ptr(dsp), B, cin, cout, res, st))
+    close(gx, gxr, rtol=1e-4, atol=1e-5 * float(gxr.abs().max()))
+    # style gradient = modulation term (partials) + demodulation term (test-side, mirrors la_style_backward_conv)
+    zd = torch.where(y > 0, y / sq2, y / (0.2 * sq2)) - bd[None, :, None, None] - nd[None, None] * noise_strength
+    ddn = (g1 * zd).sum(dim=[2, 3])
+    ds = dsp.sum(dim=2) - sd * ((ddn * d * d) @ wsq)
+    close(ds, gsr, rtol=2e-4, atol=2e-5 * float(gsr.abs().max()))
+
+
+@pytest.mark.parametrize('case', [
+    dict(B=2, cin=16, cout=16, res=8, up=False, noise_strength=0.0),
+    dict(B=3, cin=32, cout=64, res=16, up=False, noise_strength=0.3),
+    dict(B=2, cin=24, cout=132, res=32, up=False, noise_strength=0.1),     # ragged channels (not multiples of the tile)
+    dict(B=1, cin=64, cout=128, res=64, up=False, noise_strength=0.0),
+    dict(B=2, cin=16, cout=16, res=8, up=True, noise_strength=0.2),
+    dict(B=2, cin=64, cout=32, res=32, up=True, noise_strength=0.0),
+    dict(B=1, cin=128, cout=64, res=64, up=True, noise_strength=0.1),
+    dict(B=2, cin=512, cout=512, res=4, up=False, noise_strength=0.0),     # the 4x4 block
+])
+def test_modconv_vs_oracle(dev, case):
+    _modconv_case(dev, seed=7, **case)
