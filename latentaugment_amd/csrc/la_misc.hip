@@ -61,7 +61,8 @@ static int act_ok(int act) { return act == LA_ACT_LINEAR || act == LA_ACT_RELU |
 
 extern "C" int la_bias_act_f32(const float* x, const float* b, float* y, long n, long stepb, int nb, int act, float alpha,
                                float gain, float clamp, hipStream_t stream) {
-    LA_CHECK_ARG(x && y && n >= 0, "bias_act: null pointer");
+    if (n == 0) return LA_OK;   // empty tensors are legal (and have null data pointers)
+    LA_CHECK_ARG(x && y && n > 0, "bias_act: null pointer");
     LA_CHECK_ARG(act_ok(act), "bias_act: only linear(1)/relu(2)/lrelu(3) are implemented on this path");
     LA_CHECK_ARG(!b || (stepb >= 1 && nb >= 1 && n % (stepb * nb) == 0), "bias_act: bias does not tile the tensor");
     if (n == 0) return LA_OK;
@@ -76,7 +77,8 @@ extern "C" int la_bias_act_f32(const float* x, const float* b, float* y, long n,
 
 extern "C" int la_bias_act_grad_f32(const float* dy, const float* yref, float* dx, float* db, long n, long stepb, int nb,
                                     int act, float alpha, float gain, float clamp, hipStream_t stream) {
-    LA_CHECK_ARG(dy && yref && dx && n >= 0, "bias_act_grad: null pointer");
+    if (n == 0) return LA_OK;
+    LA_CHECK_ARG(dy && yref && dx && n > 0, "bias_act_grad: null pointer");
     LA_CHECK_ARG(act_ok(act), "bias_act_grad: only linear(1)/relu(2)/lrelu(3) are implemented on this path");
     if (n == 0) return LA_OK;
     long blocks = la_cdiv(n, 256);
