@@ -44,7 +44,14 @@ struct LaConvArgs {
     long xin_bstride;
     float* ds_part;          // [B][M][tiles_per_sample]
     int tiles_per_sample;
+    // split-K (optional): caller-provided scratch for the K-slice partial sums; ksplit is chosen by la_conv_launch
+    float* splitk_ws;
+    long splitk_floats;
+    int ksplit;
 };
+
+// scratch floats that let every <= 32x32 launch of a (B, M) problem use split-K: slices * B * M * G, G <= 1024
+long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx);
 
 // number of pixel tiles per sample for a launch (the ds_part leading dimension)
 int la_conv_tiles_per_sample(int Gy, int Gx);

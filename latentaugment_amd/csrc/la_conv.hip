@@ -15,12 +15,34 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 int la_conv_tiles_per_sample(int Gy, int Gx) { return la_cdiv((long)Gy * Gx, NT); }
 
-template <int MT>
+long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx) {
+    const long G = (long)Gy * Gx;
+    const int nck = la_cdiv(C, KC);
+    if (G > 1024 || nck < 2) return 0;
+    const int mtiles = la_cdiv(M, M >= 128 ? 128 : 64);
+    const int ntiles_flat = la_cdiv((long)B * G, NT);
+    int ks = la_cdiv(768, (long)ntiles_flat * mtiles);
+    if (ks > nck) ks = nck;
+    if (ks < 2) return 0;
+    ks = la_cdiv(nck, la_cdiv(nck, ks));
+    return (long)ks * B * M * G;
+}
+
+// Apply the launch's epilogue to one contraction value (shared by the direct kernel and the split-K finisher).
+__device__ __forceinline__ float la_conv_epi_fwd(const LaConvArgs& a, float v, float dmv, float nz, float bv) {
+    return la_act_fwd(v * dmv + nz + bv, a.act, a.alpha, a.gain, a.clamp);
+}
+
+// SPLIT = false: one workgroup owns a (sample, 128-pixel tile, MT-channel tile) and runs the whole K loop, epilogue fused.
+// SPLIT = true : pixels of all samples are flattened (tiles may straddle samples), blockIdx.z walks K slices, raw
+//                accumulators go to ws[slice][b][m][g]; la_conv_splitk_finish_kernel sums the slices and applies the epilogue.
+//                Used for the <= 32x32 layers, whose K loop (up to 4608 deep) would otherwise serialise on a handful of CUs.
+template <int MT, bool SPLIT>
 __global__ __launch_bounds__(256) void la_conv_igemm_kernel(LaConvArgs a) {
     constexpr int TM = MT / 64;            // 32-row MFMA tiles per wave along m
     constexpr int A_F4 = (KC * MT / 4) / 256;  // float4 loads of the A slab per thread (2 for MT=128, 1 for MT=64)
-    __shared__ __attribute__((aligned(16))) float As[KC][MT];
-    __shared__ __attribute__((aligned(16))) float Bs[KC][NT];
+    __shared__ __attribute__((aligned(16))) float As[2][KC][MT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][KC][NT];
     __shared__ float red[2][MT];
 
     const int tid = threadIdx.x;
@@ -28,23 +50,31 @@ __global__ __launch_bounds__(256) void la_conv_igemm_kernel(LaConvArgs a) {
     const int wm = wid >> 1, wn = wid & 1;
     const int ntile = blockIdx.x;
     const int m0 = blockIdx.y * MT;
-    const int b = blockIdx.z;
+    const int G = a.Gy * a.Gx;
+    const int Ntot = SPLIT ? a.B * G : G;
 
     // ---- loader roles
     const int n_l = tid & (NT - 1);
     const int khalf = tid >> 7;
-    const int G = a.Gy * a.Gx;
-    const int g_l = ntile * NT + n_l;
-    const bool nvalid = g_l < G;
+    const int nidx_l = ntile * NT + n_l;
+    const bool nvalid = nidx_l < Ntot;
+    int b_l = SPLIT ? (nvalid ? nidx_l / G : 0) : (int)blockIdx.z;
+    const int g_l = SPLIT ? nidx_l - b_l * G : nidx_l;
     const int gy_l = nvalid ? g_l / a.Gx : 0;
     const int gx_l = nvalid ? g_l - gy_l * a.Gx : 0;
     const int iy0 = gy_l * a.in_sy, ix0 = gx_l * a.in_sx;
     const long HWin = (long)a.Hin * a.Win;
-    const float* in_b = a.in + (long)b * a.in_bstride;
-    const float* sc_b = a.in_scale ? a.in_scale + (long)b * a.scale_stride : nullptr;
+    const float* in_b = a.in + (long)b_l * a.in_bstride;
+    const float* sc_b = a.in_scale ? a.in_scale + (long)b_l * a.scale_stride : nullptr;
 
     const int nck = (a.C + KC - 1) / KC;
-    const int nchunks = nck * a.ntaps;
+    int ck_beg = 0, ck_end = nck;
+    if (SPLIT) {
+        const int per = (nck + a.ksplit - 1) / a.ksplit;
+        ck_beg = blockIdx.z * per;
+        ck_end = ck_beg + per < nck ? ck_beg + per : nck;
+    }
+    const int ci_beg = ck_beg * a.ntaps, ci_end = ck_end * a.ntaps;
 
     float breg[KC / 2];
     float4 areg[A_F4];
@@ -77,6 +107,16 @@ __global__ __launch_bounds__(256) void la_conv_igemm_kernel(LaConvArgs a) {
             areg[j] = v;
         }
     };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < KC / 2; ++j) Bs[buf][khalf + 2 * j][n_l] = breg[j];
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) {
+            const int idx = tid + 256 * j;
+            const int row = idx / (MT / 4), col = (idx - row * (MT / 4)) * 4;
+            *reinterpret_cast<float4*>(&As[buf][row][col]) = areg[j];
+        }
+    };
 
     f32x16 acc[TM][2];
 #pragma unroll
@@ -86,37 +126,54 @@ __global__ __launch_bounds__(256) void la_conv_igemm_kernel(LaConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    prefetch(0);
     const int l31 = lane & 31, lh = lane >> 5;
-    for (int ci = 0; ci < nchunks; ++ci) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < KC / 2; ++j) Bs[khalf + 2 * j][n_l] = breg[j];
-#pragma unroll
-        for (int j = 0; j < A_F4; ++j) {
-            const int idx = tid + 256 * j;
-            const int row = idx / (MT / 4), col = (idx - row * (MT / 4)) * 4;
-            *reinterpret_cast<float4*>(&As[row][col]) = areg[j];
-        }
-        __syncthreads();
-        if (ci + 1 < nchunks) prefetch(ci + 1);
+    if (ci_beg < ci_end) {
+        prefetch(ci_beg);
+        stage(0);
+    }
+    __syncthreads();
+    // double-buffered LDS, one barrier per chunk: loads for chunk i+1 are in flight while chunk i feeds the MFMAs
+    for (int ci = ci_beg; ci < ci_end; ++ci) {
+        const int buf = (ci - ci_beg) & 1;
+        if (ci + 1 < ci_end) prefetch(ci + 1);
 #pragma unroll
         for (int kp = 0; kp < KC / 2; ++kp) {
             float av[TM], bv[2];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = As[2 * kp + lh][wm * (MT / 2) + i * 32 + l31];
+            for (int i = 0; i < TM; ++i) av[i] = As[buf][2 * kp + lh][wm * (MT / 2) + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bv[j] = Bs[2 * kp + lh][wn * 64 + j * 32 + l31];
+            for (int j = 0; j < 2; ++j) bv[j] = Bs[buf][2 * kp + lh][wn * 64 + j * 32 + l31];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
+        if (ci + 1 < ci_end) stage(buf ^ 1);
+        __syncthreads();
     }
 
     // ---- epilogue.  acc[i][j][r]: m = m0 + wm*(MT/2) + i*32 + (r&3) + 8*(r>>2) + 4*lh ; pixel = ntile*NT + wn*64 + j*32 + l31
-    int pix_off[2];
+    if (SPLIT) {
+        // raw slice accumulators -> ws[slice][b][m][g]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nidx = ntile * NT + wn * 64 + j * 32 + l31;
+            if (nidx >= Ntot) continue;
+            const int b = nidx / G, g = nidx - b * G;
+            float* wsp = a.splitk_ws + (((long)blockIdx.z * a.B + b) * a.M) * G + g;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * (MT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < a.M) wsp[(long)m * G] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+
+    const int b = blockIdx.z;
     bool pix_ok[2];
     long npos[2];
 #pragma unroll
@@ -126,8 +183,7 @@ __global__ __launch_bounds__(256) void la_conv_igemm_kernel(LaConvArgs a) {
         const int gy = pix_ok[j] ? g / a.Gx : 0;
         const int gx = pix_ok[j] ? g - gy * a.Gx : 0;
         const int oy = gy * a.out_sy + a.out_oy, ox = gx * a.out_sx + a.out_ox;
-        pix_off[j] = oy * a.Wout + ox;
-        npos[j] = (long)pix_off[j];
+        npos[j] = (long)oy * a.Wout + ox;
     }
     const long HWout = (long)a.Hout * a.Wout;
     float* out_b = a.out + (long)b * a.M * HWout;
@@ -191,10 +247,47 @@ __global__ __launch_bounds__(256) void la_conv_igemm_kernel(LaConvArgs a) {
             for (int j = 0; j < 2; ++j) {
                 if (!pix_ok[j]) continue;
                 float v = acc[i][j][r];
-                if (fwd) v = la_act_fwd(v * dmv + nz[j] + bv, a.act, a.alpha, a.gain, a.clamp);
+                if (fwd) v = la_conv_epi_fwd(a, v, dmv, nz[j], bv);
                 out_b[(long)m * HWout + npos[j]] = v;
             }
         }
+    }
+}
+
+// Split-K finisher: one wave per (b, m) plane of the output grid; sums the K slices in a fixed order and applies the
+// same epilogue as the direct kernel (deterministic).
+__global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (m >= a.M) return;
+    const int G = a.Gy * a.Gx;
+    const long HWout = (long)a.Hout * a.Wout;
+    const long slice = (long)a.B * a.M * G;
+    const float* wsp = a.splitk_ws + ((long)b * a.M + m) * G;
+    float* out_p = a.out + ((long)b * a.M + m) * HWout;
+    const float dmv = (a.epi == LA_EPI_FWD && a.demod) ? a.demod[(long)b * a.demod_stride + m] : 1.f;
+    const float bv = (a.epi == LA_EPI_FWD && a.bias) ? a.bias[m] : 0.f;
+    const float sc = (a.epi == LA_EPI_BWD && a.out_scale) ? a.out_scale[(long)b * a.oscale_stride + m] : 1.f;
+    const float* xin_p = (a.epi == LA_EPI_BWD && a.xin) ? a.xin + (long)b * a.xin_bstride + (long)m * HWout : nullptr;
+    float part = 0.f;
+    for (int g = lane; g < G; g += 64) {
+        float v = 0.f;
+        for (int k = 0; k < a.ksplit; ++k) v += wsp[(long)k * slice + g];
+        const int gy = g / a.Gx, gx = g - gy * a.Gx;
+        const long pos = (long)(gy * a.out_sy + a.out_oy) * a.Wout + gx * a.out_sx + a.out_ox;
+        if (a.epi == LA_EPI_FWD) {
+            const float nz = a.noise ? a.noise[(long)b * a.noise_bstride + pos] * a.noise_strength : 0.f;
+            v = la_conv_epi_fwd(a, v, dmv, nz, bv);
+        } else if (a.epi == LA_EPI_BWD) {
+            if (xin_p) part += v * xin_p[pos];
+            v *= sc;
+        }
+        out_p[pos] = v;
+    }
+    if (a.epi == LA_EPI_BWD && a.ds_part) {
+        part = la_wave_sum(part);
+        if (lane < a.tiles_per_sample) a.ds_part[((long)b * a.M + m) * a.tiles_per_sample + lane] = lane == 0 ? part : 0.f;
     }
 }
 
@@ -267,12 +360,33 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
             g_prof.overflow = 1;
         }
     }
-    if (a.M >= 128) {
-        dim3 grid(tiles, la_cdiv(a.M, 128), a.B);
-        hipLaunchKernelGGL(la_conv_igemm_kernel<128>, grid, dim3(256), 0, stream, a);
-    } else {
-        dim3 grid(tiles, la_cdiv(a.M, 64), a.B);
-        hipLaunchKernelGGL(la_conv_igemm_kernel<64>, grid, dim3(256), 0, stream, a);
+    // split-K for the small-resolution layers (see kernel comment)
+    LaConvArgs as = a;
+    as.ksplit = 1;
+    const long G = (long)a.Gy * a.Gx;
+    const int nck = la_cdiv(a.C, KC);
+    const int MTsel = a.M >= 128 ? 128 : 64;
+    const int mtiles = la_cdiv(a.M, MTsel);
+    if (a.splitk_ws && G <= 1024 && nck >= 2) {
+        const int ntiles_flat = la_cdiv((long)a.B * G, NT);
+        int ks = la_cdiv(768, (long)ntiles_flat * mtiles);
+        if (ks > nck) ks = nck;
+        if (ks >= 2) {
+            const int per = la_cdiv(nck, ks);
+            ks = la_cdiv(nck, per);
+            if ((long)ks * a.B * a.M * G <= a.splitk_floats && ks >= 2) {
+                as.ksplit = ks;
+                dim3 grid(ntiles_flat, mtiles, ks);
+                if (MTsel == 128) hipLaunchKernelGGL((la_conv_igemm_kernel<128, true>), grid, dim3(256), 0, stream, as);
+                else hipLaunchKernelGGL((la_conv_igemm_kernel<64, true>), grid, dim3(256), 0, stream, as);
+                hipLaunchKernelGGL(la_conv_splitk_finish_kernel, dim3(la_cdiv(a.M, 4), a.B), dim3(256), 0, stream, as);
+            }
+        }
+    }
+    if (as.ksplit == 1) {
+        dim3 grid(tiles, mtiles, a.B);
+        if (MTsel == 128) hipLaunchKernelGGL((la_conv_igemm_kernel<128, false>), grid, dim3(256), 0, stream, as);
+        else hipLaunchKernelGGL((la_conv_igemm_kernel<64, false>), grid, dim3(256), 0, stream, as);
     }
     LA_CHECK_LAUNCH();
     if (pslot >= 0) LA_HIP(hipEventRecord(g_prof.ev1[pslot], stream));

@@ -71,14 +71,21 @@ __global__ __launch_bounds__(256) void la_sum_scale_kernel(const float* __restri
     if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + t * scale;
 }
 
-// colsum[k] = sum_m Y[m][k]
+// colsum[k] = sum_m Y[m][k].  Block = 64 columns x 4 row groups (wave w takes rows w, w+4, ...), combined through LDS.
 __global__ __launch_bounds__(256) void la_bank_colsum_kernel(const float* __restrict__ Y, long m, long K,
                                                             float* __restrict__ colsum) {
-    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
-    float acc = 0.f;
-    for (long r = 0; r < m; ++r) acc += Y[r * K + k];
-    colsum[k] = acc;
+    __shared__ float comb[4][64];
+    const int kl = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long k = (long)blockIdx.x * 64 + kl;
+    float a0 = 0.f, a1 = 0.f;
+    if (k < K) {
+        long r = w;
+        for (; r + 4 < m; r += 8) { a0 += Y[r * K + k]; a1 += Y[(r + 4) * K + k]; }
+        if (r < m) a0 += Y[r * K + k];
+    }
+    comb[w][kl] = a0 + a1;
+    __syncthreads();
+    if (w == 0 && k < K) colsum[k] = (comb[0][kl] + comb[1][kl]) + (comb[2][kl] + comb[3][kl]);
 }
 
 int la_bank_dot(const float* Y, long m, long K, const float* X, int n, long ldx, long xmod, float* yx, float* yy,
@@ -91,7 +98,7 @@ int la_bank_dot(const float* Y, long m, long K, const float* X, int n, long ldx,
 
 int la_bank_colsum(const float* Y, long m, long K, float* colsum, hipStream_t stream) {
     LA_CHECK_ARG(Y && colsum && m >= 1 && K >= 1, "bank_colsum: bad arguments");
-    hipLaunchKernelGGL(la_bank_colsum_kernel, dim3(la_cdiv(K, 256)), dim3(256), 0, stream, Y, m, K, colsum);
+    hipLaunchKernelGGL(la_bank_colsum_kernel, dim3(la_cdiv(K, 64)), dim3(256), 0, stream, Y, m, K, colsum);
     LA_CHECK_LAUNCH();
     return LA_OK;
 }

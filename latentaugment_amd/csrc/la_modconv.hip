@@ -24,11 +24,12 @@ extern "C" int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, fl
 extern "C" int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const float* s, int s_stride,
                                      const float* d, int d_stride, const float* noise, long noise_bstride,
                                      float noise_strength, const float* bias, int act, float alpha, float gain,
-                                     float clamp, float* y, int B, int cin, int cout, int res, hipStream_t stream) {
+                                     float clamp, float* y, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res, hipStream_t stream) {
     LA_CHECK_ARG(x && wf && y, "modconv_fwd: null pointer");
     LaConvArgs a; base_args(a);
     a.in = x; a.in_bstride = x_bstride; a.wgt = wf; a.out = y;
     a.in_scale = s; a.scale_stride = s_stride;
+    a.splitk_ws = splitk_ws; a.splitk_floats = splitk_floats;
     a.B = B; a.C = cin; a.M = cout; a.Hin = a.Win = a.Hout = a.Wout = a.Gy = a.Gx = res;
     a.ntaps = 9;
     for (int t = 0; t < 9; ++t) { a.tap_dy[t] = t / 3 - 1; a.tap_dx[t] = t % 3 - 1; a.tap_w[t] = t; }
@@ -42,7 +43,7 @@ extern "C" int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float
 extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const float* s, int s_stride,
                                          const float* d, int d_stride, const float* noise, long noise_bstride,
                                          float noise_strength, const float* bias, int act, float alpha, float gain,
-                                         float clamp, const float* fir_host, float* scratch, float* y, int B, int cin,
+                                         float clamp, const float* fir_host, float* scratch, float* y, float* splitk_ws, long splitk_floats, int B, int cin,
                                          int cout, int res, hipStream_t stream) {
     LA_CHECK_ARG(x && wf && y && scratch && fir_host, "modconv_up2_fwd: null pointer");
     LA_CHECK_ARG(res >= 2 && res % 2 == 0, "modconv_up2_fwd: output resolution must be even");
@@ -51,6 +52,7 @@ extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const f
     LaConvArgs a; base_args(a);
     a.in = x; a.in_bstride = x_bstride; a.wgt = wf; a.out = scratch;
     a.in_scale = s; a.scale_stride = s_stride;
+    a.splitk_ws = splitk_ws; a.splitk_floats = splitk_floats;
     a.B = B; a.C = cin; a.M = cout; a.Hin = a.Win = hin; a.Hout = a.Wout = res + 1;
     a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW;
     for (int py = 0; py < 2; ++py)
@@ -72,11 +74,12 @@ extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const f
 }
 
 extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const float* s, int s_stride, const float* xin,
-                                     long xin_bstride, float* gx, float* ds_part, int B, int cin, int cout, int res,
+                                     long xin_bstride, float* gx, float* ds_part, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res,
                                      hipStream_t stream) {
     LA_CHECK_ARG(gz && wb && gx, "modconv_bwd: null pointer");
     LaConvArgs a; base_args(a);
     a.in = gz; a.in_bstride = (long)cout * res * res; a.wgt = wb; a.out = gx;
+    a.splitk_ws = splitk_ws; a.splitk_floats = splitk_floats;
     a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = a.Hout = a.Wout = a.Gy = a.Gx = res;
     a.ntaps = 9;
     for (int t = 0; t < 9; ++t) { a.tap_dy[t] = 1 - t / 3; a.tap_dx[t] = 1 - t % 3; a.tap_w[t] = t; }
@@ -89,7 +92,8 @@ extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const flo
 
 extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const float* s, int s_stride, const float* xin,
                                          long xin_bstride, const float* fir_host, float* scratch, float* gx,
-                                         float* ds_part, int B, int cin, int cout, int res, hipStream_t stream) {
+                                         float* ds_part, float* splitk_ws, long splitk_floats, int B, int cin, int cout,
+                                         int res, hipStream_t stream) {
     LA_CHECK_ARG(gz && wb && gx && scratch && fir_host, "modconv_up2_bwd: null pointer");
     const int hin = res / 2;
     // adjoint of [pad (1,1,1,1) -> FIR]: pad fw-1-pad = 2 per side, flipped filter, same gain (upfirdn2d.py:255-266)
@@ -97,6 +101,7 @@ extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const
     if (rc) return rc;
     LaConvArgs a; base_args(a);
     a.in = scratch; a.in_bstride = (long)cout * (res + 1) * (res + 1); a.wgt = wb; a.out = gx;
+    a.splitk_ws = splitk_ws; a.splitk_floats = splitk_floats;
     a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = res + 1; a.Hout = a.Wout = a.Gy = a.Gx = hin;
     a.in_sy = a.in_sx = 2; a.ntaps = 9;
     for (int t = 0; t < 9; ++t) { a.tap_dy[t] = t / 3; a.tap_dx[t] = t % 3; a.tap_w[t] = t; }
@@ -108,3 +113,19 @@ extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const
 }
 
 extern "C" int la_modconv_ds_tiles(int grid_res) { return la_conv_tiles_per_sample(grid_res, grid_res); }
+
+// scratch floats that enable split-K for a layer (0: the layer never uses it).  Covers forward and backward launches.
+extern "C" long la_modconv_splitk_floats(int B, int cin, int cout, int res, int up) {
+    long need = 0;
+    if (up) {
+        const int hin = res / 2;
+        long f = la_conv_splitk_floats(B, cout, cin, hin + 1, hin + 1);   // largest forward phase grid
+        long b = la_conv_splitk_floats(B, cin, cout, hin, hin);
+        need = f > b ? f : b;
+    } else {
+        long f = la_conv_splitk_floats(B, cout, cin, res, res);
+        long b = la_conv_splitk_floats(B, cin, cout, res, res);
+        need = f > b ? f : b;
+    }
+    return need;
+}

@@ -58,5 +58,6 @@ int la_style_backward_conv(const float* ds_part, int ntiles, const float* ddn_pa
                            float* ds_out, int ds_stride, hipStream_t);
 int la_style_backward_rgb(const float* dweff_part, int nslabs, const float* wrgb, int C, int imgc, int B,
                           float* ds_out, int ds_stride, hipStream_t);
-int la_affine_backward(const LaStyleTable& t, const float* ds_all, int B, int wdim, float* dws, int num_ws,
+int la_affine_bwd_chunks(const LaStyleTable& t);   // part scratch = chunks * B * wdim floats
+int la_affine_backward(const LaStyleTable& t, const float* ds_all, int B, int wdim, float* dws, int num_ws, float* part,
                        hipStream_t);

@@ -277,7 +277,9 @@ __global__ __launch_bounds__(256) void la_style_bwd_conv_kernel(const float* __r
                                                                const float* __restrict__ s, int s_stride,
                                                                const float* __restrict__ wsq, int cin, int cout,
                                                                float* __restrict__ ds_out, int ds_stride) {
-    extern __shared__ float q[];   // [cout]
+    // block = 64 input channels x 4 output-channel quarters; q[b][o] staged in LDS, quarters combined through LDS
+    extern __shared__ float q[];   // [cout] + [4][64]
+    float* comb = q + cout;
     const int b = blockIdx.y;
     for (int o = threadIdx.x; o < cout; o += blockDim.x) {
         float v = 0.f;
@@ -286,19 +288,28 @@ __global__ __launch_bounds__(256) void la_style_bwd_conv_kernel(const float* __r
         q[o] = v * dv * dv;
     }
     __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cin) return;
+    const int il = threadIdx.x & 63, qt = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
     float acc = 0.f;
-    for (int o = 0; o < cout; ++o) acc += q[o] * wsq[(long)o * cin + i];
-    float dsm = 0.f;
-    for (int k = 0; k < ntiles; ++k) dsm += ds_part[((long)b * cin + i) * ntiles + k];
-    ds_out[(long)b * ds_stride + i] = dsm - s[(long)b * s_stride + i] * acc;
+    if (i < cin) {
+        const int per = (cout + 3) / 4;
+        const int o1 = (qt + 1) * per < cout ? (qt + 1) * per : cout;
+        for (int o = qt * per; o < o1; ++o) acc += q[o] * wsq[(long)o * cin + i];
+    }
+    comb[qt * 64 + il] = acc;
+    __syncthreads();
+    if (qt == 0 && i < cin) {
+        const float tot = (comb[il] + comb[64 + il]) + (comb[128 + il] + comb[192 + il]);
+        float dsm = 0.f;
+        for (int k = 0; k < ntiles; ++k) dsm += ds_part[((long)b * cin + i) * ntiles + k];
+        ds_out[(long)b * ds_stride + i] = dsm - s[(long)b * s_stride + i] * tot;
+    }
 }
 
 int la_style_backward_conv(const float* ds_part, int ntiles, const float* ddn_part, int nslabs, const float* d,
                            int d_stride, const float* s, int s_stride, const float* wsq, int cin, int cout, int B,
                            float* ds_out, int ds_stride, hipStream_t stream) {
-    hipLaunchKernelGGL(la_style_bwd_conv_kernel, dim3(la_cdiv(cin, 256), B), dim3(256), cout * sizeof(float), stream,
+    hipLaunchKernelGGL(la_style_bwd_conv_kernel, dim3(la_cdiv(cin, 64), B), dim3(256), (cout + 256) * sizeof(float), stream,
                        ds_part, ntiles, ddn_part, nslabs, d, d_stride, s, s_stride, wsq, cin, cout, ds_out, ds_stride);
     LA_CHECK_LAUNCH();
     return LA_OK;
@@ -329,37 +340,77 @@ int la_style_backward_rgb(const float* dweff_part, int nslabs, const float* wrgb
 
 // ------------------------------------------------------------------------------------------------------------
 // affine backward: dws[b][slot][j] = wgain * sum_{l: widx_l == slot} post_gain_l * sum_i ds[b][row_l + i] * A_l[i][j]
-// one thread per j; grid (wdim/256, num_ws, ceil(B/BCH)).
-__global__ __launch_bounds__(256) void la_affine_bwd_kernel(LaStyleTable t, const float* __restrict__ ds_all, int B,
-                                                           int wdim, float wgain, float* __restrict__ dws, int num_ws) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int slot = blockIdx.y;
-    const int b0 = blockIdx.z * BCH;
-    if (j >= wdim) return;
-    float acc[BCH];
-#pragma unroll
-    for (int q = 0; q < BCH; ++q) acc[q] = 0.f;
-    for (int l = 0; l < t.nlayers; ++l) {
-        if (t.widx[l] != slot) continue;
-        const int rows = t.row_start[l + 1] - t.row_start[l];
-        const float pg = t.post_gain[l];
-        const float* A = t.aw[l];
-        for (int i = 0; i < rows; ++i) {
-            const float av = A[(long)i * wdim + j] * pg;
-#pragma unroll
-            for (int q = 0; q < BCH; ++q)
-                if (b0 + q < B) acc[q] += av * ds_all[(long)(b0 + q) * t.total_rows + t.row_start[l] + i];
-        }
+// stage 1: one block per 64-row chunk of a layer -> part[chunk][b][j] (thread = 2 consecutive j, coalesced A rows)
+// stage 2: per (b, slot, j): sum the chunks of the layers feeding that slot in a fixed order (deterministic).
+#define AFF_ROWS 64
+__device__ __forceinline__ int la_chunk_layer(const LaStyleTable& t, int chunk, int* row0) {
+    int l = 0, c0 = 0;
+    for (; l < t.nlayers; ++l) {
+        const int nc = (t.row_start[l + 1] - t.row_start[l] + AFF_ROWS - 1) / AFF_ROWS;
+        if (chunk < c0 + nc) break;
+        c0 += nc;
     }
-#pragma unroll
-    for (int q = 0; q < BCH; ++q)
-        if (b0 + q < B) dws[((long)(b0 + q) * num_ws + slot) * wdim + j] = acc[q] * wgain;
+    *row0 = (chunk - c0) * AFF_ROWS;
+    return l;
 }
 
-int la_affine_backward(const LaStyleTable& t, const float* ds_all, int B, int wdim, float* dws, int num_ws,
+__global__ __launch_bounds__(256) void la_affine_bwd_part_kernel(LaStyleTable t, const float* __restrict__ ds_all, int B,
+                                                                int wdim, float* __restrict__ part, int nchunks) {
+    const int chunk = blockIdx.x;
+    int row0;
+    const int l = la_chunk_layer(t, chunk, &row0);
+    if (l >= t.nlayers) return;
+    const int rows = t.row_start[l + 1] - t.row_start[l];
+    const int r1 = row0 + AFF_ROWS < rows ? row0 + AFF_ROWS : rows;
+    const float pg = t.post_gain[l];
+    const float* A = t.aw[l];
+    for (int b0 = blockIdx.y * BCH; b0 < B; b0 += gridDim.y * BCH) {
+        for (int j = threadIdx.x; j < wdim; j += blockDim.x) {
+            float acc[BCH];
+#pragma unroll
+            for (int q = 0; q < BCH; ++q) acc[q] = 0.f;
+            for (int i = row0; i < r1; ++i) {
+                const float av = A[(long)i * wdim + j] * pg;
+#pragma unroll
+                for (int q = 0; q < BCH; ++q)
+                    if (b0 + q < B) acc[q] += av * ds_all[(long)(b0 + q) * t.total_rows + t.row_start[l] + i];
+            }
+#pragma unroll
+            for (int q = 0; q < BCH; ++q)
+                if (b0 + q < B) part[((long)chunk * B + b0 + q) * wdim + j] = acc[q];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void la_affine_bwd_sum_kernel(LaStyleTable t, const float* __restrict__ part, int B,
+                                                               int wdim, float wgain, float* __restrict__ dws, int num_ws) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = blockIdx.y, b = blockIdx.z;
+    if (j >= wdim) return;
+    float acc = 0.f;
+    int c0 = 0;
+    for (int l = 0; l < t.nlayers; ++l) {
+        const int nc = (t.row_start[l + 1] - t.row_start[l] + AFF_ROWS - 1) / AFF_ROWS;
+        if (t.widx[l] == slot)
+            for (int c = c0; c < c0 + nc; ++c) acc += part[((long)c * B + b) * wdim + j];
+        c0 += nc;
+    }
+    dws[((long)b * num_ws + slot) * wdim + j] = acc * wgain;
+}
+
+int la_affine_bwd_chunks(const LaStyleTable& t) {
+    int n = 0;
+    for (int l = 0; l < t.nlayers; ++l) n += (t.row_start[l + 1] - t.row_start[l] + AFF_ROWS - 1) / AFF_ROWS;
+    return n;
+}
+
+int la_affine_backward(const LaStyleTable& t, const float* ds_all, int B, int wdim, float* dws, int num_ws, float* part,
                        hipStream_t stream) {
-    hipLaunchKernelGGL(la_affine_bwd_kernel, dim3(la_cdiv(wdim, 256), num_ws, la_cdiv(B, BCH)), dim3(256), 0, stream, t,
-                       ds_all, B, wdim, 1.0f / sqrtf((float)wdim), dws, num_ws);
+    const int nchunks = la_affine_bwd_chunks(t);
+    hipLaunchKernelGGL(la_affine_bwd_part_kernel, dim3(nchunks, la_cdiv(B, BCH)), dim3(256), 0, stream, t, ds_all, B, wdim,
+                       part, nchunks);
+    hipLaunchKernelGGL(la_affine_bwd_sum_kernel, dim3(la_cdiv(wdim, 256), num_ws, B), dim3(256), 0, stream, t, part, B, wdim,
+                       1.0f / sqrtf((float)wdim), dws, num_ws);
     LA_CHECK_LAUNCH();
     return LA_OK;
 }

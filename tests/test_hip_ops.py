@@ -106,7 +106,7 @@ def test_pairwise_l2_golden(dev, golden_dir):
         close(ops.l2_loss_vectorized(X, Y, compute_mean=False), gc[f'G5_{tag}_full'], rtol=1e-5, atol=1e-3)
 
 
-def _modconv_case(dev, B, cin, cout, res, up, noise_strength, seed):
+def _modconv_case(dev, B, cin, cout, res, up, noise_strength, seed, splitk=True):
     """Run the HIP modconv fwd + bwd for one layer and compare with autograd through the oracle."""
     import ctypes as C
     from latentaugment_amd import _lib
@@ -139,14 +139,16 @@ def _modconv_case(dev, B, cin, cout, res, up, noise_strength, seed):
     fir = np.ascontiguousarray(f.numpy())
     scratch = torch.empty([B * cout * (res + 1) * (res + 1)], device=dev)
     sq2 = float(np.sqrt(2))
+    skn = int(lib.la_modconv_splitk_floats(B, cin, cout, res, 1 if up else 0)) if splitk else 0
+    skw = torch.empty([max(skn, 1)], device=dev) if skn else None
     if up:
         _lib.check(lib.la_modconv3x3_up2_fwd_f32(_lib.ptr(xd), cin * rin * rin, _lib.ptr(wf), _lib.ptr(sd), cin, _lib.ptr(d),
                                                  cout, _lib.ptr(nd), 0, noise_strength, _lib.ptr(bd), 3, 0.2, sq2, clamp,
-                                                 fir.ctypes.data, _lib.ptr(scratch), _lib.ptr(y), B, cin, cout, res, st))
+                                                 fir.ctypes.data, _lib.ptr(scratch), _lib.ptr(y), _lib.ptr(skw), skn, B, cin, cout, res, st))
     else:
         _lib.check(lib.la_modconv3x3_fwd_f32(_lib.ptr(xd), cin * rin * rin, _lib.ptr(wf), _lib.ptr(sd), cin, _lib.ptr(d), cout,
                                              _lib.ptr(nd), 0, noise_strength, _lib.ptr(bd), 3, 0.2, sq2, clamp, _lib.ptr(y),
-                                             B, cin, cout, res, st))
+                                             _lib.ptr(skw), skn, B, cin, cout, res, st))
     scale = float(yr.abs().max())
     close(y, yr, rtol=1e-4, atol=1e-5 * scale)
     # backward: act' and demod applied on the test side (the engine's seam kernel does this), then the HIP contraction
@@ -158,11 +160,11 @@ def _modconv_case(dev, B, cin, cout, res, up, noise_strength, seed):
     dsp = torch.zeros([B, cin, tiles], device=dev)
     if up:
         _lib.check(lib.la_modconv3x3_up2_bwd_f32(_lib.ptr(gz), _lib.ptr(wb), _lib.ptr(sd), cin, _lib.ptr(xd), cin * rin * rin,
-                                                 fir.ctypes.data, _lib.ptr(scratch), _lib.ptr(gx), _lib.ptr(dsp), B, cin, cout,
-                                                 res, st))
+                                                 fir.ctypes.data, _lib.ptr(scratch), _lib.ptr(gx), _lib.ptr(dsp), _lib.ptr(skw), skn, B, cin,
+                                                 cout, res, st))
     else:
         _lib.check(lib.la_modconv3x3_bwd_f32(_lib.ptr(gz), _lib.ptr(wb), _lib.ptr(sd), cin, _lib.ptr(xd), cin * rin * rin,
-                                             _lib.ptr(gx), _lib.ptr(dsp), B, cin, cout, res, st))
+                                             _lib.ptr(gx), _lib.ptr(dsp), _lib.ptr(skw), skn, B, cin, cout, res, st))
     close(gx, gxr, rtol=1e-4, atol=1e-5 * float(gxr.abs().max()))
     # style gradient = modulation term (partials) + demodulation term (test-side, mirrors la_style_backward_conv)
     zd = torch.where(y > 0, y / sq2, y / (0.2 * sq2)) - bd[None, :, None, None] - nd[None, None] * noise_strength
@@ -182,4 +184,6 @@ def _modconv_case(dev, B, cin, cout, res, up, noise_strength, seed):
     dict(B=2, cin=512, cout=512, res=4, up=False, noise_strength=0.0),     # the 4x4 block
 ])
 def test_modconv_vs_oracle(dev, case):
-    _modconv_case(dev, seed=7, **case)
+    _modconv_case(dev, seed=7, **case)                    # split-K where the layer qualifies (<= 32x32)
+    if case['res'] <= 32:
+        _modconv_case(dev, seed=7, splitk=False, **case)  # same layer through the direct kernel
