@@ -38,6 +38,8 @@ def parse():
     p.add_argument('--res', type=int, default=256)
     p.add_argument('--channel-base', type=int, default=32768, help='32768 = config-f, 16384 = config-e')
     p.add_argument('--criterion-mode', default='gemm', choices=['gemm', 'collapsed'])
+    p.add_argument('--precision', default='f32', choices=['f32', 'bf16x3', 'bf16x2'],
+                   help='contraction arithmetic: exact fp32 MFMA, or fp32 split into 3 / 2 bf16 terms on the bf16 MFMA')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true', help='skip the HIP-event leg (used under rocprofv3)')
     return p.parse_args()
@@ -49,7 +51,8 @@ def make_opt(args, local_rank):
         img_resolution=args.res, batch_size=args.batch, modalities_aug='A,B', opt_num_epochs=args.latent_steps, opt_lr=0.01,
         truncation_psi=1.0, w_pix=0.1, w_lpips=0.0, w_latent=0.001, w_disc=0.0, crop_size_aug=64,
         preprocess_aug='center_random_crop', soft_aug=False, alpha=1.0, verbose_log=False, rand_aug=False,
-        lower_bound_clip=False, p_thres=0.0, init_w='inv', criterion_mode=args.criterion_mode, final_noise_mode='random')
+        lower_bound_clip=False, p_thres=0.0, init_w='inv', criterion_mode=args.criterion_mode, final_noise_mode='random',
+        precision=args.precision)
 
 
 def cpu_baseline(sd, meta, args):

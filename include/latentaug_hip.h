@@ -75,30 +75,41 @@ int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, float* wsq, i
 
 /* same-resolution layer (conv1): x [B][cin][res][res] (x_bstride = 0 broadcasts one sample), s [B][s_stride] styles,
  * d [B][d_stride] demodulation coefficients (NULL = no demod), noise [res][res] (noise_bstride 0) or per sample. */
-int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const float* s, int s_stride, const float* d,
+int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride, const float* d,
                           int d_stride, const float* noise, long noise_bstride, float noise_strength, const float* bias,
                           int act, float alpha, float gain, float clamp, float* y, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res,
                           la_stream_t stream);
 
 /* up-sampling layer (conv0): x [B][cin][res/2][res/2] -> y [B][cout][res][res];
  * scratch: B*cout*(res+1)^2 floats (the transposed-conv intermediate of conv2d_resample.py:125). */
-int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const float* s, int s_stride,
+int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
                               const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                               const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
                               float* scratch, float* y, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res, la_stream_t stream);
 
 /* backward-data + style-gradient partials.  gz [B][cout][res][res] = gradient w.r.t. the raw contraction (already
  * multiplied by d and by act').  gx = (W^T * gz) . s ;  ds_part[b][i][tile] = partial sums of sum_p (W^T*gz) . xin. */
-int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const float* s, int s_stride, const float* xin,
+int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
                           long xin_bstride, float* gx, float* ds_part, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res,
                           la_stream_t stream);
-int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const float* s, int s_stride, const float* xin,
+int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
                               long xin_bstride, const float* fir_host, float* scratch, float* gx, float* ds_part, float* splitk_ws, long splitk_floats, int B,
                               int cin, int cout, int res, la_stream_t stream);
 int la_modconv_ds_tiles(int grid_res); /* leading dimension of ds_part for a backward over a grid_res^2 grid */
 /* splitk_ws (may be NULL): scratch of la_modconv_splitk_floats() floats; with it, layers of <= 32x32 split their K loop
  * over workgroups (deterministic slice sum) instead of serialising it on a few CUs. */
 long la_modconv_splitk_floats(int B, int cin, int cout, int res, int up);
+/* Contraction precision (the `precision` argument of the la_modconv3x3_* calls; `wq` = weights packed for it or NULL):
+ *   0 LA_PREC_F32     exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ *   1 LA_PREC_BF16X3  fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate (fp32-class error)
+ *   2 LA_PREC_BF16X2  2 bf16 terms, 3 bf16 MFMAs (~4e-6 relative error per layer)
+ * wq is produced by la_pack_conv_weights_bf16_f32 (transpose = 0 for the forward calls, 1 for the backward calls). */
+#define LA_PREC_F32 0
+#define LA_PREC_BF16X3 1
+#define LA_PREC_BF16X2 2
+size_t la_modconv_bf16_pack_bytes(int cin, int cout, int transpose, int nterm);
+int la_pack_conv_weights_bf16_f32(const float* w, void* out, int cout, int cin, int ktaps, int transpose, int nterm,
+                                  la_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Criteria and optimiser
@@ -138,6 +149,9 @@ int la_synth_create(int img_resolution, int img_channels, int w_dim, const int* 
                     const float* fir_host, int fir_h, int fir_w, int max_batch, void* workspace, size_t workspace_bytes,
                     la_stream_t stream, la_synth** out);
 void la_synth_destroy(la_synth* h);
+/* contraction precision of every modulated conv of the engine (LA_PREC_*, default LA_PREC_F32) */
+int la_synth_set_precision(la_synth* h, int precision);
+int la_synth_get_precision(const la_synth* h);
 /* ws element (b,l,j) = ws[b*ws_bstride + l*ws_lstride + j] (ws_lstride = 0: W space, one w per sample).
  * noise_mode 0 'none', 1 'const', 2 explicit unit-variance tensors noises[layer] [B][res][res] ('random' drawn by the caller).
  * img_out NULL: the image stays in the engine (la_synth_image). */

@@ -14,6 +14,11 @@
 #define LA_EPI_BWD 2
 #define LA_CONV_MAX_TAPS 9
 
+// contraction arithmetic: exact fp32 MFMA, or fp32 operands split into 3 / 2 bf16 terms on the bf16 MFMA (la_conv_bf16.hip)
+#define LA_PREC_F32 0
+#define LA_PREC_BF16X3 1
+#define LA_PREC_BF16X2 2
+
 struct LaConvArgs {
     const float* in;         // [B][C][Hin][Win]; in_bstride == 0 broadcasts one sample over the batch
     const float* wgt;        // [slabs][C][M]
@@ -48,10 +53,19 @@ struct LaConvArgs {
     float* splitk_ws;
     long splitk_floats;
     int ksplit;
+    // split-bf16 path (precision != LA_PREC_F32): weights pre-split by la_pack_conv_weights_bf16
+    int precision;
+    const void* wgt_bf16;          // [term][slab][ceil(C/32)][M][32] bf16
+    long wgt_bf16_term_elems;
 };
 
+long la_conv_bf16_pack_elems(int M, int C, int ktaps);   // elements per term
+int la_pack_conv_weights_bf16(const float* w, void* out, int cout, int cin, int ktaps, int transpose, int nterm,
+                              hipStream_t stream);
+void la_conv_bf16_dispatch(const LaConvArgs& as, int MTsel, dim3 grid, bool split, hipStream_t stream);
+
 // scratch floats that let every <= 32x32 launch of a (B, M) problem use split-K: slices * B * M * G, G <= 1024
-long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx);
+long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx, int precision);
 
 // number of pixel tiles per sample for a launch (the ds_part leading dimension)
 int la_conv_tiles_per_sample(int Gy, int Gx);

@@ -7,18 +7,17 @@
 // modulation multiplied in on the way to LDS.  The next chunk's global loads are issued before the current
 // chunk's MFMAs (register-staged prefetch); fp32 MFMA takes 64 cycles per instruction so the loader has slack.
 #include "la_conv.h"
+#include "la_conv_device.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define NT 128
 #define KC 16
 
 int la_conv_tiles_per_sample(int Gy, int Gx) { return la_cdiv((long)Gy * Gx, NT); }
 
-long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx) {
+#define SPLITK_MAX_G 1156     // up to 34x34 grids (covers the 33x33 phases of the 32 -> 64 up-sampling layer)
+long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx, int precision) {
     const long G = (long)Gy * Gx;
-    const int nck = la_cdiv(C, KC);
-    if (G > 1024 || nck < 2) return 0;
+    const int nck = la_cdiv(C, precision == LA_PREC_F32 ? KC : 32);
+    if (G > SPLITK_MAX_G || nck < 2) return 0;
     const int mtiles = la_cdiv(M, M >= 128 ? 128 : 64);
     const int ntiles_flat = la_cdiv((long)B * G, NT);
     int ks = la_cdiv(768, (long)ntiles_flat * mtiles);
@@ -26,11 +25,6 @@ long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx) {
     if (ks < 2) return 0;
     ks = la_cdiv(nck, la_cdiv(nck, ks));
     return (long)ks * B * M * G;
-}
-
-// Apply the launch's epilogue to one contraction value (shared by the direct kernel and the split-K finisher).
-__device__ __forceinline__ float la_conv_epi_fwd(const LaConvArgs& a, float v, float dmv, float nz, float bv) {
-    return la_act_fwd(v * dmv + nz + bv, a.act, a.alpha, a.gain, a.clamp);
 }
 
 // SPLIT = false: one workgroup owns a (sample, 128-pixel tile, MT-channel tile) and runs the whole K loop, epilogue fused.
@@ -153,105 +147,7 @@ __global__ __launch_bounds__(256) void la_conv_igemm_kernel(LaConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue.  acc[i][j][r]: m = m0 + wm*(MT/2) + i*32 + (r&3) + 8*(r>>2) + 4*lh ; pixel = ntile*NT + wn*64 + j*32 + l31
-    if (SPLIT) {
-        // raw slice accumulators -> ws[slice][b][m][g]
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int nidx = ntile * NT + wn * 64 + j * 32 + l31;
-            if (nidx >= Ntot) continue;
-            const int b = nidx / G, g = nidx - b * G;
-            float* wsp = a.splitk_ws + (((long)blockIdx.z * a.B + b) * a.M) * G + g;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * (MT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < a.M) wsp[(long)m * G] = acc[i][j][r];
-                }
-        }
-        return;
-    }
-
-    const int b = blockIdx.z;
-    bool pix_ok[2];
-    long npos[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int g = ntile * NT + wn * 64 + j * 32 + l31;
-        pix_ok[j] = g < G;
-        const int gy = pix_ok[j] ? g / a.Gx : 0;
-        const int gx = pix_ok[j] ? g - gy * a.Gx : 0;
-        const int oy = gy * a.out_sy + a.out_oy, ox = gx * a.out_sx + a.out_ox;
-        npos[j] = (long)oy * a.Wout + ox;
-    }
-    const long HWout = (long)a.Hout * a.Wout;
-    float* out_b = a.out + (long)b * a.M * HWout;
-
-    if (a.epi == LA_EPI_BWD) {
-        const float* xin_b = a.xin ? a.xin + (long)b * a.xin_bstride : nullptr;
-        const float* os_b = a.out_scale ? a.out_scale + (long)b * a.oscale_stride : nullptr;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = wm * (MT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int m = m0 + ml;
-                const bool mok = m < a.M;
-                const float sc = (os_b && mok) ? os_b[m] : 1.f;
-                float part = 0.f;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float v = acc[i][j][r];
-                    if (mok && pix_ok[j]) {
-                        out_b[(long)m * HWout + npos[j]] = v * sc;
-                        if (xin_b) part += v * xin_b[(long)m * HWout + npos[j]];
-                    }
-                }
-                if (a.ds_part) {
-                    // sum over the 32 lanes of this half-wave (they share m)
-#pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-                    if (l31 == 0) red[wn][ml] = part;
-                }
-            }
-        }
-        if (a.ds_part) {
-            __syncthreads();
-            if (tid < MT && m0 + tid < a.M)
-                a.ds_part[((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile] = red[0][tid] + red[1][tid];
-        }
-        return;
-    }
-
-    const bool fwd = a.epi == LA_EPI_FWD;
-    const float* dm_b = (fwd && a.demod) ? a.demod + (long)b * a.demod_stride : nullptr;
-    float nz[2] = {0.f, 0.f};
-    if (fwd && a.noise) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (pix_ok[j]) nz[j] = a.noise[(long)b * a.noise_bstride + npos[j]] * a.noise_strength;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * (MT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m >= a.M) continue;
-            float dmv = 1.f, bv = 0.f;
-            if (fwd) {
-                if (dm_b) dmv = dm_b[m];
-                if (a.bias) bv = a.bias[m];
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (!pix_ok[j]) continue;
-                float v = acc[i][j][r];
-                if (fwd) v = la_conv_epi_fwd(a, v, dmv, nz[j], bv);
-                out_b[(long)m * HWout + npos[j]] = v;
-            }
-        }
-    }
+    la_conv_epilogue<MT, SPLIT>(a, acc, red, ntile, m0, G, Ntot);
 }
 
 // Split-K finisher: one wave per (b, m) plane of the output grid; sums the K slices in a fixed order and applies the
@@ -364,10 +260,12 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
     LaConvArgs as = a;
     as.ksplit = 1;
     const long G = (long)a.Gy * a.Gx;
-    const int nck = la_cdiv(a.C, KC);
+    const bool bf = a.precision != LA_PREC_F32;
+    LA_CHECK_ARG(!bf || (a.wgt_bf16 && a.wgt_bf16_term_elems > 0), "conv: split-bf16 precision needs packed bf16 weights");
+    const int nck = la_cdiv(a.C, bf ? 32 : KC);
     const int MTsel = a.M >= 128 ? 128 : 64;
     const int mtiles = la_cdiv(a.M, MTsel);
-    if (a.splitk_ws && G <= 1024 && nck >= 2) {
+    if (a.splitk_ws && G <= SPLITK_MAX_G && nck >= 2) {
         const int ntiles_flat = la_cdiv((long)a.B * G, NT);
         int ks = la_cdiv(768, (long)ntiles_flat * mtiles);
         if (ks > nck) ks = nck;
@@ -377,7 +275,8 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
             if ((long)ks * a.B * a.M * G <= a.splitk_floats && ks >= 2) {
                 as.ksplit = ks;
                 dim3 grid(ntiles_flat, mtiles, ks);
-                if (MTsel == 128) hipLaunchKernelGGL((la_conv_igemm_kernel<128, true>), grid, dim3(256), 0, stream, as);
+                if (bf) la_conv_bf16_dispatch(as, MTsel, grid, true, stream);
+                else if (MTsel == 128) hipLaunchKernelGGL((la_conv_igemm_kernel<128, true>), grid, dim3(256), 0, stream, as);
                 else hipLaunchKernelGGL((la_conv_igemm_kernel<64, true>), grid, dim3(256), 0, stream, as);
                 hipLaunchKernelGGL(la_conv_splitk_finish_kernel, dim3(la_cdiv(a.M, 4), a.B), dim3(256), 0, stream, as);
             }
@@ -385,7 +284,8 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
     }
     if (as.ksplit == 1) {
         dim3 grid(tiles, mtiles, a.B);
-        if (MTsel == 128) hipLaunchKernelGGL((la_conv_igemm_kernel<128, false>), grid, dim3(256), 0, stream, as);
+        if (bf) la_conv_bf16_dispatch(as, MTsel, grid, false, stream);
+        else if (MTsel == 128) hipLaunchKernelGGL((la_conv_igemm_kernel<128, false>), grid, dim3(256), 0, stream, as);
         else hipLaunchKernelGGL((la_conv_igemm_kernel<64, false>), grid, dim3(256), 0, stream, as);
     }
     LA_CHECK_LAUNCH();

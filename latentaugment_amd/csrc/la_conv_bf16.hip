@@ -1,0 +1,232 @@
+// Implicit-GEMM convolution on the bf16 MFMA path with fp32 operands split into bf16 terms ("split-bf16").
+//
+// fp32 MFMA runs at 1/16 of the bf16 MFMA rate on gfx950 (MI355X_MICROARCH.md, Matrix cores), so an fp32 contraction is
+// re-expressed as a few bf16 x bf16 products with fp32 accumulation:
+//     x = x_h + x_m + x_l  (each term the bf16 rounding of what the previous terms left),   same for w
+//     NTERM = 3:  x.w ~= hh + (hm + mh) + (mm + hl + lh)     6 MFMAs, error ~1e-7 relative (fp32-class; measured in
+//                                                            tests/test_hip_ops.py against an fp64 reference)
+//     NTERM = 2:  x.w ~= hh + (hm + mh)                       3 MFMAs, error ~4e-6 relative
+// bf16 x bf16 products are exact in fp32, and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the only approximation is
+// the dropped low-order cross terms.  The leading product and the correction products use separate accumulators that are
+// added once in the epilogue (small terms are not swamped inside the K loop).
+//
+// Tiling: as la_conv.hip (256 threads = 2x2 waves, tile MT x 128 pixels, wave 64x64 = 2x2 MFMA tiles), K chunk =
+// (one tap, 32 input channels) = two K=16 MFMA steps.  Weights are pre-split at pack time into
+// wgt_bf16[term][slab][ceil(C/32)][M][32] (k contiguous = the A fragment order); activations are gathered as fp32,
+// modulated, split in registers and written k-contiguous to LDS ([pixel][32] bf16, 80-byte row stride: conflict-free for
+// ds_read_b128 fragments and ds_write_b128 staging).
+#include "la_conv_device.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define KCB 32                 // channels per chunk
+#define ROWB 80                // LDS bytes per (row, 32 bf16) incl. 16 B pad
+
+// ------------------------------------------------------------------------------------------------------------
+// weight packing: W[o][i][t] (fp32) -> out[term][t][cc][m][32] bf16 with (m,k) = (o,i) forward or (i,o) backward
+__global__ void la_pack_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int cout, int cin, int ktaps,
+                                    int transpose, int nterm) {
+    const int M = transpose ? cin : cout, C = transpose ? cout : cin;
+    const int nck = (C + KCB - 1) / KCB;
+    const long per_term = (long)ktaps * nck * M * KCB;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < per_term; idx += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % KCB);
+        const int m = (int)((idx / KCB) % M);
+        const int cc = (int)((idx / ((long)KCB * M)) % nck);
+        const int t = (int)(idx / ((long)KCB * M * nck));
+        const int c = cc * KCB + k;
+        float v = 0.f;
+        if (c < C) {
+            const int o = transpose ? c : m, i = transpose ? m : c;
+            v = w[((long)o * cin + i) * ktaps + t];
+        }
+        for (int q = 0; q < nterm; ++q) {
+            const __bf16 h = (__bf16)v;
+            out[(long)q * per_term + idx] = h;
+            v -= (float)h;
+        }
+    }
+}
+
+long la_conv_bf16_pack_elems(int M, int C, int ktaps) { return (long)ktaps * la_cdiv(C, KCB) * M * KCB; }
+
+int la_pack_conv_weights_bf16(const float* w, void* out, int cout, int cin, int ktaps, int transpose, int nterm,
+                              hipStream_t stream) {
+    LA_CHECK_ARG(w && out && nterm >= 1 && nterm <= 3, "pack_bf16: bad args");
+    const long n = la_conv_bf16_pack_elems(transpose ? cin : cout, transpose ? cout : cin, ktaps);
+    long blocks = la_cdiv(n, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(la_pack_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, (__bf16*)out, cout, cin, ktaps,
+                       transpose, nterm);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+template <int MT, bool SPLIT, int NTERM>
+__global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
+    constexpr int TM = MT / 64;
+    constexpr int A_U = (MT * 4) / 256;            // 16-byte units of one term's A slab per thread (2 for MT=128, 1 for 64)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;                                   // [NTERM][MT][ROWB]
+    unsigned char* Bs = smem + NTERM * MT * ROWB;               // [NTERM][NT][ROWB]
+    float (*red)[MT] = reinterpret_cast<float (*)[MT]>(smem);   // reused after the K loop (2*MT floats)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int ntile = blockIdx.x;
+    const int m0 = blockIdx.y * MT;
+    const int G = a.Gy * a.Gx;
+    const int Ntot = SPLIT ? a.B * G : G;
+
+    // ---- loader roles: thread = (pixel n_l, 16-channel half khalf)
+    const int n_l = tid & (NT - 1);
+    const int khalf = tid >> 7;
+    const int nidx_l = ntile * NT + n_l;
+    const bool nvalid = nidx_l < Ntot;
+    const int b_l = SPLIT ? (nvalid ? nidx_l / G : 0) : (int)blockIdx.z;
+    const int g_l = SPLIT ? nidx_l - b_l * G : nidx_l;
+    const int gy_l = nvalid ? g_l / a.Gx : 0;
+    const int gx_l = nvalid ? g_l - gy_l * a.Gx : 0;
+    const int iy0 = gy_l * a.in_sy, ix0 = gx_l * a.in_sx;
+    const long HWin = (long)a.Hin * a.Win;
+    const float* in_b = a.in + (long)b_l * a.in_bstride;
+    const float* sc_b = a.in_scale ? a.in_scale + (long)b_l * a.scale_stride : nullptr;
+
+    const int nck = (a.C + KCB - 1) / KCB;
+    int ck_beg = 0, ck_end = nck;
+    if (SPLIT) {
+        const int per = (nck + a.ksplit - 1) / a.ksplit;
+        ck_beg = blockIdx.z * per;
+        ck_end = ck_beg + per < nck ? ck_beg + per : nck;
+    }
+    const int ci_beg = ck_beg * a.ntaps, ci_end = ck_end * a.ntaps;
+    const long term_elems = a.wgt_bf16_term_elems;    // elements per term in the packed weights
+    const __bf16* wbase = reinterpret_cast<const __bf16*>(a.wgt_bf16);
+
+    float breg[16];
+    uint4 areg[NTERM][A_U];
+
+    auto prefetch = [&](int ci) {
+        const int cc = ci / a.ntaps;
+        const int t = ci - cc * a.ntaps;
+        const int c0 = cc * KCB + khalf * 16;
+        const int iy = iy0 + a.tap_dy[t], ix = ix0 + a.tap_dx[t];
+        const bool ok = nvalid && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const long off = (long)iy * a.Win + ix;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = c0 + j;
+            float v = 0.f;
+            if (ok && c < a.C) {
+                v = in_b[(long)c * HWin + off];
+                if (sc_b) v *= sc_b[c];
+            }
+            breg[j] = v;
+        }
+        // A: contiguous [M][32] bf16 slab of (tap slab, channel chunk); rows m0 .. m0+MT
+        const __bf16* slab = wbase + (((long)a.tap_w[t] * nck + cc) * a.M + m0) * KCB;
+#pragma unroll
+        for (int q = 0; q < NTERM; ++q)
+#pragma unroll
+            for (int u = 0; u < A_U; ++u) {
+                const int unit = tid + 256 * u;          // 16-byte unit: row = unit/4, piece = unit%4
+                const int row = unit >> 2;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (m0 + row < a.M) v = *reinterpret_cast<const uint4*>(slab + (long)q * term_elems + (long)unit * 8);
+                areg[q][u] = v;
+            }
+    };
+    auto stage = [&]() {
+        // split the 16 fp32 activations into NTERM bf16 terms, k-contiguous
+        bf16x8 lo8[NTERM], hi8[NTERM];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float v = breg[j];
+#pragma unroll
+            for (int q = 0; q < NTERM; ++q) {
+                const __bf16 h = (__bf16)v;
+                if (j < 8) lo8[q][j] = h; else hi8[q][j - 8] = h;
+                v -= (float)h;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NTERM; ++q) {
+            unsigned char* p = Bs + ((long)q * NT + n_l) * ROWB + khalf * 32;
+            *reinterpret_cast<bf16x8*>(p) = lo8[q];
+            *reinterpret_cast<bf16x8*>(p + 16) = hi8[q];
+#pragma unroll
+            for (int u = 0; u < A_U; ++u) {
+                const int unit = tid + 256 * u;
+                *reinterpret_cast<uint4*>(As + ((long)q * MT + (unit >> 2)) * ROWB + (unit & 3) * 16) = areg[q][u];
+            }
+        }
+    };
+
+    f32x16 acc[TM][2], cor[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; cor[i][j][r] = 0.f; }
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    if (ci_beg < ci_end) prefetch(ci_beg);
+    for (int ci = ci_beg; ci < ci_end; ++ci) {
+        __syncthreads();                 // everyone is done reading the previous chunk
+        stage();
+        __syncthreads();
+        if (ci + 1 < ci_end) prefetch(ci + 1);     // global loads fly under the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[NTERM][TM], bf[NTERM][2];
+#pragma unroll
+            for (int q = 0; q < NTERM; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[q][i] = *reinterpret_cast<const bf16x8*>(As + ((long)q * MT + wm * (MT / 2) + i * 32 + l31) * ROWB + ks * 32 + lh * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bf[q][j] = *reinterpret_cast<const bf16x8*>(Bs + ((long)q * NT + wn * 64 + j * 32 + l31) * ROWB + ks * 32 + lh * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);   // hh
+                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], cor[i][j], 0, 0, 0);   // hm
+                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], cor[i][j], 0, 0, 0);   // mh
+                    if (NTERM == 3) {
+                        cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], cor[i][j], 0, 0, 0);   // mm
+                        cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], cor[i][j], 0, 0, 0);   // hl
+                        cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], cor[i][j], 0, 0, 0);   // lh
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] += cor[i][j];
+    __syncthreads();     // LDS is reused by the epilogue's reduction scratch
+    la_conv_epilogue<MT, SPLIT>(a, acc, red, ntile, m0, G, Ntot);
+}
+
+template <int NTERM>
+static void launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, hipStream_t stream) {
+    const size_t lds128 = (size_t)NTERM * (128 + NT) * ROWB, lds64 = (size_t)NTERM * (64 + NT) * ROWB;
+    if (MTsel == 128) {
+        if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, NTERM>), grid, dim3(256), lds128, stream, as);
+        else hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, NTERM>), grid, dim3(256), lds128, stream, as);
+    } else {
+        if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<64, true, NTERM>), grid, dim3(256), lds64, stream, as);
+        else hipLaunchKernelGGL((la_conv_bf16_kernel<64, false, NTERM>), grid, dim3(256), lds64, stream, as);
+    }
+}
+
+void la_conv_bf16_dispatch(const LaConvArgs& as, int MTsel, dim3 grid, bool split, hipStream_t stream) {
+    if (as.precision == LA_PREC_BF16X3) launch_bf16<3>(as, MTsel, grid, split, stream);
+    else launch_bf16<2>(as, MTsel, grid, split, stream);
+}

@@ -1,0 +1,121 @@
+// Device-side pieces shared by the contraction kernels (fp32 MFMA and split-bf16 MFMA): the fused epilogue.
+// Both kernel families leave the same accumulator fragment: acc[i][j][r] of a 32x32 MFMA tile,
+//   m = m0 + wm*(MT/2) + i*32 + (r&3) + 8*(r>>2) + 4*(lane>>5) ;  pixel = ntile*128 + wn*64 + j*32 + (lane&31).
+#pragma once
+#include "la_conv.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NT 128
+
+__device__ __forceinline__ float la_conv_epi_fwd(const LaConvArgs& a, float v, float dmv, float nz, float bv) {
+    return la_act_fwd(v * dmv + nz + bv, a.act, a.alpha, a.gain, a.clamp);
+}
+
+template <int MT, bool SPLIT>
+__device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&acc)[MT / 64][2], float (*red)[MT],
+                                                 int ntile, int m0, int G, int Ntot) {
+    constexpr int TM = MT / 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    if (SPLIT) {
+        // raw slice accumulators -> ws[slice][b][m][g]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nidx = ntile * NT + wn * 64 + j * 32 + l31;
+            if (nidx >= Ntot) continue;
+            const int b = nidx / G, g = nidx - b * G;
+            float* wsp = a.splitk_ws + (((long)blockIdx.z * a.B + b) * a.M) * G + g;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * (MT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < a.M) wsp[(long)m * G] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+
+    const int b = blockIdx.z;
+    bool pix_ok[2];
+    long npos[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g = ntile * NT + wn * 64 + j * 32 + l31;
+        pix_ok[j] = g < G;
+        const int gy = pix_ok[j] ? g / a.Gx : 0;
+        const int gx = pix_ok[j] ? g - gy * a.Gx : 0;
+        const int oy = gy * a.out_sy + a.out_oy, ox = gx * a.out_sx + a.out_ox;
+        npos[j] = (long)oy * a.Wout + ox;
+    }
+    const long HWout = (long)a.Hout * a.Wout;
+    float* out_b = a.out + (long)b * a.M * HWout;
+
+    if (a.epi == LA_EPI_BWD) {
+        const float* xin_b = a.xin ? a.xin + (long)b * a.xin_bstride : nullptr;
+        const float* os_b = a.out_scale ? a.out_scale + (long)b * a.oscale_stride : nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * (MT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + ml;
+                const bool mok = m < a.M;
+                const float sc = (os_b && mok) ? os_b[m] : 1.f;
+                float part = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float v = acc[i][j][r];
+                    if (mok && pix_ok[j]) {
+                        out_b[(long)m * HWout + npos[j]] = v * sc;
+                        if (xin_b) part += v * xin_b[(long)m * HWout + npos[j]];
+                    }
+                }
+                if (a.ds_part) {
+                    // sum over the 32 lanes of this half-wave (they share m)
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                    if (l31 == 0) red[wn][ml] = part;
+                }
+            }
+        }
+        if (a.ds_part) {
+            __syncthreads();
+            if (tid < MT && m0 + tid < a.M)
+                a.ds_part[((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile] = red[0][tid] + red[1][tid];
+        }
+        return;
+    }
+
+    const bool fwd = a.epi == LA_EPI_FWD;
+    const float* dm_b = (fwd && a.demod) ? a.demod + (long)b * a.demod_stride : nullptr;
+    float nz[2] = {0.f, 0.f};
+    if (fwd && a.noise) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (pix_ok[j]) nz[j] = a.noise[(long)b * a.noise_bstride + npos[j]] * a.noise_strength;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * (MT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= a.M) continue;
+            float dmv = 1.f, bv = 0.f;
+            if (fwd) {
+                if (dm_b) dmv = dm_b[m];
+                if (a.bias) bv = a.bias[m];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (!pix_ok[j]) continue;
+                float v = acc[i][j][r];
+                if (fwd) v = la_conv_epi_fwd(a, v, dmv, nz[j], bv);
+                out_b[(long)m * HWout + npos[j]] = v;
+            }
+        }
+    }
+}

@@ -21,7 +21,7 @@ extern "C" int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, fl
     return la_pack_conv_weights(w, wf, wb, wsq, cout, cin, ktaps, stream);
 }
 
-extern "C" int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const float* s, int s_stride,
+extern "C" int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
                                      const float* d, int d_stride, const float* noise, long noise_bstride,
                                      float noise_strength, const float* bias, int act, float alpha, float gain,
                                      float clamp, float* y, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res, hipStream_t stream) {
@@ -30,6 +30,7 @@ extern "C" int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float
     a.in = x; a.in_bstride = x_bstride; a.wgt = wf; a.out = y;
     a.in_scale = s; a.scale_stride = s_stride;
     a.splitk_ws = splitk_ws; a.splitk_floats = splitk_floats;
+    a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cout, cin, 9);
     a.B = B; a.C = cin; a.M = cout; a.Hin = a.Win = a.Hout = a.Wout = a.Gy = a.Gx = res;
     a.ntaps = 9;
     for (int t = 0; t < 9; ++t) { a.tap_dy[t] = t / 3 - 1; a.tap_dx[t] = t % 3 - 1; a.tap_w[t] = t; }
@@ -40,7 +41,7 @@ extern "C" int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float
     return la_conv_launch(a, stream);
 }
 
-extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const float* s, int s_stride,
+extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
                                          const float* d, int d_stride, const float* noise, long noise_bstride,
                                          float noise_strength, const float* bias, int act, float alpha, float gain,
                                          float clamp, const float* fir_host, float* scratch, float* y, float* splitk_ws, long splitk_floats, int B, int cin,
@@ -53,6 +54,7 @@ extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const f
     a.in = x; a.in_bstride = x_bstride; a.wgt = wf; a.out = scratch;
     a.in_scale = s; a.scale_stride = s_stride;
     a.splitk_ws = splitk_ws; a.splitk_floats = splitk_floats;
+    a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cout, cin, 9);
     a.B = B; a.C = cin; a.M = cout; a.Hin = a.Win = hin; a.Hout = a.Wout = res + 1;
     a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW;
     for (int py = 0; py < 2; ++py)
@@ -73,13 +75,14 @@ extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const f
                                          noise, noise_bstride, noise_strength, bias, act, alpha, gain, clamp, stream);
 }
 
-extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const float* s, int s_stride, const float* xin,
+extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
                                      long xin_bstride, float* gx, float* ds_part, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res,
                                      hipStream_t stream) {
     LA_CHECK_ARG(gz && wb && gx, "modconv_bwd: null pointer");
     LaConvArgs a; base_args(a);
     a.in = gz; a.in_bstride = (long)cout * res * res; a.wgt = wb; a.out = gx;
     a.splitk_ws = splitk_ws; a.splitk_floats = splitk_floats;
+    a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cin, cout, 9);
     a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = a.Hout = a.Wout = a.Gy = a.Gx = res;
     a.ntaps = 9;
     for (int t = 0; t < 9; ++t) { a.tap_dy[t] = 1 - t / 3; a.tap_dx[t] = 1 - t % 3; a.tap_w[t] = t; }
@@ -90,7 +93,7 @@ extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const flo
     return la_conv_launch(a, stream);
 }
 
-extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const float* s, int s_stride, const float* xin,
+extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
                                          long xin_bstride, const float* fir_host, float* scratch, float* gx,
                                          float* ds_part, float* splitk_ws, long splitk_floats, int B, int cin, int cout,
                                          int res, hipStream_t stream) {
@@ -102,6 +105,7 @@ extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const
     LaConvArgs a; base_args(a);
     a.in = scratch; a.in_bstride = (long)cout * (res + 1) * (res + 1); a.wgt = wb; a.out = gx;
     a.splitk_ws = splitk_ws; a.splitk_floats = splitk_floats;
+    a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cin, cout, 9);
     a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = res + 1; a.Hout = a.Wout = a.Gy = a.Gx = hin;
     a.in_sy = a.in_sx = 2; a.ntaps = 9;
     for (int t = 0; t < 9; ++t) { a.tap_dy[t] = t / 3; a.tap_dx[t] = t % 3; a.tap_w[t] = t; }
@@ -117,15 +121,28 @@ extern "C" int la_modconv_ds_tiles(int grid_res) { return la_conv_tiles_per_samp
 // scratch floats that enable split-K for a layer (0: the layer never uses it).  Covers forward and backward launches.
 extern "C" long la_modconv_splitk_floats(int B, int cin, int cout, int res, int up) {
     long need = 0;
-    if (up) {
-        const int hin = res / 2;
-        long f = la_conv_splitk_floats(B, cout, cin, hin + 1, hin + 1);   // largest forward phase grid
-        long b = la_conv_splitk_floats(B, cin, cout, hin, hin);
-        need = f > b ? f : b;
-    } else {
-        long f = la_conv_splitk_floats(B, cout, cin, res, res);
-        long b = la_conv_splitk_floats(B, cin, cout, res, res);
-        need = f > b ? f : b;
+    for (int prec = 0; prec <= 2; ++prec) {      // enough for every contraction precision
+        long f, b;
+        if (up) {
+            const int hin = res / 2;
+            f = la_conv_splitk_floats(B, cout, cin, hin + 1, hin + 1, prec);   // largest forward phase grid
+            b = la_conv_splitk_floats(B, cin, cout, hin, hin, prec);
+        } else {
+            f = la_conv_splitk_floats(B, cout, cin, res, res, prec);
+            b = la_conv_splitk_floats(B, cin, cout, res, res, prec);
+        }
+        if (f > need) need = f;
+        if (b > need) need = b;
     }
     return need;
+}
+
+// split-bf16 weight packs: bytes for one direction (forward: transpose = 0, backward: transpose = 1), nterm terms
+extern "C" size_t la_modconv_bf16_pack_bytes(int cin, int cout, int transpose, int nterm) {
+    return (size_t)nterm * (size_t)la_conv_bf16_pack_elems(transpose ? cin : cout, transpose ? cout : cin, 9) * 2;
+}
+
+extern "C" int la_pack_conv_weights_bf16_f32(const float* w, void* out, int cout, int cin, int ktaps, int transpose,
+                                             int nterm, hipStream_t stream) {
+    return la_pack_conv_weights_bf16(w, out, cout, cin, ktaps, transpose, nterm, stream);
 }

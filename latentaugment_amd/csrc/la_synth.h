@@ -13,6 +13,8 @@ int la_synth_create(int img_resolution, int img_channels, int w_dim, const int* 
                     const float* fir_host, int fir_h, int fir_w, int max_batch, void* workspace, size_t workspace_bytes,
                     hipStream_t stream, la_synth** out);
 void la_synth_destroy(la_synth* h);
+int la_synth_set_precision(la_synth* h, int precision);
+int la_synth_get_precision(const la_synth* h);
 int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, long ws_lstride, int B, int noise_mode,
                      const float* const* noises, float* img_out, hipStream_t stream);
 int la_synth_backward(la_synth* h, const float* g_img, float* dws, hipStream_t stream);

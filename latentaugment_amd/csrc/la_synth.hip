@@ -19,7 +19,8 @@ struct ConvLayer {
     int cin, cout, res, up, widx;
     const float *affine_w, *affine_b, *weight, *bias, *noise_const;
     float noise_strength;
-    float *wf, *wb, *wsq;   // packed
+    float *wf, *wb, *wsq;   // packed (fp32)
+    void *wqf, *wqb;        // packed split-bf16 (3 terms), forward / backward
     float* y;               // saved output [maxB][cout][res*res]
     int s_off, d_off, style_idx;
     const float* noise_used;   // set by forward (null when the term vanishes)
@@ -49,6 +50,7 @@ struct la_synth {
     float *zT, *G0, *G1, *ds_part, *ddn_part, *dweff_part, *splitk, *aff_part;
     long splitk_floats;
     int lastB;
+    int precision;
     float* final_img;   // where the last forward put the full-resolution image
 };
 
@@ -73,6 +75,8 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
         ConvLayer& L = h->conv[k];
         const size_t wn = (size_t)L.cin * L.cout;
         L.wf = c.take(9 * wn); L.wb = c.take(9 * wn); L.wsq = c.take(wn);
+        L.wqf = c.take((la_modconv_bf16_pack_bytes(L.cin, L.cout, 0, 3) + 3) / 4);
+        L.wqb = c.take((la_modconv_bf16_pack_bytes(L.cin, L.cout, 1, 3) + 3) / 4);
         const size_t hw = (size_t)L.res * L.res;
         L.y = c.take(mb * L.cout * hw);
         if (mb * L.cout * hw > gmax) gmax = mb * L.cout * hw;
@@ -216,6 +220,8 @@ extern "C" int la_synth_create(int img_resolution, int img_channels, int w_dim, 
             h->st.aw[L.style_idx] = L.affine_w; h->st.ab[L.style_idx] = L.affine_b;
             h->dt.wsq[ci] = L.wsq;
             rc = la_pack_conv_weights(L.weight, L.wf, L.wb, L.wsq, L.cout, L.cin, 9, stream);
+            if (!rc) rc = la_pack_conv_weights_bf16_f32(L.weight, L.wqf, L.cout, L.cin, 9, 0, 3, stream);
+            if (!rc) rc = la_pack_conv_weights_bf16_f32(L.weight, L.wqb, L.cout, L.cin, 9, 1, 3, stream);
             if (rc) { free(h); return rc; }
             ++ci;
         }
@@ -229,6 +235,14 @@ extern "C" int la_synth_create(int img_resolution, int img_channels, int w_dim, 
 }
 
 extern "C" void la_synth_destroy(la_synth* h) { free(h); }
+
+// contraction arithmetic of every modulated conv of the engine: 0 fp32 MFMA, 1 split-bf16 x3 (fp32-class), 2 split-bf16 x2
+extern "C" int la_synth_set_precision(la_synth* h, int precision) {
+    LA_CHECK_ARG(h && precision >= 0 && precision <= 2, "synth_set_precision: precision must be 0, 1 or 2");
+    h->precision = precision;
+    return LA_OK;
+}
+extern "C" int la_synth_get_precision(const la_synth* h) { return h ? h->precision : -1; }
 
 extern "C" const float* la_synth_image(const la_synth* h) { return h ? h->final_img : nullptr; }
 extern "C" const float* la_synth_block_image(const la_synth* h, int k) { return (h && k >= 0 && k < h->nblocks) ? h->rgb[k].img : nullptr; }
@@ -262,11 +276,11 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
             }
             const float sq2 = sqrtf(2.f);
             if (!L.up)
-                rc = la_modconv3x3_fwd_f32(x, x_bstride, L.wf, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
+                rc = la_modconv3x3_fwd_f32(x, x_bstride, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                            L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f, sq2,
                                            h->clamp, L.y, h->splitk, h->splitk_floats, B, L.cin, L.cout, res, stream);
             else
-                rc = la_modconv3x3_up2_fwd_f32(x, x_bstride, L.wf, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
+                rc = la_modconv3x3_up2_fwd_f32(x, x_bstride, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                                L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f,
                                                sq2, h->clamp, h->fir, h->zT, L.y, h->splitk, h->splitk_floats, B, L.cin, L.cout, res, stream);
             if (rc) return rc;
@@ -322,7 +336,7 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
             const float* xin = (k == 0) ? h->cst : h->conv[ci - 1].y;
             const long xin_bs = (k == 0) ? 0 : (long)L1.cin * HW;
             const int tiles = la_modconv_ds_tiles(res);
-            if ((rc = la_modconv3x3_bwd_f32(h->G0, L1.wb, h->s_all + L1.s_off, h->S, xin, xin_bs, h->G1, h->ds_part, h->splitk, h->splitk_floats, B, L1.cin,
+            if ((rc = la_modconv3x3_bwd_f32(h->G0, L1.wb, L1.wqb, h->precision, h->s_all + L1.s_off, h->S, xin, xin_bs, h->G1, h->ds_part, h->splitk, h->splitk_floats, B, L1.cin,
                                             L1.cout, res, stream)))
                 return rc;
             if ((rc = la_style_backward_conv(h->ds_part, tiles, h->ddn_part, slabs, h->d_all + L1.d_off, h->Dt,
@@ -344,7 +358,7 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
         {
             const int hin = res / 2;
             const int tiles = la_modconv_ds_tiles(hin);
-            if ((rc = la_modconv3x3_up2_bwd_f32(h->G1, L0.wb, h->s_all + L0.s_off, h->S, h->conv[ci - 1].y,
+            if ((rc = la_modconv3x3_up2_bwd_f32(h->G1, L0.wb, L0.wqb, h->precision, h->s_all + L0.s_off, h->S, h->conv[ci - 1].y,
                                                 (long)L0.cin * hin * hin, h->fir, h->zT, h->G0, h->ds_part, h->splitk, h->splitk_floats, B, L0.cin, L0.cout,
                                                 res, stream)))
                 return rc;

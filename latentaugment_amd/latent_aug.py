@@ -95,6 +95,7 @@ class LatentAug:
         self.verbose_log = opt.verbose_log
         self.criterion_mode = getattr(opt, 'criterion_mode', 'gemm')
         self.final_noise_mode = getattr(opt, 'final_noise_mode', 'random')
+        self.precision = getattr(opt, 'precision', 'f32')
         if self.w_disc > 0 or self.w_lpips > 0:
             raise NotImplementedError(
                 'w_disc / w_lpips > 0: the discriminator and LPIPS criteria are the next rows of the scope table '
@@ -104,7 +105,7 @@ class LatentAug:
                 'loading G/D from a network pickle (util_latent_aug.py:466-484) is the next scope row; pass '
                 '`generator=` (a module or state_dict with the reference parameter names)')
         max_local = self.batch_size
-        self.engine = SynthesisEngine.from_generator(generator, self.device, max_local)
+        self.engine = SynthesisEngine.from_generator(generator, self.device, max_local, precision=self.precision)
         assert self.engine.img_resolution == self.res, 'opt.img_resolution does not match the generator'
         assert self.engine.img_channels == len(self.modalities), 'one image channel per modality expected'
         self.num_ws, self.w_dim = self.engine.num_ws, self.engine.w_dim

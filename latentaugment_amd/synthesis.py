@@ -16,6 +16,7 @@ from . import _lib
 _CONV_KEYS = ('affine.weight', 'affine.bias', 'weight', 'bias', 'noise_const')
 _RGB_KEYS = ('affine.weight', 'affine.bias', 'weight', 'bias')
 NOISE_MODES = {'none': 0, 'const': 1, 'random': 2}
+PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16x2': 2}
 
 
 def _state_dict_of(G):
@@ -26,7 +27,7 @@ def _state_dict_of(G):
 
 
 class SynthesisEngine:
-    def __init__(self, state_dict, device, max_batch, conv_clamp=256.0):
+    def __init__(self, state_dict, device, max_batch, conv_clamp=256.0, precision='f32'):
         lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != 'cuda':
@@ -92,15 +93,22 @@ class SynthesisEngine:
                        'la_synth_create')
         self._h = h
         self._lib = lib
+        self.set_precision(precision)
+
+    def set_precision(self, precision):
+        """'f32' exact fp32 MFMA | 'bf16x3' split-bf16, 6 MFMAs (fp32-class error) | 'bf16x2' split-bf16, 3 MFMAs."""
+        _lib.check(self._lib.la_synth_set_precision(self._h, PRECISIONS[precision]), 'la_synth_set_precision')
+        self.precision = precision
 
     @classmethod
-    def from_generator(cls, G, device, max_batch, conv_clamp=None):
+    def from_generator(cls, G, device, max_batch, conv_clamp=None, precision='f32'):
         if conv_clamp is None and not isinstance(G, dict):
             try:
                 conv_clamp = getattr(G.synthesis, f'b{G.img_resolution}').conv1.conv_clamp
             except AttributeError:
                 conv_clamp = 256.0
-        return cls(_state_dict_of(G), device, max_batch, conv_clamp=256.0 if conv_clamp is None else conv_clamp)
+        return cls(_state_dict_of(G), device, max_batch, conv_clamp=256.0 if conv_clamp is None else conv_clamp,
+                   precision=precision)
 
     def __del__(self):
         h = getattr(self, '_h', None)
