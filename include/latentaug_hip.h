@@ -77,7 +77,7 @@ int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, float* wsq, i
  * d [B][d_stride] demodulation coefficients (NULL = no demod), noise [res][res] (noise_bstride 0) or per sample. */
 int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride, const float* d,
                           int d_stride, const float* noise, long noise_bstride, float noise_strength, const float* bias,
-                          int act, float alpha, float gain, float clamp, float* y, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res,
+                          int act, float alpha, float gain, float clamp, float* y, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
                           la_stream_t stream);
 
 /* up-sampling layer (conv0): x [B][cin][res/2][res/2] -> y [B][cout][res][res];
@@ -85,20 +85,21 @@ int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const
 int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
                               const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                               const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
-                              float* scratch, float* y, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res, la_stream_t stream);
+                              float* scratch, float* y, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, la_stream_t stream);
 
 /* backward-data + style-gradient partials.  gz [B][cout][res][res] = gradient w.r.t. the raw contraction (already
  * multiplied by d and by act').  gx = (W^T * gz) . s ;  ds_part[b][i][tile] = partial sums of sum_p (W^T*gz) . xin. */
 int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
-                          long xin_bstride, float* gx, float* ds_part, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res,
+                          long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
                           la_stream_t stream);
 int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
-                              long xin_bstride, const float* fir_host, float* scratch, float* gx, float* ds_part, float* splitk_ws, long splitk_floats, int B,
+                              long xin_bstride, const float* fir_host, float* scratch, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B,
                               int cin, int cout, int res, la_stream_t stream);
 int la_modconv_ds_tiles(int grid_res); /* leading dimension of ds_part for a backward over a grid_res^2 grid */
-/* splitk_ws (may be NULL): scratch of la_modconv_splitk_floats() floats; with it, layers of <= 32x32 split their K loop
- * over workgroups (deterministic slice sum) instead of serialising it on a few CUs. */
-long la_modconv_splitk_floats(int B, int cin, int cout, int res, int up);
+/* ws (may be NULL for precision 0): scratch of la_modconv_workspace_bytes() bytes.  With it, layers of <= 34x34 split
+ * their K loop over workgroups (deterministic slice sum) instead of serialising it on a few CUs; the split-bf16
+ * precisions also park the pre-split copy of the launch input there. */
+size_t la_modconv_workspace_bytes(int B, int cin, int cout, int res, int up);
 /* Contraction precision (the `precision` argument of the la_modconv3x3_* calls; `wq` = weights packed for it or NULL):
  *   0 LA_PREC_F32     exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
  *   1 LA_PREC_BF16X3  fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate (fp32-class error)

@@ -40,13 +40,13 @@ SIGNATURES = {
     'la_upfirdn2d_out_size': (_I, [_I] * 6),
     'la_upfirdn2d_f32': (_I, [_P, _P, _P] + [_I] * 15 + [_F, _P]),
     'la_pack_conv_weights_f32': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
-    'la_modconv3x3_fwd_f32': (_I, [_P, _L, _P, _P, _I, _P, _I, _P, _I, _P, _L, _F, _P, _I, _F, _F, _F, _P, _P, _L, _I, _I, _I, _I, _P]),
-    'la_modconv3x3_up2_fwd_f32': (_I, [_P, _L, _P, _P, _I, _P, _I, _P, _I, _P, _L, _F, _P, _I, _F, _F, _F, _P, _P, _P, _P, _L, _I,
+    'la_modconv3x3_fwd_f32': (_I, [_P, _L, _P, _P, _I, _P, _I, _P, _I, _P, _L, _F, _P, _I, _F, _F, _F, _P, _P, _Z, _I, _I, _I, _I, _P]),
+    'la_modconv3x3_up2_fwd_f32': (_I, [_P, _L, _P, _P, _I, _P, _I, _P, _I, _P, _L, _F, _P, _I, _F, _F, _F, _P, _P, _P, _P, _Z, _I,
                                        _I, _I, _I, _P]),
-    'la_modconv3x3_bwd_f32': (_I, [_P, _P, _P, _I, _P, _I, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
-    'la_modconv3x3_up2_bwd_f32': (_I, [_P, _P, _P, _I, _P, _I, _P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    'la_modconv3x3_bwd_f32': (_I, [_P, _P, _P, _I, _P, _I, _P, _L, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
+    'la_modconv3x3_up2_bwd_f32': (_I, [_P, _P, _P, _I, _P, _I, _P, _L, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     'la_modconv_ds_tiles': (_I, [_I]),
-    'la_modconv_splitk_floats': (_L, [_I, _I, _I, _I, _I]),
+    'la_modconv_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
     'la_modconv_bf16_pack_bytes': (_Z, [_I, _I, _I, _I]),
     'la_pack_conv_weights_bf16_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     'la_pairwise_l2_f32': (_I, [_P, _I, _P, _L, _L, _P, _P, _P, _P]),

@@ -49,10 +49,13 @@ struct LaConvArgs {
     long xin_bstride;
     float* ds_part;          // [B][M][tiles_per_sample]
     int tiles_per_sample;
-    // split-K (optional): caller-provided scratch for the K-slice partial sums; ksplit is chosen by la_conv_launch
+    // optional caller-provided scratch (la_conv_workspace_bytes): [pre-split bf16 input | split-K slice partials]
+    void* ws;
+    size_t ws_bytes;
+    // filled in by la_conv_launch
     float* splitk_ws;
-    long splitk_floats;
     int ksplit;
+    const void* in_q;              // split-bf16 path: input already split by la_conv_presplit (8 B / element), or NULL
     // split-bf16 path (precision != LA_PREC_F32): weights pre-split by la_pack_conv_weights_bf16
     int precision;
     const void* wgt_bf16;          // [term][slab][ceil(C/32)][M][32] bf16
@@ -66,6 +69,11 @@ void la_conv_bf16_dispatch(const LaConvArgs& as, int MTsel, dim3 grid, bool spli
 
 // scratch floats that let every <= 32x32 launch of a (B, M) problem use split-K: slices * B * M * G, G <= 1024
 long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx, int precision);
+// bytes of the pre-split copy of an input [B][C][Hin][Win] (split-bf16 path)
+size_t la_conv_presplit_bytes(int B, int C, int Hin, int Win);
+// x (fp32, optionally * scale[b][c]) -> {bf16 hi | bf16 mid << 16, bf16 lo} per element
+int la_conv_presplit(const float* in, long in_bstride, const float* scale, int scale_stride, void* out, int B, int C,
+                     long HW, hipStream_t stream);
 
 // number of pixel tiles per sample for a launch (the ds_part leading dimension)
 int la_conv_tiles_per_sample(int Gy, int Gx);

@@ -9,11 +9,15 @@
 // bf16 x bf16 products are exact in fp32, and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the only approximation is
 // the dropped low-order cross terms.  The leading product and the correction products use separate accumulators that are
 // added once in the epilogue (small terms are not swamped inside the K loop).
+// (Current version: one accumulator, correction products issued before the leading one within each K step; measured
+//  error stays at the fp32-MFMA level, see tests.)
 //
 // Tiling: as la_conv.hip (256 threads = 2x2 waves, tile MT x 128 pixels, wave 64x64 = 2x2 MFMA tiles), K chunk =
 // (one tap, 32 input channels) = two K=16 MFMA steps.  Weights are pre-split at pack time into
-// wgt_bf16[term][slab][ceil(C/32)][M][32] (k contiguous = the A fragment order); activations are gathered as fp32,
-// modulated, split in registers and written k-contiguous to LDS ([pixel][32] bf16, 80-byte row stride: conflict-free for
+// wgt_bf16[term][slab][ceil(C/32)][M][32] (k contiguous = the A fragment order).  Activations are modulated and split ONCE
+// per launch input by la_conv_presplit (8 bytes per element: {hi | mid<<16, lo}) -- the contraction re-reads every
+// element 9 taps x (M/MT) times, so splitting inside the gather would repeat the VALU work 9-36x.  The gather packs the
+// terms k-contiguous with v_perm_b32 and writes them to LDS ([pixel][32] bf16, 80-byte row stride: conflict-free for
 // ds_read_b128 fragments and ds_write_b128 staging).
 #include "la_conv_device.h"
 
@@ -63,6 +67,51 @@ int la_pack_conv_weights_bf16(const float* w, void* out, int cout, int cin, int 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// pre-split: q[b][c][p] = split3(x[b][c][p] * scale[b][c])  ->  uint2 {hi | mid << 16, lo}
+__global__ __launch_bounds__(256) void la_presplit_kernel(const float* __restrict__ in, long in_bstride,
+                                                         const float* __restrict__ scale, int scale_stride,
+                                                         uint2* __restrict__ out, int C, long HW) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float sc = scale ? scale[(long)b * scale_stride + c] : 1.f;
+    const float* ip = in + (long)b * in_bstride + (long)c * HW;
+    uint2* op = out + ((long)b * C + c) * HW;
+    const bool aligned16 = ((((long)b * C + c) * HW) & 1) == 0;    // odd planes (e.g. 257^2) start on an 8-byte boundary
+    for (long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2; p < HW; p += (long)gridDim.x * blockDim.x * 2) {
+        float v0 = ip[p] * sc, v1 = (p + 1 < HW) ? ip[p + 1] * sc : 0.f;
+        unsigned short t0[3], t1[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+            t0[q] = __builtin_bit_cast(unsigned short, h0);
+            t1[q] = __builtin_bit_cast(unsigned short, h1);
+            v0 -= (float)h0; v1 -= (float)h1;
+        }
+        const uint2 e0 = make_uint2((unsigned)t0[0] | ((unsigned)t0[1] << 16), (unsigned)t0[2]);
+        const uint2 e1 = make_uint2((unsigned)t1[0] | ((unsigned)t1[1] << 16), (unsigned)t1[2]);
+        if (p + 1 < HW) {
+            if (aligned16) *reinterpret_cast<uint4*>(op + p) = make_uint4(e0.x, e0.y, e1.x, e1.y);
+            else { op[p] = e0; op[p + 1] = e1; }
+        } else {
+            op[p] = e0;
+        }
+    }
+}
+
+size_t la_conv_presplit_bytes(int B, int C, int Hin, int Win) { return (size_t)B * C * Hin * Win * 8 + 16; }
+
+int la_conv_presplit(const float* in, long in_bstride, const float* scale, int scale_stride, void* out, int B, int C,
+                     long HW, hipStream_t stream) {
+    LA_CHECK_ARG(in && out && B >= 1 && C >= 1 && HW >= 1, "presplit: bad arguments");
+    LA_CHECK_ARG(((size_t)out & 15) == 0, "presplit: output must be 16-byte aligned");
+    int gx = la_cdiv(HW, 512);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(la_presplit_kernel, dim3(gx, C, B), dim3(256), 0, stream, in, in_bstride, scale, scale_stride,
+                       (uint2*)out, C, HW);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 template <int MT, bool SPLIT, int NTERM>
 __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
     constexpr int TM = MT / 64;
@@ -91,8 +140,6 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
     const int gx_l = nvalid ? g_l - gy_l * a.Gx : 0;
     const int iy0 = gy_l * a.in_sy, ix0 = gx_l * a.in_sx;
     const long HWin = (long)a.Hin * a.Win;
-    const float* in_b = a.in + (long)b_l * a.in_bstride;
-    const float* sc_b = a.in_scale ? a.in_scale + (long)b_l * a.scale_stride : nullptr;
 
     const int nck = (a.C + KCB - 1) / KCB;
     int ck_beg = 0, ck_end = nck;
@@ -105,7 +152,8 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
     const long term_elems = a.wgt_bf16_term_elems;    // elements per term in the packed weights
     const __bf16* wbase = reinterpret_cast<const __bf16*>(a.wgt_bf16);
 
-    float breg[16];
+    const uint2* inq_b = reinterpret_cast<const uint2*>(a.in_q) + (long)b_l * a.C * HWin;
+    uint2 breg[16];
     uint4 areg[NTERM][A_U];
 
     auto prefetch = [&](int ci) {
@@ -118,11 +166,8 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int c = c0 + j;
-            float v = 0.f;
-            if (ok && c < a.C) {
-                v = in_b[(long)c * HWin + off];
-                if (sc_b) v *= sc_b[c];
-            }
+            uint2 v = make_uint2(0u, 0u);
+            if (ok && c < a.C) v = inq_b[(long)c * HWin + off];
             breg[j] = v;
         }
         // A: contiguous [M][32] bf16 slab of (tap slab, channel chunk); rows m0 .. m0+MT
@@ -139,23 +184,19 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
             }
     };
     auto stage = [&]() {
-        // split the 16 fp32 activations into NTERM bf16 terms, k-contiguous
-        bf16x8 lo8[NTERM], hi8[NTERM];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float v = breg[j];
-#pragma unroll
-            for (int q = 0; q < NTERM; ++q) {
-                const __bf16 h = (__bf16)v;
-                if (j < 8) lo8[q][j] = h; else hi8[q][j - 8] = h;
-                v -= (float)h;
-            }
-        }
+        // pack term q of 16 consecutive channels k-contiguous: dword d = term(2d) | term(2d+1) << 16   (v_perm_b32)
 #pragma unroll
         for (int q = 0; q < NTERM; ++q) {
+            unsigned w[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const unsigned e0 = q == 2 ? breg[2 * d].y : breg[2 * d].x;
+                const unsigned e1 = q == 2 ? breg[2 * d + 1].y : breg[2 * d + 1].x;
+                w[d] = __builtin_amdgcn_perm(e1, e0, q == 1 ? 0x07060302u : 0x05040100u);
+            }
             unsigned char* p = Bs + ((long)q * NT + n_l) * ROWB + khalf * 32;
-            *reinterpret_cast<bf16x8*>(p) = lo8[q];
-            *reinterpret_cast<bf16x8*>(p + 16) = hi8[q];
+            *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<uint4*>(p + 16) = make_uint4(w[4], w[5], w[6], w[7]);
 #pragma unroll
             for (int u = 0; u < A_U; ++u) {
                 const int unit = tid + 256 * u;
@@ -164,13 +205,13 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
         }
     };
 
-    f32x16 acc[TM][2], cor[TM][2];
+    f32x16 acc[TM][2];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; cor[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
     if (ci_beg < ci_end) prefetch(ci_beg);
@@ -195,21 +236,18 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);   // hh
-                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], cor[i][j], 0, 0, 0);   // hm
-                    cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], cor[i][j], 0, 0, 0);   // mh
+                    // smallest products first, so they are not swamped by the leading term inside the accumulator
                     if (NTERM == 3) {
-                        cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], cor[i][j], 0, 0, 0);   // mm
-                        cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], cor[i][j], 0, 0, 0);   // hl
-                        cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], cor[i][j], 0, 0, 0);   // lh
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);   // lh
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);   // hl
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);   // mm
                     }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);   // mh
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);   // hm
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);   // hh
                 }
         }
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] += cor[i][j];
     __syncthreads();     // LDS is reused by the epilogue's reduction scratch
     la_conv_epilogue<MT, SPLIT>(a, acc, red, ntile, m0, G, Ntot);
 }

@@ -8,19 +8,19 @@ extern "C" {
 int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps, hipStream_t);
 int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride, const float* d,
                           int d_stride, const float* noise, long noise_bstride, float noise_strength, const float* bias,
-                          int act, float alpha, float gain, float clamp, float* y, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res,
+                          int act, float alpha, float gain, float clamp, float* y, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
                           hipStream_t stream);
 int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
                               const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                               const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
-                              float* scratch, float* y, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res, hipStream_t stream);
+                              float* scratch, float* y, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, hipStream_t stream);
 int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
-                          long xin_bstride, float* gx, float* ds_part, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res, hipStream_t);
+                          long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, hipStream_t);
 int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
-                              long xin_bstride, const float* fir_host, float* scratch, float* gx, float* ds_part, float* splitk_ws, long splitk_floats, int B,
+                              long xin_bstride, const float* fir_host, float* scratch, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B,
                               int cin, int cout, int res, hipStream_t stream);
 int la_modconv_ds_tiles(int grid_res);
-long la_modconv_splitk_floats(int B, int cin, int cout, int res, int up);
+size_t la_modconv_workspace_bytes(int B, int cin, int cout, int res, int up);
 size_t la_modconv_bf16_pack_bytes(int cin, int cout, int transpose, int nterm);
 int la_pack_conv_weights_bf16_f32(const float* w, void* out, int cout, int cin, int ktaps, int transpose, int nterm,
                                   hipStream_t stream);

@@ -24,12 +24,12 @@ extern "C" int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, fl
 extern "C" int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
                                      const float* d, int d_stride, const float* noise, long noise_bstride,
                                      float noise_strength, const float* bias, int act, float alpha, float gain,
-                                     float clamp, float* y, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res, hipStream_t stream) {
+                                     float clamp, float* y, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, hipStream_t stream) {
     LA_CHECK_ARG(x && wf && y, "modconv_fwd: null pointer");
     LaConvArgs a; base_args(a);
     a.in = x; a.in_bstride = x_bstride; a.wgt = wf; a.out = y;
     a.in_scale = s; a.scale_stride = s_stride;
-    a.splitk_ws = splitk_ws; a.splitk_floats = splitk_floats;
+    a.ws = ws; a.ws_bytes = ws_bytes;
     a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cout, cin, 9);
     a.B = B; a.C = cin; a.M = cout; a.Hin = a.Win = a.Hout = a.Wout = a.Gy = a.Gx = res;
     a.ntaps = 9;
@@ -44,7 +44,7 @@ extern "C" int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float
 extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
                                          const float* d, int d_stride, const float* noise, long noise_bstride,
                                          float noise_strength, const float* bias, int act, float alpha, float gain,
-                                         float clamp, const float* fir_host, float* scratch, float* y, float* splitk_ws, long splitk_floats, int B, int cin,
+                                         float clamp, const float* fir_host, float* scratch, float* y, void* ws, size_t ws_bytes, int B, int cin,
                                          int cout, int res, hipStream_t stream) {
     LA_CHECK_ARG(x && wf && y && scratch && fir_host, "modconv_up2_fwd: null pointer");
     LA_CHECK_ARG(res >= 2 && res % 2 == 0, "modconv_up2_fwd: output resolution must be even");
@@ -53,10 +53,21 @@ extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const f
     LaConvArgs a; base_args(a);
     a.in = x; a.in_bstride = x_bstride; a.wgt = wf; a.out = scratch;
     a.in_scale = s; a.scale_stride = s_stride;
-    a.splitk_ws = splitk_ws; a.splitk_floats = splitk_floats;
+    a.ws = ws; a.ws_bytes = ws_bytes;
     a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cout, cin, 9);
     a.B = B; a.C = cin; a.M = cout; a.Hin = a.Win = hin; a.Hout = a.Wout = res + 1;
     a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW;
+    if (precision != LA_PREC_F32) {
+        // split the (modulated) input once for the four phase launches
+        const size_t qb = la_conv_presplit_bytes(B, cin, hin, hin);
+        LA_CHECK_ARG(ws && ws_bytes >= qb, "modconv_up2_fwd: split-bf16 precision needs a workspace");
+        int rc = la_conv_presplit(x, x_bstride, s, s_stride, ws, B, cin, (long)hin * hin, stream);
+        if (rc) return rc;
+        const size_t off = (qb + 255) & ~(size_t)255;
+        a.in_q = ws;
+        a.ws = ws_bytes > off ? static_cast<char*>(ws) + off : nullptr;
+        a.ws_bytes = ws_bytes > off ? ws_bytes - off : 0;
+    }
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             a.out_oy = py; a.out_ox = px;
@@ -76,12 +87,12 @@ extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const f
 }
 
 extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
-                                     long xin_bstride, float* gx, float* ds_part, float* splitk_ws, long splitk_floats, int B, int cin, int cout, int res,
+                                     long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
                                      hipStream_t stream) {
     LA_CHECK_ARG(gz && wb && gx, "modconv_bwd: null pointer");
     LaConvArgs a; base_args(a);
     a.in = gz; a.in_bstride = (long)cout * res * res; a.wgt = wb; a.out = gx;
-    a.splitk_ws = splitk_ws; a.splitk_floats = splitk_floats;
+    a.ws = ws; a.ws_bytes = ws_bytes;
     a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cin, cout, 9);
     a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = a.Hout = a.Wout = a.Gy = a.Gx = res;
     a.ntaps = 9;
@@ -95,7 +106,7 @@ extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const voi
 
 extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
                                          long xin_bstride, const float* fir_host, float* scratch, float* gx,
-                                         float* ds_part, float* splitk_ws, long splitk_floats, int B, int cin, int cout,
+                                         float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
                                          int res, hipStream_t stream) {
     LA_CHECK_ARG(gz && wb && gx && scratch && fir_host, "modconv_up2_bwd: null pointer");
     const int hin = res / 2;
@@ -104,7 +115,7 @@ extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const
     if (rc) return rc;
     LaConvArgs a; base_args(a);
     a.in = scratch; a.in_bstride = (long)cout * (res + 1) * (res + 1); a.wgt = wb; a.out = gx;
-    a.splitk_ws = splitk_ws; a.splitk_floats = splitk_floats;
+    a.ws = ws; a.ws_bytes = ws_bytes;
     a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cin, cout, 9);
     a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = res + 1; a.Hout = a.Wout = a.Gy = a.Gx = hin;
     a.in_sy = a.in_sx = 2; a.ntaps = 9;
@@ -118,21 +129,26 @@ extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const
 
 extern "C" int la_modconv_ds_tiles(int grid_res) { return la_conv_tiles_per_sample(grid_res, grid_res); }
 
-// scratch floats that enable split-K for a layer (0: the layer never uses it).  Covers forward and backward launches.
-extern "C" long la_modconv_splitk_floats(int B, int cin, int cout, int res, int up) {
-    long need = 0;
-    for (int prec = 0; prec <= 2; ++prec) {      // enough for every contraction precision
+// scratch bytes for a layer's forward and backward launches at any contraction precision:
+// pre-split bf16 copy of the launch input (split-bf16 only) + split-K slice partials (<= 34x34 grids).
+extern "C" size_t la_modconv_workspace_bytes(int B, int cin, int cout, int res, int up) {
+    size_t need = 0;
+    const int hin = up ? res / 2 : res;
+    for (int prec = 0; prec <= 2; ++prec) {
         long f, b;
+        size_t qf = 0, qb = 0;
         if (up) {
-            const int hin = res / 2;
             f = la_conv_splitk_floats(B, cout, cin, hin + 1, hin + 1, prec);   // largest forward phase grid
             b = la_conv_splitk_floats(B, cin, cout, hin, hin, prec);
+            if (prec) { qf = la_conv_presplit_bytes(B, cin, hin, hin); qb = la_conv_presplit_bytes(B, cout, res + 1, res + 1); }
         } else {
             f = la_conv_splitk_floats(B, cout, cin, res, res, prec);
             b = la_conv_splitk_floats(B, cin, cout, res, res, prec);
+            if (prec) { qf = la_conv_presplit_bytes(B, cin, res, res); qb = la_conv_presplit_bytes(B, cout, res, res); }
         }
-        if (f > need) need = f;
-        if (b > need) need = b;
+        const size_t nf = ((qf + 255) & ~(size_t)255) + (size_t)f * 4, nb = ((qb + 255) & ~(size_t)255) + (size_t)b * 4;
+        if (nf > need) need = nf;
+        if (nb > need) need = nb;
     }
     return need;
 }

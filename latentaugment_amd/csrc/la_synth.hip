@@ -47,8 +47,9 @@ struct la_synth {
     LaDemodTable dt;
     int S, Dt;
     float *s_all, *d_all, *ds_all;
-    float *zT, *G0, *G1, *ds_part, *ddn_part, *dweff_part, *splitk, *aff_part;
-    long splitk_floats;
+    float *zT, *G0, *G1, *ds_part, *ddn_part, *dweff_part, *aff_part;
+    void* cws;
+    size_t cws_bytes;
     int lastB;
     int precision;
     float* final_img;   // where the last forward put the full-resolution image
@@ -70,7 +71,7 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
     Carver c{(char*)workspace, 0, cap};
     const size_t mb = h->maxB;
     size_t gmax = 0, ztmax = 0, dsp = 0, ddn = 0, dwe = 0;
-    long skf = 0;
+    size_t skf = 0;
     for (int k = 0; k < h->nconv; ++k) {
         ConvLayer& L = h->conv[k];
         const size_t wn = (size_t)L.cin * L.cout;
@@ -90,7 +91,7 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
         if (t > dsp) dsp = t;
         const size_t sl = mb * L.cout * (size_t)la_seam_slabs((long)hw);
         if (sl > ddn) ddn = sl;
-        const long sk = la_modconv_splitk_floats((int)mb, L.cin, L.cout, L.res, L.up);
+        const size_t sk = la_modconv_workspace_bytes((int)mb, L.cin, L.cout, L.res, L.up);
         if (sk > skf) skf = sk;
     }
     for (int k = 0; k < h->nblocks; ++k) {
@@ -112,8 +113,8 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
     h->ddn_part = c.take(ddn);
     h->dweff_part = c.take(dwe);
     h->aff_part = c.take((size_t)la_affine_bwd_chunks(h->st) * mb * h->wdim);
-    h->splitk = c.take((size_t)skf);
-    h->splitk_floats = skf;
+    h->cws = c.take((skf + 3) / 4);
+    h->cws_bytes = skf;
     *need = c.off;
     return LA_OK;
 }
@@ -278,11 +279,11 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
             if (!L.up)
                 rc = la_modconv3x3_fwd_f32(x, x_bstride, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                            L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f, sq2,
-                                           h->clamp, L.y, h->splitk, h->splitk_floats, B, L.cin, L.cout, res, stream);
+                                           h->clamp, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream);
             else
                 rc = la_modconv3x3_up2_fwd_f32(x, x_bstride, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                                L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f,
-                                               sq2, h->clamp, h->fir, h->zT, L.y, h->splitk, h->splitk_floats, B, L.cin, L.cout, res, stream);
+                                               sq2, h->clamp, h->fir, h->zT, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream);
             if (rc) return rc;
             x = L.y; x_bstride = (long)L.cout * res * res;
         }
@@ -336,7 +337,7 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
             const float* xin = (k == 0) ? h->cst : h->conv[ci - 1].y;
             const long xin_bs = (k == 0) ? 0 : (long)L1.cin * HW;
             const int tiles = la_modconv_ds_tiles(res);
-            if ((rc = la_modconv3x3_bwd_f32(h->G0, L1.wb, L1.wqb, h->precision, h->s_all + L1.s_off, h->S, xin, xin_bs, h->G1, h->ds_part, h->splitk, h->splitk_floats, B, L1.cin,
+            if ((rc = la_modconv3x3_bwd_f32(h->G0, L1.wb, L1.wqb, h->precision, h->s_all + L1.s_off, h->S, xin, xin_bs, h->G1, h->ds_part, h->cws, h->cws_bytes, B, L1.cin,
                                             L1.cout, res, stream)))
                 return rc;
             if ((rc = la_style_backward_conv(h->ds_part, tiles, h->ddn_part, slabs, h->d_all + L1.d_off, h->Dt,
@@ -359,7 +360,7 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
             const int hin = res / 2;
             const int tiles = la_modconv_ds_tiles(hin);
             if ((rc = la_modconv3x3_up2_bwd_f32(h->G1, L0.wb, L0.wqb, h->precision, h->s_all + L0.s_off, h->S, h->conv[ci - 1].y,
-                                                (long)L0.cin * hin * hin, h->fir, h->zT, h->G0, h->ds_part, h->splitk, h->splitk_floats, B, L0.cin, L0.cout,
+                                                (long)L0.cin * hin * hin, h->fir, h->zT, h->G0, h->ds_part, h->cws, h->cws_bytes, B, L0.cin, L0.cout,
                                                 res, stream)))
                 return rc;
             if ((rc = la_style_backward_conv(h->ds_part, tiles, h->ddn_part, slabs, h->d_all + L0.d_off, h->Dt,
