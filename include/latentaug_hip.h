@@ -168,6 +168,18 @@ const float* la_synth_style_grads(const la_synth* h);
 int la_synth_style_rows(const la_synth* h);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Mapping network (rand_aug mode): replaces G.mapping(z, c=None, truncation_psi=...) at util_latent_aug.py:203,460.
+ * weights[i] = mapping.fc{i}.weight [w_dim][in], biases[i] = mapping.fc{i}.bias (legacy.py:175-176), lr_mul 0.01
+ * (legacy.py:141), w_avg = mapping.w_avg (legacy.py:172).  tmp: 2*B*max(z_dim,w_dim) floats.
+ * la_fc_f32: FullyConnectedLayer forward y = act(x @ (W*lr_mul/sqrt(in))^T + b*lr_mul) * gain.
+ * ------------------------------------------------------------------------------------------------------------- */
+int la_fc_f32(const float* x, const float* W, const float* bias, float* y, int B, int in, int out, float lr_mul, int act,
+              float alpha, float gain, la_stream_t stream);
+int la_mapping_forward_f32(const float* z, int B, int z_dim, int w_dim, int num_layers, const float* const* weights,
+                           const float* const* biases, float lr_mul, const float* w_avg, float truncation_psi,
+                           int num_ws, float* tmp, float* ws_out, la_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * The loop: replaces LatentAug.forward(w, fname) (augments/utils/util_latent_aug.py:207-310) for 3-D w input.
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct la_opt_config {

@@ -71,6 +71,8 @@ SIGNATURES = {
     'la_latent_opt_create': (_I, [_P, _I, _I, _I, _P, _P, _L, _P, _L, _I, _P, _Z, _P]),
     'la_latent_opt_destroy': (None, [_P]),
     'la_latent_opt_run': (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
+    'la_fc_f32': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _F, _P]),
+    'la_mapping_forward_f32': (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _F, _I, _P, _P, _P]),
     'la_prof_begin': (_I, []),
     'la_prof_end': (_I, [_P, _P, _P, _P]),
 }

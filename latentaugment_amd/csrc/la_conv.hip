@@ -42,7 +42,10 @@ __global__ __launch_bounds__(256) void la_conv_igemm_kernel(LaConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int ntile = blockIdx.x;
+    // XCD-aware tile order (direct mode): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
+    // run of pixel tiles -- vertically adjacent tiles (which share the +-1 row halos of the 3x3 taps) then hit the same L2.
+    int ntile = blockIdx.x;
+    if (!SPLIT && (gridDim.x & 7) == 0) ntile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int m0 = blockIdx.y * MT;
     const int G = a.Gy * a.Gx;
     const int Ntot = SPLIT ? a.B * G : G;

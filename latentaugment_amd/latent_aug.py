@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .synthesis import SynthesisEngine
+from .synthesis import MappingEngine, SynthesisEngine
 
 
 def center_crop_geometry(load_size):
@@ -110,6 +110,8 @@ class LatentAug:
         assert self.engine.img_channels == len(self.modalities), 'one image channel per modality expected'
         self.num_ws, self.w_dim = self.engine.num_ws, self.engine.w_dim
         self.z_dim = getattr(generator, 'z_dim', self.w_dim)
+        self._generator = generator
+        self._mapping = None
         self.stats_dataset_w = latent_codes
         self.stats_loss = {}
 
@@ -192,7 +194,7 @@ class LatentAug:
         With an initialised process group every rank passes the same full-batch `w`; rank k optimises samples
         [k*b, (k+1)*b) and a single all_gather returns the whole batch everywhere."""
         if w.ndim == 2:
-            raise NotImplementedError('z input (mapping network) is the rand_aug scope row; pass w [B,1,w_dim]')
+            w = self.z_to_w(w)                      # reference :209-210
         # crop position: drawn once per forward on the host as the reference does (:216); only the (future) LPIPS
         # criterion consumes it, but the draw is kept so the python RNG stream matches the reference's.
         self.crop_params = get_params(self.res, self.crop_size, self.preprocess)
@@ -223,8 +225,23 @@ class LatentAug:
 
     __call__ = forward
 
-    def forward_ganrand(self, z):
-        raise NotImplementedError('rand_aug / forward_ganrand needs the mapping network: next scope row (SURVEY 8f rank 4)')
+    @property
+    def mapping(self):
+        if self._mapping is None:
+            self._mapping = MappingEngine(self._generator, self.device)
+            self.z_dim = self._mapping.z_dim
+        return self._mapping
+
+    def z_to_w(self, z):
+        """reference :459-464: w = reverse_broadcasting(G.mapping(z, None, truncation_psi))."""
+        ws = self.mapping.forward(z.to(self.device), self.num_ws, self.truncation_psi)
+        return self.reverse_broadcasting(ws)
+
+    def forward_ganrand(self, z, noises=None):
+        """reference :202-205: w_aug = G.mapping(z, c=None, truncation_psi); img = G.synthesis(w_aug)  (rand_aug mode)."""
+        ws = self.mapping.forward(z.to(self.device), self.num_ws, self.truncation_psi)
+        img = self.engine.forward(ws, noise_mode=self.final_noise_mode, noises=noises)
+        return img, ws
 
 
 def define_latentaugment(module_name, phase, opt, save_dir, gpu_ids=[], **inject):

@@ -206,3 +206,43 @@ class _SynthesisFn(torch.autograd.Function):
 def synthesis(engine, ws, noise_mode='const', noises=None):
     """Differentiable (w.r.t. ws) call of the HIP synthesis engine, autograd-compatible."""
     return _SynthesisFn.apply(ws, engine, noise_mode, noises)
+
+
+class MappingEngine:
+    """G.mapping(z, c=None, truncation_psi=psi) on the HIP path (reference call sites util_latent_aug.py:203,460).
+
+    Built from the `mapping.*` entries of the generator state_dict (legacy.py:172-176)."""
+
+    def __init__(self, G, device, lr_multiplier=0.01):
+        self._lib = _lib.load()
+        self.device = torch.device(device)
+        sd = G if isinstance(G, dict) else G.state_dict()
+        sd = {k[len('mapping.'):]: v for k, v in sd.items() if k.startswith('mapping.')}
+        n = 0
+        while f'fc{n}.weight' in sd:
+            n += 1
+        if n == 0:
+            raise _lib.LatentAugHipError('generator has no mapping.fc* tensors: z input / rand_aug needs the mapping network')
+        self.num_layers = n
+        self.weights = [sd[f'fc{i}.weight'].detach().to(self.device, torch.float32).contiguous() for i in range(n)]
+        self.biases = [sd[f'fc{i}.bias'].detach().to(self.device, torch.float32).contiguous() for i in range(n)]
+        self.z_dim = int(self.weights[0].shape[1])
+        self.w_dim = int(self.weights[-1].shape[0])
+        self.w_avg = sd['w_avg'].detach().to(self.device, torch.float32).contiguous() if 'w_avg' in sd else None
+        self.lr_multiplier = float(lr_multiplier)
+        self._wp = (C.c_void_p * n)(*[t.data_ptr() for t in self.weights])
+        self._bp = (C.c_void_p * n)(*[t.data_ptr() for t in self.biases])
+
+    def forward(self, z, num_ws, truncation_psi=1.0):
+        _lib.require_gpu(z)
+        z = z.contiguous().float()
+        B = z.shape[0]
+        assert z.shape[1] == self.z_dim
+        tmp = torch.empty([2 * B * max(self.z_dim, self.w_dim)], device=self.device, dtype=torch.float32)
+        ws = torch.empty([B, num_ws, self.w_dim], device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.la_mapping_forward_f32(_lib.ptr(z), B, self.z_dim, self.w_dim, self.num_layers, self._wp,
+                                                        self._bp, self.lr_multiplier, _lib.ptr(self.w_avg),
+                                                        float(truncation_psi), num_ws, _lib.ptr(tmp), _lib.ptr(ws),
+                                                        _lib.stream_ptr()), 'la_mapping_forward')
+        return ws
