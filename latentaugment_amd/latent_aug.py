@@ -13,6 +13,7 @@ Differences from the reference, all deliberate:
 """
 import ctypes as C
 import math
+import os
 import random
 
 import numpy as np
@@ -101,9 +102,12 @@ class LatentAug:
                 'w_disc / w_lpips > 0: the discriminator and LPIPS criteria are the next rows of the scope table '
                 '(SURVEY.md 8f) and are not in this build yet')
         if generator is None:
-            raise NotImplementedError(
-                'loading G/D from a network pickle (util_latent_aug.py:466-484) is the next scope row; pass '
-                '`generator=` (a module or state_dict with the reference parameter names)')
+            # load_stylegan (reference :466-484): <model_dir>/<dataset>/training-runs/<dataset_name>/<modalities>/<exp>/<pkl>
+            from . import formats
+            path = formats.find_network_pkl(opt.model_dir, opt.dataset_aug, opt.dataset_name_aug, self.modalities,
+                                            opt.exp_stylegan, opt.network_pkl_stylegan)
+            print(f'Loading stylegan from "{path}"...')
+            generator = formats.load_network_pkl(path)['G_ema']
         max_local = self.batch_size
         self.engine = SynthesisEngine.from_generator(generator, self.device, max_local, precision=self.precision)
         assert self.engine.img_resolution == self.res, 'opt.img_resolution does not match the generator'
@@ -115,6 +119,22 @@ class LatentAug:
         self.stats_dataset_w = latent_codes
         self.stats_loss = {}
 
+        if banks is None and getattr(opt, 'interim_dir', None) and getattr(opt, 'dataset_aug', None):
+            # real-data banks from the interim zips (reference :137-158), cached as DatasetStats pickles
+            from . import formats
+            root = os.path.join(opt.interim_dir, opt.dataset_aug)
+            cache_dir = os.path.join(root, 'cache_dir')
+            banks = {}
+            wzip = os.path.join(root, str(getattr(opt, 'dataset_w_name', '')) + '.zip')
+            if self.stats_dataset_w is None and os.path.isfile(wzip):
+                self.stats_dataset_w = formats.LatentCodeDataset(os.path.join(root, opt.dataset_w_name + '.zip'),
+                                                                 split=self.phase, w_dim=self.w_dim, num_ws=self.num_ws)
+            if self.w_latent > 0:
+                banks['W'] = formats.compute_stats(self.stats_dataset_w, 'latent', cache_dir, step=opt.step_w).get_all_torch()
+            if self.w_pix > 0:
+                ds = formats.ImgDataset(os.path.join(root, opt.dataset_name_aug + '.zip'), split=self.phase,
+                                        modalities=self.modalities, resolution=self.res)
+                banks['X'] = formats.compute_stats(ds, 'img', cache_dir, step=opt.step_img).get_all_torch()
         banks = banks or {}
         lib = _lib.load()
         self._lib = lib
