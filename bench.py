@@ -40,6 +40,7 @@ def parse():
     p.add_argument('--criterion-mode', default='gemm', choices=['gemm', 'collapsed'])
     p.add_argument('--precision', default='f32', choices=['f32', 'bf16x3', 'bf16x2'],
                    help='contraction arithmetic: exact fp32 MFMA, or fp32 split into 3 / 2 bf16 terms on the bf16 MFMA')
+    p.add_argument('--w-disc', type=float, default=0.0, help='discriminator criterion weight (BASELINE.md second run: 0.01)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true', help='skip the HIP-event leg (used under rocprofv3)')
     return p.parse_args()
@@ -49,7 +50,7 @@ def make_opt(args, local_rank):
     return types.SimpleNamespace(
         aug='latent', gpu_ids=[local_rank], gpu_ids_aug=str(local_rank), checkpoints_dir='/tmp', name='bench', phase='train',
         img_resolution=args.res, batch_size=args.batch, modalities_aug='A,B', opt_num_epochs=args.latent_steps, opt_lr=0.01,
-        truncation_psi=1.0, w_pix=0.1, w_lpips=0.0, w_latent=0.001, w_disc=0.0, crop_size_aug=64,
+        truncation_psi=1.0, w_pix=0.1, w_lpips=0.0, w_latent=0.001, w_disc=args.w_disc, crop_size_aug=64,
         preprocess_aug='center_random_crop', soft_aug=False, alpha=1.0, verbose_log=False, rand_aug=False,
         lower_bound_clip=False, p_thres=0.0, init_w='inv', criterion_mode=args.criterion_mode, final_noise_mode='random',
         precision=args.precision)
@@ -119,6 +120,9 @@ def main():
     # each rank owns its own B images (weak scaling); the plugin itself is run un-sharded per rank, the gather of the
     # whole job's output is done below with the same single collective the sharded plugin path uses
     opt.inject = dict(generator=sd, banks={'W': W, 'X': X}, latent_codes=codes, group=None)
+    if args.w_disc > 0:
+        opt.inject['discriminator'] = synthetic.make_discriminator_state_dict(img_resolution=args.res, img_channels=2,
+                                                                              channel_base=args.channel_base)
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -182,7 +186,8 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'SG2 config-{"f" if args.channel_base == 32768 else "e"} {args.res}x{args.res} 2-ch, '
                                f'random-init G, batch={args.batch}/GPU, {args.latent_steps} latent steps, '
-                               f'w_latent=0.001 w_pix=0.1 (M_w=1024, M_x=256, criterion_mode={args.criterion_mode})',
+                               f'w_latent=0.001 w_pix=0.1 w_disc={args.w_disc:g} (M_w=1024, M_x=256, criterion_mode={args.criterion_mode}), '
+                               f'contraction={args.precision}',
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}'},
     }
     if roof is not None:

@@ -180,13 +180,38 @@ int la_mapping_forward_f32(const float* z, int B, int z_dim, int w_dim, int num_
                            int num_ws, float* tmp, float* ws_out, la_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Discriminator engine: replaces  D(x, c=None)  and its backward to x inside calc_loss_disc (util_latent_aug.py:363-371).
+ * Architecture 'resnet' + MinibatchStd epilogue (legacy.py:220-247).  params: device tensors in this order (names of
+ * legacy.py:271-288), resolution R first:
+ *   bR: fromrgb.weight, fromrgb.bias, conv0.weight, conv0.bias, conv1.weight, conv1.bias, skip.weight
+ *   b(R/2) .. b8: conv0.weight, conv0.bias, conv1.weight, conv1.bias, skip.weight
+ *   b4: conv.weight, conv.bias, fc.weight, fc.bias, out.weight, out.bias
+ * channels[k] = channels at resolution 4 << k (same table as the generator).  mbstd_group_size: 4 in every SG2 config;
+ * the batch of a forward must be divisible by min(group, batch) exactly as in the reference.
+ * la_disc_loss: loss_out[0] = softplus(-logits).mean() * w_disc and keeps d(loss)/d(logits) for la_disc_backward.
+ * la_disc_backward: g_img [B][C][R][R] (accumulate != 0: added to what g_img holds).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct la_disc la_disc;
+int la_disc_num_params(int img_resolution);
+size_t la_disc_workspace_bytes(int img_resolution, int img_channels, const int* channels, int max_batch);
+int la_disc_create(int img_resolution, int img_channels, const int* channels, float conv_clamp, const float* const* params,
+                   int nparams, const float* fir_host, int mbstd_group_size, int max_batch, void* workspace,
+                   size_t workspace_bytes, la_stream_t stream, la_disc** out);
+void la_disc_destroy(la_disc* h);
+int la_disc_set_precision(la_disc* h, int precision);
+int la_disc_forward(la_disc* h, const float* img, int B, la_stream_t stream);
+int la_disc_loss(la_disc* h, float w_disc, int norm_batch, float* loss_out, la_stream_t stream);
+int la_disc_backward(la_disc* h, const float* dlogits, float* g_img, int accumulate, la_stream_t stream);
+const float* la_disc_logits(const la_disc* h);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * The loop: replaces LatentAug.forward(w, fname) (augments/utils/util_latent_aug.py:207-310) for 3-D w input.
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct la_opt_config {
     int steps;              /* opt_num_epochs (latent_aug.py:81) */
     float lr;               /* opt_lr (latent_aug.py:82) */
     float beta1, beta2, eps;
-    float w_latent, w_pix, w_disc, w_lpips; /* latent_aug.py:88-91; w_disc / w_lpips must be 0 in this version */
+    float w_latent, w_pix, w_disc, w_lpips; /* latent_aug.py:88-91; w_lpips must be 0 in this version */
     int criterion_mode;     /* 0: scan the banks every step (reference formulation); 1: cached bank column sums */
     int soft_aug;           /* latent_aug.py:94 */
     float alpha;            /* latent_aug.py:95 */
@@ -204,6 +229,8 @@ int la_latent_opt_create(la_synth* g, int img_resolution, int img_channels, int 
                          const float* bankW, long Mw, const float* bankXc, long Mx, int max_batch, void* workspace,
                          size_t workspace_bytes, la_latent_opt** out);
 void la_latent_opt_destroy(la_latent_opt* h);
+/* attach the discriminator used when cfg.w_disc != 0 (must outlive the loop handle) */
+int la_latent_opt_set_disc(la_latent_opt* h, la_disc* d);
 /* w0 [B][w_dim] -> img_out [B][C][R][R], w_aug_out [B][num_ws][w_dim]; losses_out (may be NULL) [steps][4] =
  * weighted {latent, pix, disc, lpips} per step. */
 int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const float* const* final_noises, float* img_out,

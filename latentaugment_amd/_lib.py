@@ -73,6 +73,16 @@ SIGNATURES = {
     'la_latent_opt_run': (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
     'la_fc_f32': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _F, _P]),
     'la_mapping_forward_f32': (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _F, _I, _P, _P, _P]),
+    'la_disc_num_params': (_I, [_I]),
+    'la_disc_workspace_bytes': (_Z, [_I, _I, _P, _I]),
+    'la_disc_create': (_I, [_I, _I, _P, _F, _P, _I, _P, _I, _I, _P, _Z, _P, _P]),
+    'la_disc_destroy': (None, [_P]),
+    'la_disc_set_precision': (_I, [_P, _I]),
+    'la_disc_forward': (_I, [_P, _P, _I, _P]),
+    'la_disc_loss': (_I, [_P, _F, _I, _P, _P]),
+    'la_disc_backward': (_I, [_P, _P, _P, _I, _P]),
+    'la_disc_logits': (_P, [_P]),
+    'la_latent_opt_set_disc': (_I, [_P, _P]),
     'la_prof_begin': (_I, []),
     'la_prof_end': (_I, [_P, _P, _P, _P]),
 }

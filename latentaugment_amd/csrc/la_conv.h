@@ -42,6 +42,8 @@ struct LaConvArgs {
     const float* bias;
     int act;
     float alpha, gain, clamp;
+    const float* addend;     // optional [B][M][Hout][Wout]: out2 = y + addend (residual sum), y itself still goes to `out`
+    float* out2;
     // LA_EPI_BWD:  out = acc * out_scale[b][m];  ds_part[b][m][tile] = sum_pixels acc * xin[b][m][pixel]
     const float* out_scale;
     int oscale_stride;
@@ -64,7 +66,7 @@ struct LaConvArgs {
 
 long la_conv_bf16_pack_elems(int M, int C, int ktaps);   // elements per term
 int la_pack_conv_weights_bf16(const float* w, void* out, int cout, int cin, int ktaps, int transpose, int nterm,
-                              hipStream_t stream);
+                              hipStream_t stream, float scale = 1.f, int m_pad = 0);
 void la_conv_bf16_dispatch(const LaConvArgs& as, int MTsel, dim3 grid, bool split, hipStream_t stream);
 
 // scratch floats that let every <= 32x32 launch of a (B, M) problem use split-K: slices * B * M * G, G <= 1024

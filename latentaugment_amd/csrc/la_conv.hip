@@ -178,6 +178,10 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
         if (a.epi == LA_EPI_FWD) {
             const float nz = a.noise ? a.noise[(long)b * a.noise_bstride + pos] * a.noise_strength : 0.f;
             v = la_conv_epi_fwd(a, v, dmv, nz, bv);
+            if (a.out2) {
+                const long o2 = ((long)b * a.M + m) * HWout + pos;
+                a.out2[o2] = v + (a.addend ? a.addend[o2] : 0.f);
+            }
         } else if (a.epi == LA_EPI_BWD) {
             if (xin_p) part += v * xin_p[pos];
             v *= sc;

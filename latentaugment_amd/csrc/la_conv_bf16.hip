@@ -29,8 +29,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // ------------------------------------------------------------------------------------------------------------
 // weight packing: W[o][i][t] (fp32) -> out[term][t][cc][m][32] bf16 with (m,k) = (o,i) forward or (i,o) backward
 __global__ void la_pack_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int cout, int cin, int ktaps,
-                                    int transpose, int nterm) {
-    const int M = transpose ? cin : cout, C = transpose ? cout : cin;
+                                    int transpose, int nterm, float scale, int m_pad) {
+    const int Mreal = transpose ? cin : cout, C = transpose ? cout : cin;
+    const int M = m_pad > Mreal ? m_pad : Mreal;
     const int nck = (C + KCB - 1) / KCB;
     const long per_term = (long)ktaps * nck * M * KCB;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < per_term; idx += (long)gridDim.x * blockDim.x) {
@@ -40,9 +41,9 @@ __global__ void la_pack_bf16_kernel(const float* __restrict__ w, __bf16* __restr
         const int t = (int)(idx / ((long)KCB * M * nck));
         const int c = cc * KCB + k;
         float v = 0.f;
-        if (c < C) {
+        if (c < C && m < Mreal) {
             const int o = transpose ? c : m, i = transpose ? m : c;
-            v = w[((long)o * cin + i) * ktaps + t];
+            v = w[((long)o * cin + i) * ktaps + t] * scale;
         }
         for (int q = 0; q < nterm; ++q) {
             const __bf16 h = (__bf16)v;
@@ -55,13 +56,14 @@ __global__ void la_pack_bf16_kernel(const float* __restrict__ w, __bf16* __restr
 long la_conv_bf16_pack_elems(int M, int C, int ktaps) { return (long)ktaps * la_cdiv(C, KCB) * M * KCB; }
 
 int la_pack_conv_weights_bf16(const float* w, void* out, int cout, int cin, int ktaps, int transpose, int nterm,
-                              hipStream_t stream) {
+                              hipStream_t stream, float scale, int m_pad) {
     LA_CHECK_ARG(w && out && nterm >= 1 && nterm <= 3, "pack_bf16: bad args");
-    const long n = la_conv_bf16_pack_elems(transpose ? cin : cout, transpose ? cout : cin, ktaps);
+    const int Mreal = transpose ? cin : cout;
+    const long n = la_conv_bf16_pack_elems(m_pad > Mreal ? m_pad : Mreal, transpose ? cout : cin, ktaps);
     long blocks = la_cdiv(n, 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(la_pack_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, (__bf16*)out, cout, cin, ktaps,
-                       transpose, nterm);
+                       transpose, nterm, scale, m_pad);
     LA_CHECK_LAUNCH();
     return LA_OK;
 }

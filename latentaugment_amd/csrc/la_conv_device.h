@@ -115,6 +115,10 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                 float v = acc[i][j][r];
                 if (fwd) v = la_conv_epi_fwd(a, v, dmv, nz[j], bv);
                 out_b[(long)m * HWout + npos[j]] = v;
+                if (fwd && a.out2) {
+                    const long o2 = ((long)b * a.M + m) * HWout + npos[j];
+                    a.out2[o2] = v + (a.addend ? a.addend[o2] : 0.f);
+                }
             }
         }
     }

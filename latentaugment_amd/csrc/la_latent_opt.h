@@ -24,6 +24,8 @@ int la_latent_opt_create(la_synth* g, int img_resolution, int img_channels, int 
                          const float* bankW, long Mw, const float* bankXc, long Mx, int max_batch, void* workspace,
                          size_t workspace_bytes, la_latent_opt** out);
 void la_latent_opt_destroy(la_latent_opt* h);
+struct la_disc;
+int la_latent_opt_set_disc(la_latent_opt* h, la_disc* d);
 int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const float* const* final_noises, float* img_out,
                       float* w_aug_out, float* losses_out, hipStream_t stream);
 }

@@ -8,9 +8,11 @@
 #include <string.h>
 
 #include "la_criteria.h"
+#include "la_disc.h"
 
 struct la_latent_opt {
     la_synth* g;
+    la_disc* d;
     la_opt_config cfg;
     int R, imgc, wdim, num_ws, maxB;
     const float* bankW; long Mw;
@@ -51,8 +53,7 @@ extern "C" int la_latent_opt_create(la_synth* g, int img_resolution, int img_cha
                                     void* workspace, size_t workspace_bytes, la_latent_opt** out) {
     LA_CHECK_ARG(g && cfg && workspace && out, "latent_opt_create: null pointer");
     LA_CHECK_ARG(cfg->steps >= 0, "latent_opt_create: negative step count");
-    LA_CHECK_ARG(cfg->w_disc == 0.f && cfg->w_lpips == 0.f,
-                 "latent_opt_create: discriminator / LPIPS criteria are not part of this library yet (w_disc, w_lpips must be 0)");
+    LA_CHECK_ARG(cfg->w_lpips == 0.f, "latent_opt_create: the LPIPS criterion is not part of this library yet (w_lpips must be 0)");
     LA_CHECK_ARG(cfg->w_latent == 0.f || (bankW && Mw >= 1), "latent_opt_create: w_latent > 0 needs the latent bank W");
     LA_CHECK_ARG(cfg->w_pix == 0.f || (bankXc && Mx >= 1), "latent_opt_create: w_pix > 0 needs the cropped image bank X");
     LA_CHECK_ARG(cfg->crop >= 1 && cfg->crop_off >= 0 && cfg->crop + cfg->crop_off <= img_resolution,
@@ -71,6 +72,13 @@ extern "C" int la_latent_opt_create(la_synth* g, int img_resolution, int img_cha
 }
 
 extern "C" void la_latent_opt_destroy(la_latent_opt* h) { free(h); }
+
+// attach the discriminator engine used by the w_disc criterion (required before la_latent_opt_run when w_disc != 0)
+extern "C" int la_latent_opt_set_disc(la_latent_opt* h, la_disc* d) {
+    LA_CHECK_ARG(h, "latent_opt_set_disc: null handle");
+    h->d = d;
+    return LA_OK;
+}
 
 static int refresh_colsums(la_latent_opt* h, hipStream_t stream) {
     int rc;
@@ -97,7 +105,9 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     LA_HIP(hipMemcpyAsync(h->w_opt, w0, nw * sizeof(float), hipMemcpyDeviceToDevice, stream));
     LA_HIP(hipMemsetAsync(h->m, 0, nw * sizeof(float), stream));
     LA_HIP(hipMemsetAsync(h->v, 0, nw * sizeof(float), stream));
-    const bool img_crit = c.w_pix != 0.f;
+    const bool use_disc = c.w_disc != 0.f;
+    LA_CHECK_ARG(!use_disc || h->d, "latent_opt_run: w_disc != 0 but no discriminator attached (la_latent_opt_set_disc)");
+    const bool img_crit = c.w_pix != 0.f || use_disc;
     const bool want_losses = (c.criterion_mode == 0) || losses_out;
     if (c.criterion_mode == 1 && !h->colsums_valid) {
         if ((rc = refresh_colsums(h, stream))) return rc;
@@ -128,8 +138,16 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
         }
         const float* dws = nullptr;
         if (img_crit) {
-            if ((rc = la_pix_grad(img, h->colsumX, h->g_img, B, h->imgc, h->R, cc, off, -2.f * pix_coef, (float)h->Mx, stream)))
+            if (c.w_pix != 0.f &&
+                (rc = la_pix_grad(img, h->colsumX, h->g_img, B, h->imgc, h->R, cc, off, -2.f * pix_coef, (float)h->Mx, stream)))
                 return rc;
+            if (use_disc) {
+                // loss_disc = softplus(-D(x)).mean() * w_disc enters the total with a plus sign (:270)
+                if ((rc = la_disc_forward(h->d, img, B, stream))) return rc;
+                if ((rc = la_disc_loss(h->d, c.w_disc, c.norm_batch, want_losses ? h->losses + (size_t)(step - 1) * 4 + 2 : nullptr, stream)))
+                    return rc;
+                if ((rc = la_disc_backward(h->d, nullptr, h->g_img, c.w_pix != 0.f, stream))) return rc;
+            }
             if ((rc = la_synth_backward(h->g, h->g_img, h->dws, stream))) return rc;
             dws = h->dws;
         }

@@ -44,7 +44,8 @@ struct LaSeamArgs {
     float* dweff_part;       // [B][imgc][C][slabs]
 };
 
-int la_pack_conv_weights(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps, hipStream_t);
+int la_pack_conv_weights(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps, hipStream_t,
+                         float scale = 1.f, int wb_ld = 0);   // wb_ld > cin: backward slab rows padded with zero columns
 int la_affine_forward(const LaStyleTable& t, const float* ws, long ws_bstride, long ws_lstride, int B, int wdim,
                       float* s_all, hipStream_t);
 int la_demod_forward(const LaDemodTable& t, const float* s_all, int s_stride, int B, float* d_all, hipStream_t);

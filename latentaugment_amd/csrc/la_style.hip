@@ -8,27 +8,29 @@
 // ------------------------------------------------------------------------------------------------------------
 // weight packing:  W[o][i][ky][kx]  ->  wf[t][i][o], wb[t][o][i], wsq[o][i] = sum_t W^2      (t = ky*3+kx)
 __global__ void la_pack_conv_kernel(const float* __restrict__ w, float* wf, float* wb, float* wsq, int cout, int cin,
-                                    int ktaps) {
+                                    int ktaps, float scale, int wb_ld) {
     const long n = (long)cout * cin;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
         const int o = (int)(idx / cin), i = (int)(idx - (long)o * cin);
         float sq = 0.f;
         for (int t = 0; t < ktaps; ++t) {
-            const float v = w[idx * ktaps + t];
+            const float v = w[idx * ktaps + t] * scale;
             sq += v * v;
             if (wf) wf[((long)t * cin + i) * cout + o] = v;
-            if (wb) wb[((long)t * cout + o) * cin + i] = v;
+            if (wb) wb[((long)t * cout + o) * wb_ld + i] = v;
         }
         if (wsq) wsq[idx] = sq;
     }
 }
 
 int la_pack_conv_weights(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps,
-                         hipStream_t stream) {
+                         hipStream_t stream, float scale, int wb_ld) {
     LA_CHECK_ARG(w && cout > 0 && cin > 0 && ktaps > 0, "pack: bad args");
+    if (wb_ld <= 0) wb_ld = cin;
+    if (wb && wb_ld != cin) LA_HIP(hipMemsetAsync(wb, 0, sizeof(float) * (size_t)ktaps * cout * wb_ld, stream));   // zero the pad columns
     const long n = (long)cout * cin;
     hipLaunchKernelGGL(la_pack_conv_kernel, dim3(la_cdiv(n, 256) < 4096 ? la_cdiv(n, 256) : 4096), dim3(256), 0, stream,
-                       w, wf, wb, wsq, cout, cin, ktaps);
+                       w, wf, wb, wsq, cout, cin, ktaps, scale, wb_ld);
     LA_CHECK_LAUNCH();
     return LA_OK;
 }
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_kernel(const float* __restri
     const int b = blockIdx.y;
     for (int k = threadIdx.x; k < IMGC * C; k += blockDim.x) {
         const int i = k % C;
-        weff[k] = wrgb[k] * s[(long)b * s_stride + i];
+        weff[k] = wrgb[k] * (s ? s[(long)b * s_stride + i] : 1.f);
     }
     __syncthreads();
     const long p4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;

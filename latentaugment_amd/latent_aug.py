@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .synthesis import MappingEngine, SynthesisEngine
+from .synthesis import DiscriminatorEngine, MappingEngine, SynthesisEngine
 
 
 def center_crop_geometry(load_size):
@@ -70,7 +70,8 @@ class InMemoryLatentCodes:
 
 
 class LatentAug:
-    def __init__(self, phase, opt, save_dir, gpu_ids, generator=None, banks=None, latent_codes=None, group=None):
+    def __init__(self, phase, opt, save_dir, gpu_ids, generator=None, discriminator=None, banks=None, latent_codes=None,
+                 group=None):
         self.save_dir = save_dir
         self.phase = phase
         self.group = group
@@ -97,17 +98,20 @@ class LatentAug:
         self.criterion_mode = getattr(opt, 'criterion_mode', 'gemm')
         self.final_noise_mode = getattr(opt, 'final_noise_mode', 'random')
         self.precision = getattr(opt, 'precision', 'f32')
-        if self.w_disc > 0 or self.w_lpips > 0:
+        if self.w_lpips > 0:
             raise NotImplementedError(
-                'w_disc / w_lpips > 0: the discriminator and LPIPS criteria are the next rows of the scope table '
-                '(SURVEY.md 8f) and are not in this build yet')
+                'w_lpips > 0: the LPIPS criterion is the next row of the scope table (SURVEY.md 8f rank 2) and is not in '
+                'this build yet')
         if generator is None:
             # load_stylegan (reference :466-484): <model_dir>/<dataset>/training-runs/<dataset_name>/<modalities>/<exp>/<pkl>
             from . import formats
             path = formats.find_network_pkl(opt.model_dir, opt.dataset_aug, opt.dataset_name_aug, self.modalities,
                                             opt.exp_stylegan, opt.network_pkl_stylegan)
             print(f'Loading stylegan from "{path}"...')
-            generator = formats.load_network_pkl(path)['G_ema']
+            nets_ = formats.load_network_pkl(path)
+            generator = nets_['G_ema']
+            if discriminator is None:
+                discriminator = nets_.get('D')
         max_local = self.batch_size
         self.engine = SynthesisEngine.from_generator(generator, self.device, max_local, precision=self.precision)
         assert self.engine.img_resolution == self.res, 'opt.img_resolution does not match the generator'
@@ -158,7 +162,7 @@ class LatentAug:
             self.Xc = xc.permute(1, 0, 2, 3).contiguous()      # modality-major [C][M][crop*crop]
             del X, xc
         cfg = _lib.OptConfig(steps=int(self.num_epochs), lr=float(self.opt_lr), beta1=0.9, beta2=0.999, eps=1e-8,
-                             w_latent=float(self.w_latent), w_pix=float(self.w_pix), w_disc=0.0, w_lpips=0.0,
+                             w_latent=float(self.w_latent), w_pix=float(self.w_pix), w_disc=float(self.w_disc), w_lpips=0.0,
                              criterion_mode={'gemm': 0, 'collapsed': 1}[self.criterion_mode],
                              soft_aug=int(self.soft_aug), alpha=float(self.alpha), loop_noise_mode=1,
                              final_noise_mode={'none': 0, 'const': 1, 'random': 2}[self.final_noise_mode],
@@ -173,6 +177,13 @@ class LatentAug:
                                             _lib.ptr(self._workspace), self._workspace.numel(), C.byref(h)),
                    'la_latent_opt_create')
         self._h = h
+        self.disc = None
+        if self.w_disc > 0:
+            if discriminator is None:
+                raise _lib.LatentAugHipError('w_disc > 0 needs the discriminator (pass `discriminator=` or a network pickle)')
+            self.disc = DiscriminatorEngine(discriminator, self.device, max_local, precision=self.precision)
+            assert self.disc.img_resolution == self.res and self.disc.img_channels == self.engine.img_channels
+            _lib.check(lib.la_latent_opt_set_disc(h, self.disc.handle), 'la_latent_opt_set_disc')
 
     def __del__(self):
         h = getattr(self, '_h', None)
@@ -239,7 +250,7 @@ class LatentAug:
         if self.verbose_log and losses is not None:
             L = losses.cpu().numpy()
             for e in range(self.num_epochs):
-                self.stats_loss[f'epoch_{e}'] = dict(loss_latent=float(L[e, 0]), loss_pix=float(L[e, 1]),
+                self.stats_loss[f'epoch_{e}'] = dict(loss_latent=float(L[e, 0]), loss_pix=float(L[e, 1]), loss_disc=float(L[e, 2]),
                                                      loss=float(-L[e, 0] - L[e, 1] - L[e, 3] + L[e, 2]))
         return img, w_aug
 

@@ -246,3 +246,89 @@ class MappingEngine:
                                                         float(truncation_psi), num_ws, _lib.ptr(tmp), _lib.ptr(ws),
                                                         _lib.stream_ptr()), 'la_mapping_forward')
         return ws
+
+
+class DiscriminatorEngine:
+    """D(x, c=None) and d(loss_disc)/dx on the HIP path (reference calc_loss_disc, util_latent_aug.py:363-371).
+
+    Built from the discriminator's state_dict (names of legacy.py:271-288: b{res}.{fromrgb,conv0,conv1,skip}.*,
+    b4.{conv,fc,out}.*); architecture 'resnet', MinibatchStd group 4."""
+
+    def __init__(self, D, device, max_batch, conv_clamp=256.0, precision='f32', mbstd_group_size=4):
+        lib = _lib.load()
+        self._lib = lib
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.LatentAugHipError('DiscriminatorEngine needs a ROCm device (no CPU fallback)')
+        sd = D if isinstance(D, dict) else D.state_dict()
+        res_list = sorted({int(k.split('.')[0][1:]) for k in sd if k.startswith('b') and k.split('.')[0][1:].isdigit()})
+        assert res_list[0] == 4 and len(res_list) >= 2, 'expected discriminator blocks b4..bR'
+        R = res_list[-1]
+        self.img_resolution = R
+        self.img_channels = int(sd[f'b{R}.fromrgb.weight'].shape[1])
+        # channel table at resolution 4 << k: C[res] = in-channels of b{res}.conv0 ; C[4] = out-channels of b8.conv1
+        ch = {r: int(sd[f'b{r}.conv0.weight'].shape[1]) for r in res_list if r > 4}
+        ch[4] = int(sd['b4.conv.weight'].shape[0])
+        self.channels = [ch[r] for r in res_list]
+        self._keep = []
+
+        def dev(name):
+            t = sd[name].detach().to(device=self.device, dtype=torch.float32).contiguous()
+            self._keep.append(t)
+            return t
+
+        params = []
+        for r in reversed(res_list[1:]):
+            if r == R:
+                params += [dev(f'b{r}.fromrgb.weight'), dev(f'b{r}.fromrgb.bias')]
+            params += [dev(f'b{r}.conv0.weight'), dev(f'b{r}.conv0.bias'), dev(f'b{r}.conv1.weight'), dev(f'b{r}.conv1.bias'),
+                       dev(f'b{r}.skip.weight')]
+        params += [dev('b4.conv.weight'), dev('b4.conv.bias'), dev('b4.fc.weight'), dev('b4.fc.bias'), dev('b4.out.weight'),
+                   dev('b4.out.bias')]
+        assert len(params) == lib.la_disc_num_params(R)
+        f1 = np.array([1, 3, 3, 1], dtype=np.float32)
+        self._fir = np.ascontiguousarray(np.outer(f1, f1) / 64.0, dtype=np.float32)
+        chan = (C.c_int * len(self.channels))(*self.channels)
+        self.max_batch = int(max_batch)
+        nbytes = lib.la_disc_workspace_bytes(R, self.img_channels, chan, self.max_batch)
+        assert nbytes > 0
+        self._workspace = torch.empty([nbytes], dtype=torch.uint8, device=self.device)
+        pp = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        h = C.c_void_p()
+        clamp = float(-1.0 if conv_clamp is None else conv_clamp)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.la_disc_create(R, self.img_channels, chan, clamp, pp, len(params), self._fir.ctypes.data,
+                                          int(mbstd_group_size), self.max_batch, _lib.ptr(self._workspace), nbytes,
+                                          _lib.stream_ptr(), C.byref(h)), 'la_disc_create')
+        self._h = h
+        _lib.check(lib.la_disc_set_precision(h, PRECISIONS[precision]), 'la_disc_set_precision')
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            self._lib.la_disc_destroy(h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def forward(self, img):
+        """img [B,C,R,R] -> logits [B,1]."""
+        _lib.require_gpu(img)
+        img = img.contiguous().float()
+        B = img.shape[0]
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.la_disc_forward(self._h, _lib.ptr(img), B, _lib.stream_ptr()), 'la_disc_forward')
+            p = self._lib.la_disc_logits(self._h)
+            off = p - self._workspace.data_ptr()
+            return self._workspace[off:off + 4 * B].view(torch.float32).clone().reshape(B, 1)
+
+    def backward(self, dlogits):
+        """d(loss)/d(logits) [B,1] -> d(loss)/d(img) for the last forward."""
+        dl = dlogits.contiguous().float().reshape(-1)
+        B = dl.shape[0]
+        g = torch.empty([B, self.img_channels, self.img_resolution, self.img_resolution], device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.la_disc_backward(self._h, _lib.ptr(dl), _lib.ptr(g), 0, _lib.stream_ptr()), 'la_disc_backward')
+        return g

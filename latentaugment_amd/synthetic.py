@@ -73,3 +73,30 @@ def make_banks(num_ws, res=256, img_channels=2, w_dim=512, M_w=1024, M_x=256, se
     W = torch.randn([M_w, 1, w_dim], generator=torch.Generator().manual_seed(seed_w)).repeat(1, num_ws, 1)
     X = torch.rand([M_x, img_channels, res, res], generator=torch.Generator().manual_seed(seed_x)) * 2 - 1
     return W, X
+
+
+def make_discriminator_state_dict(img_resolution=256, img_channels=2, channel_base=32768, channel_max=512, seed=1000):
+    """state_dict of a random-init SG2 discriminator (architecture 'resnet'), keys as in the reference's D
+    (legacy.py:271-288): weights randn, biases 0."""
+    g = torch.Generator().manual_seed(seed)
+    ch = channels_dict(img_resolution, channel_base, channel_max)
+    sd = {}
+    for res in sorted(ch, reverse=True):
+        if res == 4:
+            break
+        p = f'b{res}'
+        if res == img_resolution:
+            sd[f'{p}.fromrgb.weight'] = torch.randn([ch[res], img_channels, 1, 1], generator=g)
+            sd[f'{p}.fromrgb.bias'] = torch.zeros([ch[res]])
+        sd[f'{p}.conv0.weight'] = torch.randn([ch[res], ch[res], 3, 3], generator=g)
+        sd[f'{p}.conv0.bias'] = torch.zeros([ch[res]])
+        sd[f'{p}.conv1.weight'] = torch.randn([ch[res // 2], ch[res], 3, 3], generator=g)
+        sd[f'{p}.conv1.bias'] = torch.zeros([ch[res // 2]])
+        sd[f'{p}.skip.weight'] = torch.randn([ch[res // 2], ch[res], 1, 1], generator=g)
+    sd['b4.conv.weight'] = torch.randn([ch[4], ch[4] + 1, 3, 3], generator=g)
+    sd['b4.conv.bias'] = torch.zeros([ch[4]])
+    sd['b4.fc.weight'] = torch.randn([ch[4], ch[4] * 16], generator=g)
+    sd['b4.fc.bias'] = torch.zeros([ch[4]])
+    sd['b4.out.weight'] = torch.randn([1, ch[4]], generator=g)
+    sd['b4.out.bias'] = torch.zeros([1])
+    return sd
