@@ -26,6 +26,15 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
+# fp32-equivalent peak of each contraction mode: one fp32 product = 1 fp32 MFMA, or 6 / 3 bf16 MFMAs of the split scheme
+CONTRACTION = {
+    'f32': dict(peak=MFMA_F32_PEAK_TFLOPS, kernel='la_conv_igemm_kernel (fp32 MFMA 32x32x2, exact fp32)', mfma_per_product=1),
+    'bf16x3': dict(peak=MFMA_BF16_PEAK_TFLOPS / 6, kernel='la_conv_bf16_kernel<NTERM=3> (fp32 split into 3 bf16 terms, 6 bf16 '
+                   'MFMA 32x32x16 per product, fp32 accumulate; fp32-class error)', mfma_per_product=6),
+    'bf16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_kernel<NTERM=2> (2 bf16 terms, 3 bf16 MFMA per product; '
+                   'approximate mode)', mfma_per_product=3),
+}
 
 
 def parse():
@@ -38,7 +47,7 @@ def parse():
     p.add_argument('--res', type=int, default=256)
     p.add_argument('--channel-base', type=int, default=32768, help='32768 = config-f, 16384 = config-e')
     p.add_argument('--criterion-mode', default='gemm', choices=['gemm', 'collapsed'])
-    p.add_argument('--precision', default='f32', choices=['f32', 'bf16x3', 'bf16x2'],
+    p.add_argument('--precision', default='bf16x3', choices=['f32', 'bf16x3', 'bf16x2'],
                    help='contraction arithmetic: exact fp32 MFMA, or fp32 split into 3 / 2 bf16 terms on the bf16 MFMA')
     p.add_argument('--w-disc', type=float, default=0.0, help='discriminator criterion weight (BASELINE.md second run: 0.01)')
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -166,14 +175,21 @@ def main():
         rc = lib.la_prof_end(C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
         if rc == 0 and ms.value > 0:
             tf = fl.value / (ms.value * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'la_conv_igemm_kernel (fp32 MFMA 32x32x2 implicit GEMM, all launches)',
-                    'achieved': tf, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TFLOPS,
+            cm = CONTRACTION[args.precision]
+            roof = {'bound': 'mfma', 'kernel': cm['kernel'] + ', all contraction launches',
+                    'achieved': tf, 'peak': cm['peak'], 'unit': 'TFLOP/s', 'frac': tf / cm['peak'],
+                    'peak_note': 'fp32-equivalent: dense MFMA peak of the instruction used / MFMAs issued per fp32 product '
+                                 f"({cm['mfma_per_product']}); executed MFMA rate = {tf * cm['mfma_per_product']:.0f} TFLOP/s",
                     'traffic': None, 'launches': n.value, 'avg_launch_ms': ms.value / max(n.value, 1),
                     'kernel_time_frac_of_wall': ms.value * 1e-3 / elapsed,
                     'algorithmic_gbs': by.value / (ms.value * 1e-3) / 1e9, 'hbm_peak_gbs': HBM_PEAK_GBS}
             pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
             if os.path.isfile(pmc):
-                roof['traffic'] = json.load(open(pmc)).get('bytes_per_launch')
+                pj = json.load(open(pmc))
+                if pj.get('precision') == args.precision and args.w_disc == 0:
+                    roof['traffic'] = pj.get('bytes_per_launch')
+                    roof['traffic_note'] = pj.get('note')
+            roof['algorithmic_bytes_per_launch'] = by.value / max(n.value, 1)
     assert out['A'].shape == (args.batch, 1, args.res, args.res)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -183,7 +199,9 @@ def main():
     line = {
         'metric': 'augmented images/sec (256^2, 20 latent steps)', 'value': images / elapsed, 'unit': 'images/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': {'f32': 'f32', 'bf16x3': 'f32 (split-bf16x3 on bf16 MFMA, fp32 accumulate)',
+                  'bf16x2': 'f32 (split-bf16x2 on bf16 MFMA, approximate)'}[args.precision], 'data': 'synthetic',
         'config': {'workload': f'SG2 config-{"f" if args.channel_base == 32768 else "e"} {args.res}x{args.res} 2-ch, '
                                f'random-init G, batch={args.batch}/GPU, {args.latent_steps} latent steps, '
                                f'w_latent=0.001 w_pix=0.1 w_disc={args.w_disc:g} (M_w=1024, M_x=256, criterion_mode={args.criterion_mode}), '

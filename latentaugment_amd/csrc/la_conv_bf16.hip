@@ -257,9 +257,170 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
     la_conv_epilogue<MT, SPLIT>(a, acc, red, ntile, m0, G, Ntot);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Halo variant for dense stride-1 3x3 launches on grids that tile exactly into 4 x 32 pixel tiles (the >= 64x64 layers,
+// i.e. the bulk of the FLOPs).  The flat kernel above re-gathers every input element once per tap (9x) from L2; here the
+// (4+2) x (32+2) halo of a 32-channel chunk is staged in LDS ONCE and the 9 taps read shifted fragments from it, so the
+// per-tap work of the loader shrinks to the 30 KB weight slab.  LDS: halo 204 px x 80 B x NTERM + A 128 x 80 B x NTERM
+// = 79.7 KB (x3) -> two workgroups per CU.
+#define HALO_W 34
+#define HALO_PX (6 * HALO_W)
+template <int MT, int NTERM>
+__global__ __launch_bounds__(256) void la_conv_bf16_halo_kernel(LaConvArgs a) {
+    constexpr int TM = MT / 64;
+    constexpr int A_U = (MT * 4) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;                                   // [NTERM][MT][ROWB]
+    unsigned char* Bs = smem + NTERM * MT * ROWB;               // [NTERM][HALO_PX][ROWB]
+    float (*red)[MT] = reinterpret_cast<float (*)[MT]>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    int ntile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) ntile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous tile runs
+    const int m0 = blockIdx.y * MT;
+    const int b = blockIdx.z;
+    const int G = a.Gy * a.Gx;
+    const int tpr = a.Gx >> 5;
+    const int tyb = ntile / tpr, txb = ntile - tyb * tpr;
+    const int y0 = tyb * 4 - 1, x0 = txb * 32 - 1;              // grid coordinates of halo pixel (0, 0)
+    const long HWin = (long)a.Hin * a.Win;
+    const uint2* inq_b = reinterpret_cast<const uint2*>(a.in_q) + (long)b * a.C * HWin;
+    const int nck = (a.C + KCB - 1) / KCB;
+    const long term_elems = a.wgt_bf16_term_elems;
+    const __bf16* wbase = reinterpret_cast<const __bf16*>(a.wgt_bf16);
+
+    uint4 areg[NTERM][A_U];
+    auto prefetch_a = [&](int cc, int t) {
+        const __bf16* slab = wbase + (((long)a.tap_w[t] * nck + cc) * a.M + m0) * KCB;
+#pragma unroll
+        for (int q = 0; q < NTERM; ++q)
+#pragma unroll
+            for (int u = 0; u < A_U; ++u) {
+                const int unit = tid + 256 * u;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (m0 + (unit >> 2) < a.M) v = *reinterpret_cast<const uint4*>(slab + (long)q * term_elems + (long)unit * 8);
+                areg[q][u] = v;
+            }
+    };
+    auto stage_a = [&]() {
+#pragma unroll
+        for (int q = 0; q < NTERM; ++q)
+#pragma unroll
+            for (int u = 0; u < A_U; ++u) {
+                const int unit = tid + 256 * u;
+                *reinterpret_cast<uint4*>(As + ((long)q * MT + (unit >> 2)) * ROWB + (unit & 3) * 16) = areg[q][u];
+            }
+    };
+    // halo staging: work item = (halo pixel, 16-channel half); 2 * HALO_PX = 408 items over 256 threads
+    auto stage_b = [&](int cc) {
+        for (int item = tid; item < 2 * HALO_PX; item += 256) {
+            const int hp = item >> 1, half = item & 1;
+            const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+            const int iy = y0 + hy, ix = x0 + hx;
+            const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            const long off = (long)iy * a.Win + ix;
+            const int c0 = cc * KCB + half * 16;
+            uint2 e[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                uint2 v = make_uint2(0u, 0u);
+                if (ok && c0 + j < a.C) v = inq_b[(long)(c0 + j) * HWin + off];
+                e[j] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < NTERM; ++q) {
+                unsigned w[8];
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    const unsigned e0 = q == 2 ? e[2 * d].y : e[2 * d].x;
+                    const unsigned e1 = q == 2 ? e[2 * d + 1].y : e[2 * d + 1].x;
+                    w[d] = __builtin_amdgcn_perm(e1, e0, q == 1 ? 0x07060302u : 0x05040100u);
+                }
+                unsigned char* p = Bs + ((long)q * HALO_PX + hp) * ROWB + half * 32;
+                *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+                *reinterpret_cast<uint4*>(p + 16) = make_uint4(w[4], w[5], w[6], w[7]);
+            }
+        }
+    };
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    prefetch_a(0, 0);
+    for (int cc = 0; cc < nck; ++cc) {
+        __syncthreads();                       // previous chunk's MFMAs are done with the halo
+        stage_b(cc);
+        for (int t = 0; t < a.ntaps; ++t) {
+            if (t > 0) __syncthreads();        // previous tap's MFMAs are done with the A slab
+            stage_a();
+            __syncthreads();
+            if (t + 1 < a.ntaps) prefetch_a(cc, t + 1);
+            else if (cc + 1 < nck) prefetch_a(cc + 1, 0);
+            const int shift = (1 + a.tap_dy[t]) * HALO_W + (1 + a.tap_dx[t]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[NTERM][TM], bf[NTERM][2];
+#pragma unroll
+                for (int q = 0; q < NTERM; ++q) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        af[q][i] = *reinterpret_cast<const bf16x8*>(As + ((long)q * MT + wm * (MT / 2) + i * 32 + l31) * ROWB + ks * 32 + lh * 16);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        bf[q][j] = *reinterpret_cast<const bf16x8*>(Bs + ((long)q * HALO_PX + (wn * 2 + j) * HALO_W + l31 + shift) * ROWB + ks * 32 + lh * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (NTERM == 3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);   // lh
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);   // hl
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);   // mm
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);   // mh
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);   // hm
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);   // hh
+                    }
+            }
+        }
+    }
+    __syncthreads();     // LDS is reused by the epilogue's reduction scratch
+    la_conv_epilogue<MT, false, true>(a, acc, red, ntile, m0, G, G);
+}
+
+// can this launch use the halo kernel?  dense stride-1 taps within +-1, grid = whole 4x32 tiles, not a split-K candidate
+static bool halo_ok(const LaConvArgs& a) {
+    if (a.in_sy != 1 || a.in_sx != 1 || a.out_sy != 1 || a.out_sx != 1 || a.out_oy != 0 || a.out_ox != 0) return false;
+    if ((a.Gx & 31) != 0 || (a.Gy & 3) != 0 || a.Gy != a.Hout || a.Gx != a.Wout) return false;
+    for (int t = 0; t < a.ntaps; ++t)
+        if (a.tap_dy[t] < -1 || a.tap_dy[t] > 1 || a.tap_dx[t] < -1 || a.tap_dx[t] > 1) return false;
+    return true;
+}
+
 template <int NTERM>
 static void launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, hipStream_t stream) {
     const size_t lds128 = (size_t)NTERM * (128 + NT) * ROWB, lds64 = (size_t)NTERM * (64 + NT) * ROWB;
+    if (!split && halo_ok(as)) {
+        const size_t h128 = (size_t)NTERM * (128 + HALO_PX) * ROWB, h64 = (size_t)NTERM * (64 + HALO_PX) * ROWB;
+        static bool attr_done = false;
+        if (!attr_done) {      // > 64 KB of dynamic LDS needs the opt-in (idempotent)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, NTERM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h128);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<64, NTERM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h64);
+            attr_done = true;
+        }
+        if (MTsel == 128) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, NTERM>), grid, dim3(256), h128, stream, as);
+        else hipLaunchKernelGGL((la_conv_bf16_halo_kernel<64, NTERM>), grid, dim3(256), h64, stream, as);
+        return;
+    }
     if (MTsel == 128) {
         if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, NTERM>), grid, dim3(256), lds128, stream, as);
         else hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, NTERM>), grid, dim3(256), lds128, stream, as);

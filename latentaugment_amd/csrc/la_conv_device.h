@@ -12,7 +12,9 @@ __device__ __forceinline__ float la_conv_epi_fwd(const LaConvArgs& a, float v, f
     return la_act_fwd(v * dmv + nz + bv, a.act, a.alpha, a.gain, a.clamp);
 }
 
-template <int MT, bool SPLIT>
+// TILE2D: the 128 pixels of a tile are 4 rows x 32 columns of the output grid (halo kernel) instead of 128 consecutive
+// grid positions; wave N-subtile (wn, j) is then row wn*2 + j of the tile.
+template <int MT, bool SPLIT, bool TILE2D = false>
 __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&acc)[MT / 64][2], float (*red)[MT],
                                                  int ntile, int m0, int G, int Ntot) {
     constexpr int TM = MT / 64;
@@ -44,10 +46,18 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
     long npos[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int g = ntile * NT + wn * 64 + j * 32 + l31;
-        pix_ok[j] = g < G;
-        const int gy = pix_ok[j] ? g / a.Gx : 0;
-        const int gx = pix_ok[j] ? g - gy * a.Gx : 0;
+        int gy, gx;
+        if (TILE2D) {
+            const int tpr = a.Gx >> 5;                  // tiles per row of tiles
+            const int tyb = ntile / tpr, txb = ntile - tyb * tpr;
+            gy = tyb * 4 + wn * 2 + j; gx = txb * 32 + l31;
+            pix_ok[j] = true;                           // the halo kernel only runs on grids that tile exactly
+        } else {
+            const int g = ntile * NT + wn * 64 + j * 32 + l31;
+            pix_ok[j] = g < G;
+            gy = pix_ok[j] ? g / a.Gx : 0;
+            gx = pix_ok[j] ? g - gy * a.Gx : 0;
+        }
         const int oy = gy * a.out_sy + a.out_oy, ox = gx * a.out_sx + a.out_ox;
         npos[j] = (long)oy * a.Wout + ox;
     }
