@@ -52,6 +52,9 @@ def parse():
     p.add_argument('--w-disc', type=float, default=0.0, help='discriminator criterion weight (BASELINE.md second run: 0.01)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true', help='skip the HIP-event leg (used under rocprofv3)')
+    p.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                   help="'gloo' + --force-device rehearses the multi-rank path on a 1-GPU box (collective staged through host)")
+    p.add_argument('--force-device', type=int, default=-1, help='rehearsal only: every rank uses this device index')
     return p.parse_args()
 
 
@@ -109,11 +112,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run')
+    if args.force_device >= 0:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)      # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group('gloo')
 
     from latentaugment_amd import _lib, synthetic
     from latentaugment_amd.augments import create_augment
@@ -146,8 +154,13 @@ def main():
         img, w_aug, _ = la.run_local(aug.w_AB)
         if world > 1:
             flat = torch.cat([img.reshape(args.batch, -1), w_aug.reshape(args.batch, -1)], dim=1)
-            out = torch.empty([world * args.batch, flat.shape[1]], device=dev)
-            dist.all_gather_into_tensor(out, flat)          # ONE RCCL collective per batch over xGMI
+            if args.dist_backend == 'nccl':
+                out = torch.empty([world * args.batch, flat.shape[1]], device=dev)
+                dist.all_gather_into_tensor(out, flat)      # ONE RCCL collective per batch over xGMI
+            else:                                           # rehearsal path (gloo): same collective, staged through host
+                hflat = flat.cpu()
+                out = torch.empty([world * args.batch, hflat.shape[1]])
+                dist.all_gather_into_tensor(out, hflat)
         aug.real_AB_aug, aug.w_AB_aug = img, w_aug
         return aug.get_output()
 
@@ -192,7 +205,7 @@ def main():
             roof['algorithmic_bytes_per_launch'] = by.value / max(n.value, 1)
     assert out['A'].shape == (args.batch, 1, args.res, args.res)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.dist_backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     images = args.steps * args.batch * world
