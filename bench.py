@@ -81,9 +81,9 @@ def cpu_baseline(sd, meta, args):
                        channel_base=args.channel_base)
     G.load_state_dict(sd, strict=False)
     G = G.eval().requires_grad_(False)
-    b = 2
+    b = 4
     W, X = synthetic.make_banks(G.num_ws, res=args.res, M_w=1024, M_x=256)
-    nstep = 2
+    nstep = 4
     ref = lar.LatentAugRef(G, None, W=W, X=X, res=args.res, num_epochs=nstep, opt_lr=0.01, crop_size=64, w_latent=0.001,
                            w_pix=0.1)
     w0 = synthetic.make_latents(b)
