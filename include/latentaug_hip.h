@@ -205,13 +205,41 @@ int la_disc_backward(la_disc* h, const float* dlogits, float* g_img, int accumul
 const float* la_disc_logits(const la_disc* h);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Perceptual feature engine: replaces  self.vgg16(x, resize_images=False, return_lpips=True)  and its backward inside
+ * calc_loss_lpips_torchscript (util_latent_aug.py:387-409).  The network is described by the caller as a list of ops
+ * (VGG16 = 13 x conv3x3+ReLU, 4 x max-pool, 5 taps); a tap emits f * rsqrt(sum_c f^2 + 1e-10) * sqrt(lin[c]) / sqrt(H*W),
+ * so squared L2 between two outputs is their LPIPS distance.  params: per op in order -- conv: weight [cout][cin][3][3],
+ * bias [cout]; tap: lin [C]; pools: none.  la_crop_repeat_f32: the crop + `.repeat([1,3,1,1])` of :394 for every modality
+ * (rows ordered modality-major: row = c*B + b) with an affine preprocess; la_crop_repeat_grad_f32: its adjoint, ADDED to
+ * g_img.
+ * ------------------------------------------------------------------------------------------------------------- */
+#define LA_FEAT_CONV_RELU 0
+#define LA_FEAT_TAP 1
+#define LA_FEAT_MAXPOOL2 2
+#define LA_FEAT_AVGPOOL2 3
+typedef struct la_feat_op { int kind, cin, cout; } la_feat_op;
+typedef struct la_feat la_feat;
+size_t la_feat_workspace_bytes(int nops, const la_feat_op* ops, int in_ch, int in_res, int max_batch);
+int la_feat_create(int nops, const la_feat_op* ops, const float* const* params, int nparams, int in_ch, int in_res,
+                   int max_batch, void* workspace, size_t workspace_bytes, la_stream_t stream, la_feat** out);
+void la_feat_destroy(la_feat* h);
+int la_feat_num_features(const la_feat* h);
+int la_feat_set_precision(la_feat* h, int precision);
+int la_feat_forward(la_feat* h, const float* x, int N, float* feat_out, la_stream_t stream);
+int la_feat_backward(la_feat* h, const float* gfeat, float* gx, la_stream_t stream);
+int la_crop_repeat_f32(const float* img, float* xc, int B, int imgc, int R, int S, int y0, int x0, int rep, float scale,
+                       float shift, la_stream_t stream);
+int la_crop_repeat_grad_f32(const float* gxc, float* g_img, int B, int imgc, int R, int S, int y0, int x0, int rep,
+                            float scale, la_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * The loop: replaces LatentAug.forward(w, fname) (augments/utils/util_latent_aug.py:207-310) for 3-D w input.
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct la_opt_config {
     int steps;              /* opt_num_epochs (latent_aug.py:81) */
     float lr;               /* opt_lr (latent_aug.py:82) */
     float beta1, beta2, eps;
-    float w_latent, w_pix, w_disc, w_lpips; /* latent_aug.py:88-91; w_lpips must be 0 in this version */
+    float w_latent, w_pix, w_disc, w_lpips; /* latent_aug.py:88-91 */
     int criterion_mode;     /* 0: scan the banks every step (reference formulation); 1: cached bank column sums */
     int soft_aug;           /* latent_aug.py:94 */
     float alpha;            /* latent_aug.py:95 */
@@ -231,6 +259,14 @@ int la_latent_opt_create(la_synth* g, int img_resolution, int img_channels, int 
 void la_latent_opt_destroy(la_latent_opt* h);
 /* attach the discriminator used when cfg.w_disc != 0 (must outlive the loop handle) */
 int la_latent_opt_set_disc(la_latent_opt* h, la_disc* d);
+/* attach the LPIPS criterion used when cfg.w_lpips != 0: feature engine, real-feature banks [C][Mf][F] (register_buffer
+ * 'fea_<mode>', util_latent_aug.py:171; modality-major), crop size S (crop_size_aug), input preprocess x*scale+shift.
+ * la_latent_opt_set_crop_pos: absolute (x, y) of the S x S window, drawn by the host once per forward
+ * (util_dataset.py:284-296 + the centre-crop offset). */
+size_t la_latent_opt_lpips_workspace_bytes(int img_channels, int F, int S, long Mf, int max_batch);
+int la_latent_opt_set_lpips(la_latent_opt* h, la_feat* f, const float* bankF, long Mf, int S, float pre_scale,
+                            float pre_shift, void* ws, size_t ws_bytes);
+int la_latent_opt_set_crop_pos(la_latent_opt* h, int x, int y);
 /* w0 [B][w_dim] -> img_out [B][C][R][R], w_aug_out [B][num_ws][w_dim]; losses_out (may be NULL) [steps][4] =
  * weighted {latent, pix, disc, lpips} per step. */
 int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const float* const* final_noises, float* img_out,

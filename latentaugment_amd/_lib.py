@@ -14,6 +14,11 @@ class LatentAugHipError(RuntimeError):
     pass
 
 
+class FeatOp(C.Structure):
+    """Mirror of `la_feat_op`."""
+    _fields_ = [('kind', C.c_int), ('cin', C.c_int), ('cout', C.c_int)]
+
+
 class OptConfig(C.Structure):
     """Mirror of `la_opt_config` (include/latentaug_hip.h)."""
     _fields_ = [
@@ -83,6 +88,18 @@ SIGNATURES = {
     'la_disc_backward': (_I, [_P, _P, _P, _I, _P]),
     'la_disc_logits': (_P, [_P]),
     'la_latent_opt_set_disc': (_I, [_P, _P]),
+    'la_feat_workspace_bytes': (_Z, [_I, _P, _I, _I, _I]),
+    'la_feat_create': (_I, [_I, _P, _P, _I, _I, _I, _I, _P, _Z, _P, _P]),
+    'la_feat_destroy': (None, [_P]),
+    'la_feat_num_features': (_I, [_P]),
+    'la_feat_set_precision': (_I, [_P, _I]),
+    'la_feat_forward': (_I, [_P, _P, _I, _P, _P]),
+    'la_feat_backward': (_I, [_P, _P, _P, _P]),
+    'la_crop_repeat_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    'la_crop_repeat_grad_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    'la_latent_opt_lpips_workspace_bytes': (_Z, [_I, _I, _I, _L, _I]),
+    'la_latent_opt_set_lpips': (_I, [_P, _P, _P, _L, _I, _F, _F, _P, _Z]),
+    'la_latent_opt_set_crop_pos': (_I, [_P, _I, _I]),
     'la_prof_begin': (_I, []),
     'la_prof_end': (_I, [_P, _P, _P, _P]),
 }

@@ -26,6 +26,11 @@ int la_latent_opt_create(la_synth* g, int img_resolution, int img_channels, int 
 void la_latent_opt_destroy(la_latent_opt* h);
 struct la_disc;
 int la_latent_opt_set_disc(la_latent_opt* h, la_disc* d);
+struct la_feat;
+size_t la_latent_opt_lpips_workspace_bytes(int img_channels, int F, int S, long Mf, int max_batch);
+int la_latent_opt_set_lpips(la_latent_opt* h, la_feat* f, const float* bankF, long Mf, int S, float pre_scale, float pre_shift,
+                            void* ws, size_t ws_bytes);
+int la_latent_opt_set_crop_pos(la_latent_opt* h, int x, int y);
 int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const float* const* final_noises, float* img_out,
                       float* w_aug_out, float* losses_out, hipStream_t stream);
 }

@@ -9,6 +9,7 @@
 
 #include "la_criteria.h"
 #include "la_disc.h"
+#include "la_feat.h"
 
 struct la_latent_opt {
     la_synth* g;
@@ -19,6 +20,12 @@ struct la_latent_opt {
     const float* bankX; long Mx;     // [imgc][Mx][cc*cc]
     float *w_opt, *m, *v, *dw, *dws, *g_img, *colsumW, *colsumX, *yx, *yy, *xx, *xc, *losses;
     int colsums_valid;
+    // LPIPS criterion (la_latent_opt_set_lpips)
+    la_feat* f;
+    const float* bankF; long Mf; int F, S, crop_x, crop_y;
+    float pre_scale, pre_shift;
+    float *l_xc, *l_feat, *l_gfeat, *l_gxc, *l_colsum, *l_yx, *l_yy, *l_xx;
+    int l_colsum_valid;
 };
 
 static size_t al(size_t n) { return ((n * sizeof(float)) + 63) & ~(size_t)63; }
@@ -53,7 +60,6 @@ extern "C" int la_latent_opt_create(la_synth* g, int img_resolution, int img_cha
                                     void* workspace, size_t workspace_bytes, la_latent_opt** out) {
     LA_CHECK_ARG(g && cfg && workspace && out, "latent_opt_create: null pointer");
     LA_CHECK_ARG(cfg->steps >= 0, "latent_opt_create: negative step count");
-    LA_CHECK_ARG(cfg->w_lpips == 0.f, "latent_opt_create: the LPIPS criterion is not part of this library yet (w_lpips must be 0)");
     LA_CHECK_ARG(cfg->w_latent == 0.f || (bankW && Mw >= 1), "latent_opt_create: w_latent > 0 needs the latent bank W");
     LA_CHECK_ARG(cfg->w_pix == 0.f || (bankXc && Mx >= 1), "latent_opt_create: w_pix > 0 needs the cropped image bank X");
     LA_CHECK_ARG(cfg->crop >= 1 && cfg->crop_off >= 0 && cfg->crop + cfg->crop_off <= img_resolution,
@@ -78,6 +84,52 @@ extern "C" int la_latent_opt_set_disc(la_latent_opt* h, la_disc* d) {
     LA_CHECK_ARG(h, "latent_opt_set_disc: null handle");
     h->d = d;
     return LA_OK;
+}
+
+// LPIPS criterion: feature engine, real-feature banks [imgc][Mf][F] (modality-major), crop size S (crop_size_aug) and the
+// affine input preprocess x*scale + shift.  ws: la_latent_opt_lpips_workspace_bytes() of device memory.
+extern "C" size_t la_latent_opt_lpips_workspace_bytes(int img_channels, int F, int S, long Mf, int max_batch) {
+    const size_t n = (size_t)img_channels * max_batch;
+    size_t off = 0;
+    off += al(n * 3 * S * S) * 2;          // xc, gxc
+    off += al(n * F) * 2;                  // feat, gfeat
+    off += al((size_t)img_channels * F);   // colsum
+    off += al((size_t)Mf * max_batch) + al((size_t)Mf) + al((size_t)max_batch);
+    return off;
+}
+
+extern "C" int la_latent_opt_set_lpips(la_latent_opt* h, la_feat* f, const float* bankF, long Mf, int S, float pre_scale,
+                                       float pre_shift, void* ws, size_t ws_bytes) {
+    LA_CHECK_ARG(h && f && bankF && Mf >= 1 && S >= 1 && ws, "latent_opt_set_lpips: bad arguments");
+    const int F = la_feat_num_features(f);
+    LA_CHECK_ARG(ws_bytes >= la_latent_opt_lpips_workspace_bytes(h->imgc, F, S, Mf, h->maxB), "latent_opt_set_lpips: workspace too small");
+    h->f = f; h->bankF = bankF; h->Mf = Mf; h->F = F; h->S = S; h->pre_scale = pre_scale; h->pre_shift = pre_shift;
+    char* base = (char*)ws; size_t off = 0;
+    auto take = [&](size_t n) { float* p = (float*)(base + off); off += al(n); return p; };
+    const size_t n = (size_t)h->imgc * h->maxB;
+    h->l_xc = take(n * 3 * S * S); h->l_gxc = take(n * 3 * S * S);
+    h->l_feat = take(n * F); h->l_gfeat = take(n * F);
+    h->l_colsum = take((size_t)h->imgc * F);
+    h->l_yx = take((size_t)Mf * h->maxB); h->l_yy = take((size_t)Mf); h->l_xx = take((size_t)h->maxB);
+    h->l_colsum_valid = 0;
+    return LA_OK;
+}
+
+// position of the crop_size_aug window inside the image, drawn by the host once per forward (util_dataset.py:284-296);
+// (x, y) are absolute pixel coordinates (centre-crop offset already added)
+extern "C" int la_latent_opt_set_crop_pos(la_latent_opt* h, int x, int y) {
+    LA_CHECK_ARG(h && x >= 0 && y >= 0, "latent_opt_set_crop_pos: bad arguments");
+    h->crop_x = x; h->crop_y = y;
+    return LA_OK;
+}
+
+__global__ void la_lpips_gfeat_kernel(const float* __restrict__ feat, const float* __restrict__ colsum, float* __restrict__ g, int B,
+                                      int F, float coef2, float mrows, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long n = i / F; const int k = (int)(i - n * F);
+    const int c = (int)(n / B);
+    g[i] = coef2 * (mrows * feat[i] - colsum[(long)c * F + k]);
 }
 
 static int refresh_colsums(la_latent_opt* h, hipStream_t stream) {
@@ -107,7 +159,11 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     LA_HIP(hipMemsetAsync(h->v, 0, nw * sizeof(float), stream));
     const bool use_disc = c.w_disc != 0.f;
     LA_CHECK_ARG(!use_disc || h->d, "latent_opt_run: w_disc != 0 but no discriminator attached (la_latent_opt_set_disc)");
-    const bool img_crit = c.w_pix != 0.f || use_disc;
+    const bool use_lpips = c.w_lpips != 0.f;
+    LA_CHECK_ARG(!use_lpips || h->f, "latent_opt_run: w_lpips != 0 but no feature engine attached (la_latent_opt_set_lpips)");
+    LA_CHECK_ARG(!use_lpips || (h->crop_x + h->S <= h->R && h->crop_y + h->S <= h->R), "latent_opt_run: LPIPS crop outside the image");
+    const bool img_crit = c.w_pix != 0.f || use_disc || use_lpips;
+    const float lp_coef = use_lpips ? c.w_lpips / ((float)h->imgc * (float)h->Mf * nb) : 0.f;
     const bool want_losses = (c.criterion_mode == 0) || losses_out;
     if (c.criterion_mode == 1 && !h->colsums_valid) {
         if ((rc = refresh_colsums(h, stream))) return rc;
@@ -147,6 +203,32 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
                 if ((rc = la_disc_loss(h->d, c.w_disc, c.norm_batch, want_losses ? h->losses + (size_t)(step - 1) * 4 + 2 : nullptr, stream)))
                     return rc;
                 if ((rc = la_disc_backward(h->d, nullptr, h->g_img, c.w_pix != 0.f, stream))) return rc;
+            }
+            if (use_lpips) {
+                // loss_lpips = mean_modes( sum_{m,n} |f_n - F_m|^2 / (n*m) ) * w_lpips, entering the total with a minus sign (:270)
+                const int N = h->imgc * B;
+                const long FF = h->F;
+                if (c.w_pix == 0.f && !use_disc) LA_HIP(hipMemsetAsync(h->g_img, 0, sizeof(float) * (size_t)B * h->imgc * h->R * h->R, stream));
+                if ((rc = la_crop_repeat_f32(img, h->l_xc, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, 3, h->pre_scale, h->pre_shift, stream))) return rc;
+                if ((rc = la_feat_forward(h->f, h->l_xc, N, h->l_feat, stream))) return rc;
+                if (c.criterion_mode == 0 || !h->l_colsum_valid) {
+                    for (int ch = 0; ch < h->imgc; ++ch)
+                        if ((rc = la_bank_colsum(h->bankF + (long)ch * h->Mf * FF, h->Mf, FF, h->l_colsum + (long)ch * FF, stream))) return rc;
+                    h->l_colsum_valid = 1;
+                }
+                if (want_losses) {
+                    float* L = h->losses + (size_t)(step - 1) * 4 + 3;
+                    for (int ch = 0; ch < h->imgc; ++ch)
+                        if ((rc = la_l2_mean_from_bank(h->bankF + (long)ch * h->Mf * FF, h->Mf, FF, h->l_feat + (long)ch * B * FF, B, FF, 0,
+                                                       h->l_yx, h->l_yy, h->l_xx, lp_coef, L, ch > 0, stream)))
+                            return rc;
+                }
+                const long total = (long)N * FF;
+                hipLaunchKernelGGL(la_lpips_gfeat_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, stream, h->l_feat, h->l_colsum, h->l_gfeat,
+                                   B, (int)FF, -2.f * lp_coef, (float)h->Mf, total);
+                if ((rc = la_feat_backward(h->f, h->l_gfeat, h->l_gxc, stream))) return rc;
+                if ((rc = la_crop_repeat_grad_f32(h->l_gxc, h->g_img, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, 3, h->pre_scale, stream)))
+                    return rc;
             }
             if ((rc = la_synth_backward(h->g, h->g_img, h->dws, stream))) return rc;
             dws = h->dws;

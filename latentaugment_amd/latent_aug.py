@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .synthesis import DiscriminatorEngine, MappingEngine, SynthesisEngine
+from .synthesis import DiscriminatorEngine, FeatureEngine, MappingEngine, SynthesisEngine
 
 
 def center_crop_geometry(load_size):
@@ -71,7 +71,7 @@ class InMemoryLatentCodes:
 
 class LatentAug:
     def __init__(self, phase, opt, save_dir, gpu_ids, generator=None, discriminator=None, banks=None, latent_codes=None,
-                 group=None):
+                 feature_net=None, group=None):
         self.save_dir = save_dir
         self.phase = phase
         self.group = group
@@ -98,10 +98,11 @@ class LatentAug:
         self.criterion_mode = getattr(opt, 'criterion_mode', 'gemm')
         self.final_noise_mode = getattr(opt, 'final_noise_mode', 'random')
         self.precision = getattr(opt, 'precision', 'f32')
-        if self.w_lpips > 0:
+        if self.w_lpips > 0 and feature_net is None:
             raise NotImplementedError(
-                'w_lpips > 0: the LPIPS criterion is the next row of the scope table (SURVEY.md 8f rank 2) and is not in '
-                'this build yet')
+                'w_lpips > 0 needs `feature_net=` (op list for synthesis.FeatureEngine, e.g. vgg16_lpips_ops(...)) and '
+                "banks['fea']: the NVIDIA vgg16.pt / LPIPS weights the reference downloads (util_latent_aug.py:36) are not "
+                'obtainable offline')
         if generator is None:
             # load_stylegan (reference :466-484): <model_dir>/<dataset>/training-runs/<dataset_name>/<modalities>/<exp>/<pkl>
             from . import formats
@@ -162,7 +163,8 @@ class LatentAug:
             self.Xc = xc.permute(1, 0, 2, 3).contiguous()      # modality-major [C][M][crop*crop]
             del X, xc
         cfg = _lib.OptConfig(steps=int(self.num_epochs), lr=float(self.opt_lr), beta1=0.9, beta2=0.999, eps=1e-8,
-                             w_latent=float(self.w_latent), w_pix=float(self.w_pix), w_disc=float(self.w_disc), w_lpips=0.0,
+                             w_latent=float(self.w_latent), w_pix=float(self.w_pix), w_disc=float(self.w_disc),
+                             w_lpips=float(self.w_lpips),
                              criterion_mode={'gemm': 0, 'collapsed': 1}[self.criterion_mode],
                              soft_aug=int(self.soft_aug), alpha=float(self.alpha), loop_noise_mode=1,
                              final_noise_mode={'none': 0, 'const': 1, 'random': 2}[self.final_noise_mode],
@@ -185,6 +187,23 @@ class LatentAug:
             assert self.disc.img_resolution == self.res and self.disc.img_channels == self.engine.img_channels
             _lib.check(lib.la_latent_opt_set_disc(h, self.disc.handle), 'la_latent_opt_set_disc')
 
+        self.feat = None
+        if self.w_lpips > 0:
+            # perceptual criterion (reference :160-171, :387-409): features of crop_size_aug^2 crops, one bank per modality
+            imgc = self.engine.img_channels
+            self.feat = FeatureEngine(feature_net, self.device, in_res=self.crop_size, max_batch=imgc * max_local,
+                                      precision=self.precision)
+            fea = banks['fea']
+            assert len(fea) == imgc
+            self.Fbank = torch.stack([t.to(device=self.device, dtype=torch.float32) for t in fea]).contiguous()   # [C][Mf][F]
+            assert self.Fbank.shape[2] == self.feat.num_features, 'feature bank does not match the feature net'
+            Mf = self.Fbank.shape[1]
+            scale, shift = getattr(opt, 'lpips_preproc', (1.0, 0.0))
+            nb = lib.la_latent_opt_lpips_workspace_bytes(imgc, self.feat.num_features, self.crop_size, Mf, max_local)
+            self._lpips_ws = torch.empty([nb], dtype=torch.uint8, device=self.device)
+            _lib.check(lib.la_latent_opt_set_lpips(h, self.feat.handle, _lib.ptr(self.Fbank), Mf, self.crop_size, float(scale),
+                                                   float(shift), _lib.ptr(self._lpips_ws), nb), 'la_latent_opt_set_lpips')
+
     def __del__(self):
         h = getattr(self, '_h', None)
         if h:
@@ -200,8 +219,21 @@ class LatentAug:
         return latent[:, :1, :]
 
     # ------------------------------------------------------------------ the hot path
-    def run_local(self, w, final_noises=None, want_losses=False):
+    def crop_window(self, crop_pos):
+        """Absolute (x, y) of the crop_size_aug window for a position drawn by get_params (relative to the centre crop
+        when preprocess is 'center_random_crop'; util_dataset.py:298-315)."""
+        x1, y1 = crop_pos
+        off = self.center_off if self.preprocess in ('center_crop', 'center_random_crop') else 0
+        return off + int(x1), off + int(y1)
+
+    def run_local(self, w, final_noises=None, want_losses=False, crop_pos=None):
         """w [b,1,w_dim] on this device -> (img [b,C,R,R], w_aug [b,num_ws,w_dim], losses or None)."""
+        if self.feat is not None:
+            if crop_pos is None:
+                crop_pos = getattr(self, 'crop_params', None)
+                crop_pos = crop_pos['crop_pos'] if crop_pos else get_params(self.res, self.crop_size, self.preprocess)['crop_pos']
+            ax, ay = self.crop_window(crop_pos)
+            _lib.check(self._lib.la_latent_opt_set_crop_pos(self._h, ax, ay), 'la_latent_opt_set_crop_pos')
         w = w.to(device=self.device, dtype=torch.float32).contiguous()
         b = w.shape[0]
         assert w.ndim == 3 and w.shape[1:] == (1, self.w_dim)
@@ -251,7 +283,7 @@ class LatentAug:
             L = losses.cpu().numpy()
             for e in range(self.num_epochs):
                 self.stats_loss[f'epoch_{e}'] = dict(loss_latent=float(L[e, 0]), loss_pix=float(L[e, 1]), loss_disc=float(L[e, 2]),
-                                                     loss=float(-L[e, 0] - L[e, 1] - L[e, 3] + L[e, 2]))
+                                                     loss_lpips=float(L[e, 3]), loss=float(-L[e, 0] - L[e, 1] - L[e, 3] + L[e, 2]))
         return img, w_aug
 
     __call__ = forward

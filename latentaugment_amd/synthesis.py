@@ -332,3 +332,97 @@ class DiscriminatorEngine:
         with torch.cuda.device(self.device):
             _lib.check(self._lib.la_disc_backward(self._h, _lib.ptr(dl), _lib.ptr(g), 0, _lib.stream_ptr()), 'la_disc_backward')
         return g
+
+
+FEAT_CONV, FEAT_TAP, FEAT_MAXPOOL, FEAT_AVGPOOL = 0, 1, 2, 3
+
+
+class FeatureEngine:
+    """LPIPS-style feature net on the HIP path: `vgg16(x, resize_images=False, return_lpips=True)` of
+    util_latent_aug.py:395 and its backward.  `ops` is a list of ('conv', weight, bias) | ('tap', lin) | ('maxpool',) |
+    ('avgpool',) in execution order; see `vgg16_lpips_ops` for the VGG16 layout."""
+
+    def __init__(self, ops, device, in_res, max_batch, in_ch=3, precision='f32'):
+        lib = _lib.load()
+        self._lib = lib
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.LatentAugHipError('FeatureEngine needs a ROCm device (no CPU fallback)')
+        self._keep = []
+        desc, params = [], []
+        c = in_ch
+        for op in ops:
+            if op[0] == 'conv':
+                w = op[1].detach().to(self.device, torch.float32).contiguous()
+                b = op[2].detach().to(self.device, torch.float32).contiguous()
+                assert w.shape[1] == c and w.shape[2:] == (3, 3)
+                desc.append(_lib.FeatOp(FEAT_CONV, c, w.shape[0]))
+                c = w.shape[0]
+                params += [w, b]
+            elif op[0] == 'tap':
+                lin = op[1].detach().to(self.device, torch.float32).contiguous()
+                assert lin.shape == (c,)
+                desc.append(_lib.FeatOp(FEAT_TAP, c, c))
+                params.append(lin)
+            elif op[0] in ('maxpool', 'avgpool'):
+                desc.append(_lib.FeatOp(FEAT_MAXPOOL if op[0] == 'maxpool' else FEAT_AVGPOOL, c, c))
+            else:
+                raise ValueError(op[0])
+        self._keep = params
+        self.in_ch, self.in_res, self.max_batch = in_ch, in_res, int(max_batch)
+        arr = (_lib.FeatOp * len(desc))(*desc)
+        nbytes = lib.la_feat_workspace_bytes(len(desc), arr, in_ch, in_res, self.max_batch)
+        assert nbytes > 0, 'invalid feature-net description'
+        self._workspace = torch.empty([nbytes], dtype=torch.uint8, device=self.device)
+        pp = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.la_feat_create(len(desc), arr, pp, len(params), in_ch, in_res, self.max_batch,
+                                          _lib.ptr(self._workspace), nbytes, _lib.stream_ptr(), C.byref(h)), 'la_feat_create')
+        self._h = h
+        self.num_features = lib.la_feat_num_features(h)
+        _lib.check(lib.la_feat_set_precision(h, PRECISIONS[precision]), 'la_feat_set_precision')
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            self._lib.la_feat_destroy(h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def forward(self, x):
+        _lib.require_gpu(x)
+        x = x.contiguous().float()
+        N = x.shape[0]
+        assert x.shape[1:] == (self.in_ch, self.in_res, self.in_res)
+        f = torch.empty([N, self.num_features], device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.la_feat_forward(self._h, _lib.ptr(x), N, _lib.ptr(f), _lib.stream_ptr()), 'la_feat_forward')
+        self._x = x
+        return f
+
+    def backward(self, gfeat):
+        gfeat = gfeat.contiguous().float()
+        gx = torch.empty_like(self._x)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.la_feat_backward(self._h, _lib.ptr(gfeat), _lib.ptr(gx), _lib.stream_ptr()), 'la_feat_backward')
+        return gx
+
+
+def vgg16_lpips_ops(state_dict, lins):
+    """Op list of the LPIPS VGG16 from torchvision-style names (`features.{0,2,5,7,10,12,14,17,19,21,24,26,28}.weight/bias`,
+    cf. augments/criteria/lpips/networks.py:87-97) and the five per-channel lin weights; taps after relu1_2, 2_2, 3_3, 4_3, 5_3."""
+    conv_ids = [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]
+    tap_after = {2: 0, 7: 1, 14: 2, 21: 3, 28: 4}
+    pool_after = {2, 7, 14, 21}
+    ops = []
+    for i in conv_ids:
+        ops.append(('conv', state_dict[f'features.{i}.weight'], state_dict[f'features.{i}.bias']))
+        if i in tap_after:
+            ops.append(('tap', lins[tap_after[i]]))
+        if i in pool_after:
+            ops.append(('maxpool',))
+    return ops

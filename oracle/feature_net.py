@@ -39,3 +39,57 @@ class TinyFeatureNet(nn.Module):
         f1 = F.relu(F.conv2d(x, self.w1, self.b1, padding=1))
         f2 = F.relu(F.conv2d(F.avg_pool2d(f1, 2), self.w2, self.b2, padding=1))
         return _lpips_pack([f1, f2], [self.lin1, self.lin2])
+
+
+class VGG16Features(nn.Module):
+    """VGG16-shaped LPIPS feature net (13 conv3x3+ReLU, 4 max-pools, taps after relu1_2/2_2/3_3/4_3/5_3) with random
+    He-initialised weights and random positive lin weights.  `width` scales the channel counts (64 = the real VGG16)."""
+    CFG = [(1, 2), (2, 2), (4, 3), (8, 3), (8, 3)]      # (channel multiple, convs) per stage
+
+    def __init__(self, seed=7, width=64, in_ch=3):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.stages = []
+        c = in_ch
+        k = 0
+        for si, (mult, n) in enumerate(self.CFG):
+            convs = []
+            for _ in range(n):
+                co = mult * width
+                w = nn.Parameter(torch.randn([co, c, 3, 3], generator=g) * (2.0 / (c * 9)) ** 0.5, requires_grad=False)
+                b = nn.Parameter(torch.randn([co], generator=g) * 0.05, requires_grad=False)
+                self.register_parameter(f'w{k}', w)
+                self.register_parameter(f'b{k}', b)
+                convs.append((w, b))
+                c = co
+                k += 1
+            lin = nn.Parameter(torch.rand([c], generator=g) + 0.1, requires_grad=False)
+            self.register_parameter(f'lin{si}', lin)
+            self.stages.append((convs, lin))
+
+    def ops(self):
+        """The op list latentaugment_amd.synthesis.FeatureEngine consumes."""
+        out = []
+        for si, (convs, lin) in enumerate(self.stages):
+            for w, b in convs:
+                out.append(('conv', w, b))
+            out.append(('tap', lin))
+            if si + 1 < len(self.stages):
+                out.append(('maxpool',))
+        return out
+
+    def forward(self, x):
+        feats, lins = [], []
+        for si, (convs, lin) in enumerate(self.stages):
+            for w, b in convs:
+                x = F.relu(F.conv2d(x, w, b, padding=1))
+            feats.append(x)
+            lins.append(lin)
+            if si + 1 < len(self.stages):
+                x = F.max_pool2d(x, 2)
+        return _lpips_pack(feats, lins)
+
+
+def tiny_ops(net):
+    """Op list of TinyFeatureNet for latentaugment_amd.synthesis.FeatureEngine."""
+    return [('conv', net.w1, net.b1), ('tap', net.lin1), ('avgpool',), ('conv', net.w2, net.b2), ('tap', net.lin2)]
