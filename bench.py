@@ -50,6 +50,9 @@ def parse():
     p.add_argument('--precision', default='bf16x3', choices=['f32', 'bf16x3', 'bf16x2'],
                    help='contraction arithmetic: exact fp32 MFMA, or fp32 split into 3 / 2 bf16 terms on the bf16 MFMA')
     p.add_argument('--w-disc', type=float, default=0.0, help='discriminator criterion weight (BASELINE.md second run: 0.01)')
+    p.add_argument('--preset', default='B', choices=['B', 'E'],
+                   help="B: BASELINE.json configs[1] (the metric's config). E: configs[4] per-GPU shape -- config-e 256^2, all four "
+                        "criteria at the authors' weights (w_lpips 10, w_pix 0.1, w_latent 0.001, w_disc 0.01), Pelvis-scale banks")
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true', help='skip the HIP-event leg (used under rocprofv3)')
     p.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
@@ -58,11 +61,19 @@ def parse():
     return p.parse_args()
 
 
+def apply_preset(args):
+    args.w_pix, args.w_latent, args.w_lpips, args.M_w, args.M_x = 0.1, 0.001, 0.0, 1024, 256
+    if args.preset == 'E':
+        args.channel_base = 16384
+        args.w_lpips, args.w_disc, args.M_w, args.M_x = 10.0, 0.01, 6026, 1572     # backbone_latentaug.py:46-54, SURVEY 8d
+    return args
+
+
 def make_opt(args, local_rank):
     return types.SimpleNamespace(
         aug='latent', gpu_ids=[local_rank], gpu_ids_aug=str(local_rank), checkpoints_dir='/tmp', name='bench', phase='train',
         img_resolution=args.res, batch_size=args.batch, modalities_aug='A,B', opt_num_epochs=args.latent_steps, opt_lr=0.01,
-        truncation_psi=1.0, w_pix=0.1, w_lpips=0.0, w_latent=0.001, w_disc=args.w_disc, crop_size_aug=64,
+        truncation_psi=1.0, w_pix=args.w_pix, w_lpips=args.w_lpips, w_latent=args.w_latent, w_disc=args.w_disc, crop_size_aug=64,
         preprocess_aug='center_random_crop', soft_aug=False, alpha=1.0, verbose_log=False, rand_aug=False,
         lower_bound_clip=False, p_thres=0.0, init_w='inv', criterion_mode=args.criterion_mode, final_noise_mode='random',
         precision=args.precision)
@@ -103,7 +114,7 @@ def cpu_baseline(sd, meta, args):
 
 
 def main():
-    args = parse()
+    args = apply_preset(parse())
     import torch
     import torch.distributed as dist
 
@@ -129,7 +140,7 @@ def main():
 
     sd, meta = synthetic.make_generator_state_dict(img_resolution=args.res, img_channels=2, channel_base=args.channel_base,
                                                    seed=0)
-    W, X = synthetic.make_banks(meta['num_ws'], res=args.res, M_w=1024, M_x=256)
+    W, X = synthetic.make_banks(meta['num_ws'], res=args.res, M_w=args.M_w, M_x=args.M_x)
     data = synthetic.make_batch(args.batch, res=args.res, seed=2 + rank)
     w0 = synthetic.make_latents(args.batch, seed=1 + rank)
     codes = InMemoryLatentCodes({p: w0[i, 0].numpy() for i, p in enumerate(data['A_paths'])})
@@ -137,6 +148,12 @@ def main():
     # each rank owns its own B images (weak scaling); the plugin itself is run un-sharded per rank, the gather of the
     # whole job's output is done below with the same single collective the sharded plugin path uses
     opt.inject = dict(generator=sd, banks={'W': W, 'X': X}, latent_codes=codes, group=None)
+    if args.w_lpips > 0:
+        # VGG16-shaped feature net with random weights (the real vgg16.pt is a download); feature banks drawn on the device
+        opt.inject['feature_net'] = synthetic.make_vgg16_lpips_ops(seed=7)
+        F = synthetic.lpips_num_features(64)
+        gen = torch.Generator(device=dev).manual_seed(5)
+        opt.inject['banks']['fea'] = [torch.randn([args.M_x, F], device=dev, generator=gen) * (1.0 / F) ** 0.5 for _ in range(2)]
     if args.w_disc > 0:
         opt.inject['discriminator'] = synthetic.make_discriminator_state_dict(img_resolution=args.res, img_channels=2,
                                                                               channel_base=args.channel_base)
@@ -199,7 +216,7 @@ def main():
             pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
             if os.path.isfile(pmc):
                 pj = json.load(open(pmc))
-                if pj.get('precision') == args.precision and args.w_disc == 0:
+                if pj.get('precision') == args.precision and args.w_disc == 0 and args.preset == 'B':
                     roof['traffic'] = pj.get('bytes_per_launch')
                     roof['traffic_note'] = pj.get('note')
             roof['algorithmic_bytes_per_launch'] = by.value / max(n.value, 1)
@@ -217,13 +234,14 @@ def main():
                   'bf16x2': 'f32 (split-bf16x2 on bf16 MFMA, approximate)'}[args.precision], 'data': 'synthetic',
         'config': {'workload': f'SG2 config-{"f" if args.channel_base == 32768 else "e"} {args.res}x{args.res} 2-ch, '
                                f'random-init G, batch={args.batch}/GPU, {args.latent_steps} latent steps, '
-                               f'w_latent=0.001 w_pix=0.1 w_disc={args.w_disc:g} (M_w=1024, M_x=256, criterion_mode={args.criterion_mode}), '
+                               f'w_latent={args.w_latent:g} w_pix={args.w_pix:g} w_disc={args.w_disc:g} w_lpips={args.w_lpips:g} '
+                               f'(M_w={args.M_w}, M_x={args.M_x}, criterion_mode={args.criterion_mode}), '
                                f'contraction={args.precision}',
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}'},
     }
     if roof is not None:
         line['roofline'] = roof
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.preset == 'B' and args.w_disc == 0:
         line['cpu_baseline'] = cpu_baseline(sd, meta, args)
     if rank == 0:
         print(json.dumps(line), flush=True)

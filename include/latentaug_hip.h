@@ -118,7 +118,8 @@ int la_pack_conv_weights_bf16_f32(const float* w, void* out, int cout, int cin, 
 
 /* l2_loss_vectorized (augments/utils/util_latent_aug.py:315-361) on flattened rows: X [n][K], Y [m][K] ->
  * D [m][n] = |Y_m|^2 + |X_n|^2 - 2<Y_m,X_n> (compute_mean=False); mean_out (may be NULL) = sum(D)/(m*n)/K.
- * workspace: m + n floats. */
+ * workspace: la_pairwise_l2_workspace_floats(n, m) floats (K-slice partials of the bank scan). */
+long la_pairwise_l2_workspace_floats(int n, long m);
 int la_pairwise_l2_f32(const float* X, int n, const float* Y, long m, long K, float* D, float* mean_out,
                        float* workspace, la_stream_t stream);
 

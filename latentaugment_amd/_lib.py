@@ -54,6 +54,7 @@ SIGNATURES = {
     'la_modconv_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
     'la_modconv_bf16_pack_bytes': (_Z, [_I, _I, _I, _I]),
     'la_pack_conv_weights_bf16_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    'la_pairwise_l2_workspace_floats': (_L, [_I, _L]),
     'la_pairwise_l2_f32': (_I, [_P, _I, _P, _L, _L, _P, _P, _P, _P]),
     'la_center_crop_f32': (_I, [_P, _P, _L, _I, _I, _I, _P]),
     'la_adam_step_f32': (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _P]),

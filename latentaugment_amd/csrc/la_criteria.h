@@ -5,7 +5,11 @@
 int la_bank_dot(const float* Y, long m, long K, const float* X, int n, long ldx, long xmod, float* yx, float* yy,
                 hipStream_t stream);
 int la_bank_colsum(const float* Y, long m, long K, float* colsum, hipStream_t stream);
-// out[0] (+)= scale * sum_{m,n} (|Y_m|^2 + |X_n|^2 - 2<Y_m,X_n>); workspaces: yx_ws [m*n], yy_ws [m], xx_ws [n]
+// scratch sizes of the bank kernels (floats): yx 5*m*n, yy 5*m, xx 33*n
+#define LA_YX_FLOATS(m, n) (5L * (m) * (n))
+#define LA_YY_FLOATS(m) (5L * (m))
+#define LA_XX_FLOATS(n) (33L * (n))
+// out[0] (+)= scale * sum_{m,n} (|Y_m|^2 + |X_n|^2 - 2<Y_m,X_n>); workspaces: yx_ws LA_YX_FLOATS, yy_ws LA_YY_FLOATS, xx_ws LA_XX_FLOATS
 int la_l2_mean_from_bank(const float* Y, long m, long K, const float* X, int n, long ldx, long xmod, float* yx_ws,
                          float* yy_ws, float* xx_ws, float scale, float* out, int accumulate, hipStream_t stream);
 int la_pix_grad(const float* img, const float* colsum, float* g, int B, int imgc, int R, int cc, int off, float coef2,
@@ -15,6 +19,7 @@ int la_latent_combine(const float* dws, const float* w, const float* colsumW, fl
 int la_broadcast_mix(const float* w_opt, const float* w0, float* w_aug, int B, int num_ws, int wdim, float alpha,
                      int soft, hipStream_t stream);
 extern "C" {
+long la_pairwise_l2_workspace_floats(int n, long m);
 int la_pairwise_l2_f32(const float* X, int n, const float* Y, long m, long K, float* D, float* mean_out,
                        float* workspace, hipStream_t stream);
 int la_center_crop_f32(const float* src, float* dst, long planes, int R, int cc, int off, hipStream_t stream);

@@ -6,49 +6,111 @@
 
 #define NCH 8   // query rows handled per pass over the bank
 
-// yx[m][n] = <Y_m, X_n>,  yy[m] = |Y_m|^2.   One workgroup per bank row; X element (n,k) = X[n*ldx + k % xmod].
-__global__ __launch_bounds__(256) void la_bank_dot_kernel(const float* __restrict__ Y, long K, const float* __restrict__ X,
-                                                         int n, long ldx, long xmod, float* __restrict__ yx,
-                                                         float* __restrict__ yy) {
+// yx[m][n] = <Y_m, X_n>,  yy[m] = |Y_m|^2  -- skinny GEMM, HBM-bound on the bank.
+// Block = RB bank rows x one K slice; the NCH query rows are re-used across the RB bank rows from registers (one X load
+// feeds RB FMAs), each thread keeps RB x NCH accumulators, K slices are summed by la_bank_dot_finish_kernel in a fixed
+// order (deterministic).  X element (n, k) = X[n*ldx + k % xmod].  VEC = 4 needs K % 4 == 0 and 16-byte aligned rows.
+#define RB 8
+#define KSPLIT 4
+template <int VEC>
+__global__ __launch_bounds__(256) void la_bank_dot_kernel(const float* __restrict__ Y, long m, long K, const float* __restrict__ X,
+                                                         int n, int n0, long ldx, long xmod, float* __restrict__ part_yx,
+                                                         float* __restrict__ part_yy) {
     __shared__ float red[4];
-    const long m = blockIdx.x;
-    const float* yrow = Y + m * K;
-    for (int n0 = 0; n0 < n; n0 += NCH) {
-        float acc[NCH], sq = 0.f;
+    const long r0 = (long)blockIdx.x * RB;
+    const int ks = blockIdx.y;
+    const long kper = ((K + KSPLIT - 1) / KSPLIT + VEC * 256 - 1) / (VEC * 256) * (VEC * 256);
+    const long kbeg = ks * kper, kend = (kbeg + kper < K) ? kbeg + kper : K;
+    float acc[RB][NCH], sq[RB];
 #pragma unroll
-        for (int q = 0; q < NCH; ++q) acc[q] = 0.f;
-        for (long k = threadIdx.x; k < K; k += blockDim.x) {
-            const float yv = yrow[k];
-            sq += yv * yv;
-            const long kx = (xmod > 0) ? k % xmod : k;
+    for (int r = 0; r < RB; ++r) { sq[r] = 0.f;
 #pragma unroll
-            for (int q = 0; q < NCH; ++q)
-                if (n0 + q < n) acc[q] += yv * X[(long)(n0 + q) * ldx + kx];
-        }
+        for (int q = 0; q < NCH; ++q) acc[r][q] = 0.f; }
+    for (long k = kbeg + (long)threadIdx.x * VEC; k < kend; k += 256 * VEC) {
+        float xv[NCH][VEC];
+        const long kx = (xmod > 0) ? k % xmod : k;
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
-            const float t = la_block_sum_256(acc[q], red);
-            if (threadIdx.x == 0 && n0 + q < n) yx[m * n + n0 + q] = t;
+            if (n0 + q < n) {
+                if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(X + (long)(n0 + q) * ldx + kx); xv[q][0] = t.x; xv[q][1] = t.y; xv[q][2] = t.z; xv[q][3] = t.w; }
+                else xv[q][0] = X[(long)(n0 + q) * ldx + kx];
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) xv[q][e] = 0.f;
+            }
         }
-        if (n0 == 0 && yy) {
-            const float t = la_block_sum_256(sq, red);
-            if (threadIdx.x == 0) yy[m] = t;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if (r0 + r >= m) break;
+            float yv[VEC];
+            if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(Y + (r0 + r) * K + k); yv[0] = t.x; yv[1] = t.y; yv[2] = t.z; yv[3] = t.w; }
+            else yv[0] = Y[(r0 + r) * K + k];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                sq[r] += yv[e] * yv[e];
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) acc[r][q] += yv[e] * xv[q][e];
+            }
+        }
+    }
+    for (int r = 0; r < RB; ++r) {
+        if (r0 + r >= m) break;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const float t = la_block_sum_256(acc[r][q], red);
+            if (threadIdx.x == 0 && n0 + q < n) part_yx[((long)ks * m + r0 + r) * n + n0 + q] = t;
+        }
+        if (n0 == 0 && part_yy) {
+            const float t = la_block_sum_256(sq[r], red);
+            if (threadIdx.x == 0) part_yy[(long)ks * m + r0 + r] = t;
         }
     }
 }
 
-// xx[n] = |X_n|^2 (K elements, with the same modulo addressing)
+__global__ void la_bank_dot_finish_kernel(const float* __restrict__ part_yx, const float* __restrict__ part_yy,
+                                          float* __restrict__ yx, float* __restrict__ yy, long m, int n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m * n) {
+        float v = 0.f;
+        for (int k = 0; k < KSPLIT; ++k) v += part_yx[(long)k * m * n + i];
+        yx[i] = v;
+    }
+    if (yy && i < m) {
+        float v = 0.f;
+        for (int k = 0; k < KSPLIT; ++k) v += part_yy[(long)k * m + i];
+        yy[i] = v;
+    }
+}
+
+// xx[n] = |X_n|^2 (K elements, with the same modulo addressing); 32 slices per row, then a fixed-order sum
+#define SQ_SLICES 32
 __global__ __launch_bounds__(256) void la_rows_sqnorm_kernel(const float* __restrict__ X, long K, long ldx, long xmod,
-                                                            float* __restrict__ xx) {
+                                                            float* __restrict__ part) {
     __shared__ float red[4];
     const long n = blockIdx.x;
+    const long per = (K + SQ_SLICES - 1) / SQ_SLICES;
+    const long k0 = blockIdx.y * per, k1 = (k0 + per < K) ? k0 + per : K;
     float sq = 0.f;
-    for (long k = threadIdx.x; k < K; k += blockDim.x) {
+    for (long k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
         const float v = X[n * ldx + ((xmod > 0) ? k % xmod : k)];
         sq += v * v;
     }
     const float t = la_block_sum_256(sq, red);
-    if (threadIdx.x == 0) xx[n] = t;
+    if (threadIdx.x == 0) part[n * SQ_SLICES + blockIdx.y] = t;
+}
+__global__ void la_rows_sqnorm_finish_kernel(const float* __restrict__ part, float* __restrict__ xx, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;
+    for (int k = 0; k < SQ_SLICES; ++k) v += part[(long)i * SQ_SLICES + k];
+    xx[i] = v;
+}
+
+// xx_ws: n * (SQ_SLICES + 1) floats; result in xx_ws[0 .. n)
+static int rows_sqnorm(const float* X, long K, long ldx, long xmod, float* xx_ws, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(la_rows_sqnorm_kernel, dim3(n, SQ_SLICES), dim3(256), 0, stream, X, K, ldx, xmod, xx_ws + n);
+    hipLaunchKernelGGL(la_rows_sqnorm_finish_kernel, dim3(la_cdiv(n, 256)), dim3(256), 0, stream, xx_ws + n, xx_ws, n);
+    return LA_OK;
 }
 
 // D[m][n] = yy[m] + xx[n] - 2 yx[m][n]   (in place over yx)
@@ -88,10 +150,19 @@ __global__ __launch_bounds__(256) void la_bank_colsum_kernel(const float* __rest
     if (w == 0 && k < K) colsum[k] = (comb[0][kl] + comb[1][kl]) + (comb[2][kl] + comb[3][kl]);
 }
 
+// yx: (KSPLIT + 1) * m * n floats (result in the first m*n); yy (may be NULL): (KSPLIT + 1) * m floats
 int la_bank_dot(const float* Y, long m, long K, const float* X, int n, long ldx, long xmod, float* yx, float* yy,
                 hipStream_t stream) {
     LA_CHECK_ARG(Y && X && yx && m >= 1 && K >= 1 && n >= 1, "bank_dot: bad arguments");
-    hipLaunchKernelGGL(la_bank_dot_kernel, dim3((unsigned)m), dim3(256), 0, stream, Y, K, X, n, ldx, xmod, yx, yy);
+    float* pyx = yx + m * n;
+    float* pyy = yy ? yy + m : nullptr;
+    const bool vec = (K % 4 == 0) && (ldx % 4 == 0) && (xmod % 4 == 0) && (((size_t)Y | (size_t)X) & 15) == 0;
+    dim3 grid(la_cdiv(m, RB), KSPLIT);
+    for (int n0 = 0; n0 < n; n0 += NCH) {
+        if (vec) hipLaunchKernelGGL(la_bank_dot_kernel<4>, grid, dim3(256), 0, stream, Y, m, K, X, n, n0, ldx, xmod, pyx, pyy);
+        else hipLaunchKernelGGL(la_bank_dot_kernel<1>, grid, dim3(256), 0, stream, Y, m, K, X, n, n0, ldx, xmod, pyx, pyy);
+    }
+    hipLaunchKernelGGL(la_bank_dot_finish_kernel, dim3(la_cdiv(m * n > m ? m * n : m, 256)), dim3(256), 0, stream, pyx, pyy, yx, yy, m, n);
     LA_CHECK_LAUNCH();
     return LA_OK;
 }
@@ -107,7 +178,7 @@ int la_l2_mean_from_bank(const float* Y, long m, long K, const float* X, int n, 
                          float* yy_ws, float* xx_ws, float scale, float* out, int accumulate, hipStream_t stream) {
     int rc = la_bank_dot(Y, m, K, X, n, ldx, xmod, yx_ws, yy_ws, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(la_rows_sqnorm_kernel, dim3(n), dim3(256), 0, stream, X, K, ldx, xmod, xx_ws);
+    rows_sqnorm(X, K, ldx, xmod, xx_ws, n, stream);
     hipLaunchKernelGGL(la_l2_finish_kernel, dim3(la_cdiv(m * n, 256)), dim3(256), 0, stream, yx_ws, yy_ws, xx_ws, m, n);
     hipLaunchKernelGGL(la_sum_scale_kernel, dim3(1), dim3(256), 0, stream, yx_ws, m * n, scale, out, accumulate);
     LA_CHECK_LAUNCH();
@@ -115,16 +186,23 @@ int la_l2_mean_from_bank(const float* Y, long m, long K, const float* X, int n, 
 }
 
 // Public op: the reference's l2_loss_vectorized on flattened rows.  D [m][n] always written; mean optional.
+extern "C" long la_pairwise_l2_workspace_floats(int n, long m) {
+    return (KSPLIT + 1) * m * n + (KSPLIT + 1) * m + (long)(SQ_SLICES + 1) * n;
+}
+
 extern "C" int la_pairwise_l2_f32(const float* X, int n, const float* Y, long m, long K, float* D, float* mean_out,
-                                  float* workspace /* m + n floats */, hipStream_t stream) {
+                                  float* workspace /* la_pairwise_l2_workspace_floats(n, m) */, hipStream_t stream) {
     LA_CHECK_ARG(X && Y && D && workspace, "pairwise_l2: null pointer");
     LA_CHECK_ARG(n >= 1 && m >= 1 && K >= 1, "pairwise_l2: empty input");
-    float* yy = workspace;
-    float* xx = workspace + m;
-    int rc = la_bank_dot(Y, m, K, X, n, K, 0, D, yy, stream);
+    // workspace: yx (KSPLIT+1)*m*n | yy (KSPLIT+1)*m | xx (SQ_SLICES+1)*n
+    float* yx = workspace;
+    float* yy = yx + (KSPLIT + 1) * m * n;
+    float* xx = yy + (KSPLIT + 1) * m;
+    int rc = la_bank_dot(Y, m, K, X, n, K, 0, yx, yy, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(la_rows_sqnorm_kernel, dim3(n), dim3(256), 0, stream, X, K, K, (long)0, xx);
-    hipLaunchKernelGGL(la_l2_finish_kernel, dim3(la_cdiv(m * n, 256)), dim3(256), 0, stream, D, yy, xx, m, n);
+    rows_sqnorm(X, K, K, 0, xx, n, stream);
+    hipLaunchKernelGGL(la_l2_finish_kernel, dim3(la_cdiv(m * n, 256)), dim3(256), 0, stream, yx, yy, xx, m, n);
+    LA_HIP(hipMemcpyAsync(D, yx, sizeof(float) * m * n, hipMemcpyDeviceToDevice, stream));
     if (mean_out)
         hipLaunchKernelGGL(la_sum_scale_kernel, dim3(1), dim3(256), 0, stream, D, m * n,
                            1.0f / ((float)m * (float)n) / (float)K, mean_out, 0);

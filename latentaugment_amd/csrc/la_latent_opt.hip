@@ -40,7 +40,7 @@ static size_t carve(la_latent_opt* h, char* base) {
     h->colsumW = take((size_t)h->num_ws * wd);
     h->colsumX = take((size_t)h->imgc * cc2);
     const size_t mm = (size_t)(h->Mw > h->Mx ? h->Mw : h->Mx);
-    h->yx = take((mm ? mm : 1) * B); h->yy = take(mm ? mm : 1); h->xx = take(B);
+    h->yx = take(LA_YX_FLOATS(mm ? mm : 1, B)); h->yy = take(LA_YY_FLOATS(mm ? mm : 1)); h->xx = take(LA_XX_FLOATS(B));
     h->xc = take(B * h->imgc * cc2);
     h->losses = take((size_t)(h->cfg.steps > 0 ? h->cfg.steps : 1) * 4);
     return off;
@@ -94,7 +94,7 @@ extern "C" size_t la_latent_opt_lpips_workspace_bytes(int img_channels, int F, i
     off += al(n * 3 * S * S) * 2;          // xc, gxc
     off += al(n * F) * 2;                  // feat, gfeat
     off += al((size_t)img_channels * F);   // colsum
-    off += al((size_t)Mf * max_batch) + al((size_t)Mf) + al((size_t)max_batch);
+    off += al(LA_YX_FLOATS(Mf, max_batch)) + al(LA_YY_FLOATS(Mf)) + al(LA_XX_FLOATS(max_batch));
     return off;
 }
 
@@ -110,7 +110,7 @@ extern "C" int la_latent_opt_set_lpips(la_latent_opt* h, la_feat* f, const float
     h->l_xc = take(n * 3 * S * S); h->l_gxc = take(n * 3 * S * S);
     h->l_feat = take(n * F); h->l_gfeat = take(n * F);
     h->l_colsum = take((size_t)h->imgc * F);
-    h->l_yx = take((size_t)Mf * h->maxB); h->l_yy = take((size_t)Mf); h->l_xx = take((size_t)h->maxB);
+    h->l_yx = take(LA_YX_FLOATS(Mf, h->maxB)); h->l_yy = take(LA_YY_FLOATS(Mf)); h->l_xx = take(LA_XX_FLOATS(h->maxB));
     h->l_colsum_valid = 0;
     return LA_OK;
 }

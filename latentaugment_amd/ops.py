@@ -188,7 +188,7 @@ def l2_loss_vectorized(X, Y, compute_mean=True):
     assert Yf.shape[1] == K
     D = torch.empty([m, n], device=X.device, dtype=torch.float32)
     mean = torch.empty([1], device=X.device, dtype=torch.float32)
-    ws = torch.empty([m + n], device=X.device, dtype=torch.float32)
+    ws = torch.empty([lib.la_pairwise_l2_workspace_floats(n, m)], device=X.device, dtype=torch.float32)
     _lib.check(lib.la_pairwise_l2_f32(_lib.ptr(Xf), n, _lib.ptr(Yf), m, K, _lib.ptr(D), _lib.ptr(mean), _lib.ptr(ws),
                                       _lib.stream_ptr()), 'pairwise_l2')
     return mean[0] if compute_mean else D

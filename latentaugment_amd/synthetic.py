@@ -100,3 +100,27 @@ def make_discriminator_state_dict(img_resolution=256, img_channels=2, channel_ba
     sd['b4.out.weight'] = torch.randn([1, ch[4]], generator=g)
     sd['b4.out.bias'] = torch.zeros([1])
     return sd
+
+
+def make_vgg16_lpips_ops(seed=7, width=64, in_ch=3):
+    """Op list (for synthesis.FeatureEngine) of a VGG16-shaped LPIPS net with random He-initialised weights: 13 x
+    conv3x3+ReLU, 4 x max-pool, taps after relu1_2 / 2_2 / 3_3 / 4_3 / 5_3 with random positive lin weights.  Stand-in for
+    NVIDIA's vgg16.pt (util_latent_aug.py:36), which cannot be downloaded offline."""
+    g = torch.Generator().manual_seed(seed)
+    ops = []
+    c = in_ch
+    cfg = [(1, 2), (2, 2), (4, 3), (8, 3), (8, 3)]
+    for si, (mult, n) in enumerate(cfg):
+        for _ in range(n):
+            co = mult * width
+            ops.append(('conv', torch.randn([co, c, 3, 3], generator=g) * (2.0 / (c * 9)) ** 0.5,
+                        torch.randn([co], generator=g) * 0.05))
+            c = co
+        ops.append(('tap', torch.rand([c], generator=g) + 0.1))
+        if si + 1 < len(cfg):
+            ops.append(('maxpool',))
+    return ops
+
+
+def lpips_num_features(crop=64, width=64):
+    return sum(m * width * (crop >> i) ** 2 for i, (m, _) in enumerate([(1, 2), (2, 2), (4, 3), (8, 3), (8, 3)]))
