@@ -113,6 +113,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime: import it FIRST so that liblatentaug_hip.so binds to the runtime that owns torch's
+    # streams and allocations (loading ours first leaves two runtimes in the process and HIP calls fail with
+    # "no ROCm-capable device is detected")
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise LatentAugHipError(
             f'{LIB_PATH} not found: build it with `make -C latentaugment_amd/csrc` (or __graft_entry__.build()). '

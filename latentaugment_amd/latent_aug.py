@@ -52,11 +52,14 @@ def gather_shards(local, per, batch, group=None):
     """ONE all_gather of equally padded shards -> the full batch on every rank (the reference gathers to gpu_ids[0])."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    pad = torch.zeros([per] + list(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dev = local.device
+    # RCCL ('nccl') gathers device buffers directly over xGMI; a gloo group (CPU rehearsal / tests) is staged through host
+    stage = dev.type == 'cuda' and dist.get_backend(group) == 'gloo'
+    pad = torch.zeros([per] + list(local.shape[1:]), dtype=local.dtype, device='cpu' if stage else dev)
     pad[:local.shape[0]] = local
-    out = torch.empty([world * per] + list(local.shape[1:]), dtype=local.dtype, device=local.device)
+    out = torch.empty([world * per] + list(local.shape[1:]), dtype=local.dtype, device=pad.device)
     dist.all_gather_into_tensor(out, pad, group=group)
-    return out[:batch]
+    return out[:batch].to(dev)
 
 
 class InMemoryLatentCodes:
