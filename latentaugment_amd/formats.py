@@ -154,10 +154,14 @@ class DatasetStats:
         return obj
 
 
-def compute_stats(dataset, manifold, cache_dir, cache_tag='', step=10, max_items=100000):
-    """util_latent_aug.py:503-563 for the 'latent' and 'img' manifolds (feature manifolds need the LPIPS net)."""
-    if manifold not in ('latent', 'img'):
-        raise NotImplementedError(f"manifold {manifold!r}: only 'latent' and 'img' banks are built on this path")
+def compute_stats(dataset, manifold, cache_dir, cache_tag='', step=10, max_items=100000, feature_fn=None):
+    """util_latent_aug.py:503-563.  'latent' / 'img' banks, and 'features_jit' (the TorchScript-LPIPS bank, :565-580) when
+    `feature_fn(x [1,C,R,R] float32 raw image) -> [1,F]` is given (it crops one modality, repeats it to 3 channels and
+    runs the feature net; see LatentAug._lpips_bank_feature_fn)."""
+    if manifold not in ('latent', 'img', 'features_jit'):
+        raise NotImplementedError(f"manifold {manifold!r}: only 'latent', 'img' and 'features_jit' banks are built on this path")
+    if manifold == 'features_jit' and feature_fn is None:
+        raise ValueError("manifold 'features_jit' needs feature_fn")
     num_items = len(dataset) if max_items is None else min(len(dataset), max_items)
     os.makedirs(cache_dir, exist_ok=True)
     tag = f'{manifold}-step_{step}-maxitems_{num_items}'
@@ -172,6 +176,11 @@ def compute_stats(dataset, manifold, cache_dir, cache_tag='', step=10, max_items
         x = np.asarray(x, dtype=np.float32)[None]          # the reference iterates a batch-size-1 DataLoader
         if manifold == 'img':
             x = x / 127.5 - 1                              # synthetic images live in [-1, 1]  (:544)
+        elif manifold == 'features_jit':
+            stem = os.path.splitext(os.path.basename(fname))[0]
+            if stem[-5:] not in stats.schedule:            # do not run the net on slices the schedule drops anyway
+                continue
+            x = np.asarray(feature_fn(x), dtype=np.float32)
         if stats.append(x, fname) < 0:
             break
     stats.save(cache_file)

@@ -198,6 +198,10 @@ class LatentAug:
             imgc = self.engine.img_channels
             self.feat = FeatureEngine(feature_net, self.device, in_res=self.crop_size, max_batch=imgc * max_local,
                                       precision=self.precision)
+            if 'fea' not in banks:
+                if not (getattr(opt, 'interim_dir', None) and getattr(opt, 'dataset_aug', None)):
+                    raise _lib.LatentAugHipError("w_lpips > 0 needs banks['fea'] or the interim image zip to build them from")
+                banks['fea'] = self._build_feature_banks(opt)
             fea = banks['fea']
             assert len(fea) == imgc
             self.Fbank = torch.stack([t.to(device=self.device, dtype=torch.float32) for t in fea]).contiguous()   # [C][Mf][F]
@@ -208,6 +212,31 @@ class LatentAug:
             self._lpips_ws = torch.empty([nb], dtype=torch.uint8, device=self.device)
             _lib.check(lib.la_latent_opt_set_lpips(h, self.feat.handle, _lib.ptr(self.Fbank), Mf, self.crop_size, float(scale),
                                                    float(shift), _lib.ptr(self._lpips_ws), nb), 'la_latent_opt_set_lpips')
+
+    def _build_feature_banks(self, opt):
+        """fea_<mode> banks (reference :160-171 / extract_features_mode_torchscript :565-580): per real image and modality,
+        a crop_size_aug^2 crop at a freshly drawn random position, repeated to 3 channels, through the feature net.
+        `opt.lpips_bank_range`: 'unit' (default) feeds x/127.5-1, consistent with the synthesised images; 'raw' reproduces
+        the reference's 0..255 input (SURVEY 3.4 defect f)."""
+        from . import formats
+        root = os.path.join(opt.interim_dir, opt.dataset_aug)
+        ds = formats.ImgDataset(os.path.join(root, opt.dataset_name_aug + '.zip'), split=self.phase, modalities=self.modalities,
+                                resolution=self.res)
+        raw = getattr(opt, 'lpips_bank_range', 'unit') == 'raw'
+        scale, shift = getattr(opt, 'lpips_preproc', (1.0, 0.0))
+        out = []
+        for mode_id, mode in enumerate(self.modalities):
+            def feature_fn(x, mode_id=mode_id):
+                t = torch.from_numpy(x[:, mode_id:mode_id + 1]).to(self.device)
+                if not raw:
+                    t = t / 127.5 - 1
+                ax, ay = self.crop_window(get_params(self.res, self.crop_size, self.preprocess)['crop_pos'])
+                t = t[:, :, ay:ay + self.crop_size, ax:ax + self.crop_size].repeat(1, 3, 1, 1) * scale + shift   # plumbing
+                return self.feat.forward(t.contiguous()).cpu().numpy()
+            st = formats.compute_stats(ds, 'features_jit', os.path.join(root, 'cache_dir'), cache_tag=f'{mode}-{self.crop_size}',
+                                       step=opt.step_img, feature_fn=feature_fn)
+            out.append(st.get_all_torch())
+        return out
 
     def __del__(self):
         h = getattr(self, '_h', None)
