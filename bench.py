@@ -32,6 +32,8 @@ CONTRACTION = {
     'f32': dict(peak=MFMA_F32_PEAK_TFLOPS, kernel='la_conv_igemm_kernel (fp32 MFMA 32x32x2, exact fp32)', mfma_per_product=1),
     'bf16x3': dict(peak=MFMA_BF16_PEAK_TFLOPS / 6, kernel='la_conv_bf16_kernel<NTERM=3> (fp32 split into 3 bf16 terms, 6 bf16 '
                    'MFMA 32x32x16 per product, fp32 accumulate; fp32-class error)', mfma_per_product=6),
+    'f16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_kernel<FMT_F16X2> (fp32 scaled by powers of two and split into '
+                  '2 fp16 terms, 3 fp16 MFMA 32x32x16 per product, fp32 accumulate; fp32-class error)', mfma_per_product=3),
     'bf16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_kernel<NTERM=2> (2 bf16 terms, 3 bf16 MFMA per product; '
                    'approximate mode)', mfma_per_product=3),
 }
@@ -47,7 +49,7 @@ def parse():
     p.add_argument('--res', type=int, default=256)
     p.add_argument('--channel-base', type=int, default=32768, help='32768 = config-f, 16384 = config-e')
     p.add_argument('--criterion-mode', default='gemm', choices=['gemm', 'collapsed'])
-    p.add_argument('--precision', default='bf16x3', choices=['f32', 'bf16x3', 'bf16x2'],
+    p.add_argument('--precision', default='bf16x3', choices=['f32', 'f16x2', 'bf16x3', 'bf16x2'],
                    help='contraction arithmetic: exact fp32 MFMA, or fp32 split into 3 / 2 bf16 terms on the bf16 MFMA')
     p.add_argument('--w-disc', type=float, default=0.0, help='discriminator criterion weight (BASELINE.md second run: 0.01)')
     p.add_argument('--preset', default='B', choices=['B', 'E'],
@@ -230,7 +232,8 @@ def main():
         'metric': 'augmented images/sec (256^2, 20 latent steps)', 'value': images / elapsed, 'unit': 'images/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': {'f32': 'f32', 'bf16x3': 'f32 (split-bf16x3 on bf16 MFMA, fp32 accumulate)',
+        'dtype': {'f32': 'f32', 'f16x2': 'f32 (scaled split-fp16x2 on fp16 MFMA, fp32 accumulate)',
+                  'bf16x3': 'f32 (split-bf16x3 on bf16 MFMA, fp32 accumulate)',
                   'bf16x2': 'f32 (split-bf16x2 on bf16 MFMA, approximate)'}[args.precision], 'data': 'synthetic',
         'config': {'workload': f'SG2 config-{"f" if args.channel_base == 32768 else "e"} {args.res}x{args.res} 2-ch, '
                                f'random-init G, batch={args.batch}/GPU, {args.latent_steps} latent steps, '

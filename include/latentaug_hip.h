@@ -104,10 +104,13 @@ size_t la_modconv_workspace_bytes(int B, int cin, int cout, int res, int up);
  *   0 LA_PREC_F32     exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
  *   1 LA_PREC_BF16X3  fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate (fp32-class error)
  *   2 LA_PREC_BF16X2  2 bf16 terms, 3 bf16 MFMAs (~4e-6 relative error per layer)
+ *   3 LA_PREC_F16X2   operands scaled by per-sample / per-layer powers of two and split into 2 fp16 terms, 3 fp16 MFMAs per
+ *                     product, fp32 accumulate (fp32-class error: 2 x 11 mantissa bits)
  * wq is produced by la_pack_conv_weights_bf16_f32 (transpose = 0 for the forward calls, 1 for the backward calls). */
 #define LA_PREC_F32 0
 #define LA_PREC_BF16X3 1
 #define LA_PREC_BF16X2 2
+#define LA_PREC_F16X2 3
 size_t la_modconv_bf16_pack_bytes(int cin, int cout, int transpose, int nterm);
 int la_pack_conv_weights_bf16_f32(const float* w, void* out, int cout, int cin, int ktaps, int transpose, int nterm,
                                   la_stream_t stream);

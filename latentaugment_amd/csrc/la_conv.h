@@ -18,6 +18,7 @@
 #define LA_PREC_F32 0
 #define LA_PREC_BF16X3 1
 #define LA_PREC_BF16X2 2
+#define LA_PREC_F16X2 3     // fp32 operands scaled by a power of two and split into 2 fp16 terms, 3 fp16 MFMAs per product
 
 struct LaConvArgs {
     const float* in;         // [B][C][Hin][Win]; in_bstride == 0 broadcasts one sample over the batch
@@ -60,8 +61,11 @@ struct LaConvArgs {
     const void* in_q;              // split-bf16 path: input already split by la_conv_presplit (8 B / element), or NULL
     // split-bf16 path (precision != LA_PREC_F32): weights pre-split by la_pack_conv_weights_bf16
     int precision;
-    const void* wgt_bf16;          // [term][slab][ceil(C/32)][M][32] bf16
-    long wgt_bf16_term_elems;
+    const void* wgt_bf16;          // split pack (la_conv_split_pack_bytes): 3 bf16 terms, 2 fp16 terms, fp16 weight scale
+    long wgt_bf16_term_elems;      // elements per term: slabs * ceil(C/32) * M * 32
+    // LA_PREC_F16X2: acc is divided by xscale[b] * wscale (exact powers of two) before the epilogue; set by la_conv_prepare_input
+    const float* acc_scale_x;      // [B]
+    const float* acc_scale_w;      // [1]
 };
 
 long la_conv_bf16_pack_elems(int M, int C, int ktaps);   // elements per term
@@ -71,11 +75,14 @@ void la_conv_bf16_dispatch(const LaConvArgs& as, int MTsel, dim3 grid, bool spli
 
 // scratch floats that let every <= 32x32 launch of a (B, M) problem use split-K: slices * B * M * G, G <= 1024
 long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx, int precision);
-// bytes of the pre-split copy of an input [B][C][Hin][Win] (split-bf16 path)
+// bytes of the pre-split copy of an input [B][C][Hin][Win] (split paths; sized for the larger, 8 B/element format)
 size_t la_conv_presplit_bytes(int B, int C, int Hin, int Win);
-// x (fp32, optionally * scale[b][c]) -> {bf16 hi | bf16 mid << 16, bf16 lo} per element
-int la_conv_presplit(const float* in, long in_bstride, const float* scale, int scale_stride, void* out, int B, int C,
-                     long HW, hipStream_t stream);
+// bytes of one weight pack serving every split precision
+size_t la_conv_split_pack_bytes(int M, int C, int ktaps);
+// If a.precision needs a pre-split input and a.in_q is not set: split a.in (* a.in_scale) into the head of a.ws, point
+// a.in_q / a.acc_scale_x at it and advance a.ws / a.ws_bytes past it.  Callers that launch several phases over one input
+// call this once.  bf16: {hi | mid << 16, lo} (8 B / element);  fp16: per-sample power-of-two scale, {hi | lo << 16} (4 B).
+int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream);
 
 // number of pixel tiles per sample for a launch (the ds_part leading dimension)
 int la_conv_tiles_per_sample(int Gy, int Gx);

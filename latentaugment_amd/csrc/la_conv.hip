@@ -272,21 +272,13 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
     const int nck = la_cdiv(a.C, bf ? 32 : KC);
     const int MTsel = a.M >= 128 ? 128 : 64;
     const int mtiles = la_cdiv(a.M, MTsel);
-    // carve the scratch: pre-split input first (split-bf16 only), split-K partials after it
-    size_t ws_off = 0;
-    if (bf && !a.in_q) {
-        const size_t qb = la_conv_presplit_bytes(a.B, a.C, a.Hin, a.Win);
-        LA_CHECK_ARG(a.ws && a.ws_bytes >= qb, "conv: split-bf16 precision needs a workspace (la_modconv_workspace_bytes)");
-        int rc = la_conv_presplit(a.in, a.in_bstride, a.in_scale, a.scale_stride, a.ws, a.B, a.C, (long)a.Hin * a.Win, stream);
-        if (rc) return rc;
-        as.in_q = a.ws;
-        ws_off = (qb + 255) & ~(size_t)255;
-    }
+    // scratch: pre-split input first (split precisions only), split-K partials after it
+    if (bf) { int rc = la_conv_prepare_input(as, stream); if (rc) return rc; }
     as.splitk_ws = nullptr;
     long splitk_floats = 0;
-    if (a.ws && a.ws_bytes > ws_off) {
-        as.splitk_ws = reinterpret_cast<float*>(static_cast<char*>(a.ws) + ws_off);
-        splitk_floats = (long)((a.ws_bytes - ws_off) / sizeof(float));
+    if (as.ws && as.ws_bytes >= sizeof(float)) {
+        as.splitk_ws = reinterpret_cast<float*>(as.ws);
+        splitk_floats = (long)(as.ws_bytes / sizeof(float));
     }
     if (as.splitk_ws && G <= SPLITK_MAX_G && nck >= 2) {
         const int ntiles_flat = la_cdiv((long)a.B * G, NT);

@@ -22,6 +22,19 @@
 #include "la_conv_device.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// FMT template parameter of the kernels below
+#define FMT_BF16X3 3
+#define FMT_BF16X2 2
+#define FMT_F16X2 16
+#define PRESPLIT_HDR 512       // bytes in front of a pre-split copy: [0,256) xscale[b] floats, [256,512) |x| max bit patterns
+
+template <bool F16>
+__device__ __forceinline__ f32x16 la_mma(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 #define KCB 32                 // channels per chunk
 #define ROWB 80                // LDS bytes per (row, 32 bf16) incl. 16 B pad
@@ -55,15 +68,81 @@ __global__ void la_pack_bf16_kernel(const float* __restrict__ w, __bf16* __restr
 
 long la_conv_bf16_pack_elems(int M, int C, int ktaps) { return (long)ktaps * la_cdiv(C, KCB) * M * KCB; }
 
+// pack layout: [3 bf16 terms][2 fp16 terms][pad to 16 B][wscale float]
+size_t la_conv_split_pack_bytes(int M, int C, int ktaps) {
+    return (size_t)5 * la_conv_bf16_pack_elems(M, C, ktaps) * 2 + 256;
+}
+__host__ __device__ static inline size_t pack_f16_offset(long term_elems) { return (size_t)3 * term_elems * 2; }
+static inline size_t pack_wscale_offset(long term_elems) { return ((size_t)5 * term_elems * 2 + 15) & ~(size_t)15; }
+
+// |w * scale| max over the tensor -> bit pattern via atomicMax (non-negative floats order like unsigned ints)
+__global__ void la_absmax_kernel(const float* __restrict__ w, long n, float scale, unsigned* __restrict__ amax_bits) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i] * scale));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax_bits, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+
+// power-of-two scale that brings a tensor's max magnitude to ~2^12 (fp16 max is 2^16; products accumulate in fp32)
+__device__ __forceinline__ float la_pow2_scale(float amax) {
+    if (!(amax > 0.f) || !isfinite(amax)) return 1.f;
+    int e;
+    frexpf(amax, &e);                    // amax = f * 2^e, f in [0.5, 1)
+    int s = 15 - e;                      // scaled max in [2^14, 2^15): fp16 never overflows, 3 more bits above the subnormals
+    s = s > 100 ? 100 : (s < -100 ? -100 : s);
+    return ldexpf(1.f, s);
+}
+
+__global__ void la_pack_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, const unsigned* __restrict__ amax_bits,
+                                   float* __restrict__ wscale_out, int cout, int cin, int ktaps, int transpose, float scale,
+                                   int m_pad) {
+    const int Mreal = transpose ? cin : cout, C = transpose ? cout : cin;
+    const int M = m_pad > Mreal ? m_pad : Mreal;
+    const int nck = (C + KCB - 1) / KCB;
+    const long per_term = (long)ktaps * nck * M * KCB;
+    const float ws = la_pow2_scale(__uint_as_float(*amax_bits));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *wscale_out = ws;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < per_term; idx += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % KCB);
+        const int m = (int)((idx / KCB) % M);
+        const int cc = (int)((idx / ((long)KCB * M)) % nck);
+        const int t = (int)(idx / ((long)KCB * M * nck));
+        const int c = cc * KCB + k;
+        float v = 0.f;
+        if (c < C && m < Mreal) {
+            const int o = transpose ? c : m, i = transpose ? m : c;
+            v = w[((long)o * cin + i) * ktaps + t] * scale * ws;
+        }
+        const _Float16 h = (_Float16)v;
+        out[idx] = h;
+        out[per_term + idx] = (_Float16)(v - (float)h);
+    }
+}
+
+// packs EVERY split precision into `out` (la_conv_split_pack_bytes): bf16 x3 terms, fp16 x2 terms (+ their weight scale)
 int la_pack_conv_weights_bf16(const float* w, void* out, int cout, int cin, int ktaps, int transpose, int nterm,
                               hipStream_t stream, float scale, int m_pad) {
     LA_CHECK_ARG(w && out && nterm >= 1 && nterm <= 3, "pack_bf16: bad args");
+    LA_CHECK_ARG(((size_t)out & 15) == 0, "pack_bf16: output must be 16-byte aligned");
     const int Mreal = transpose ? cin : cout;
     const long n = la_conv_bf16_pack_elems(m_pad > Mreal ? m_pad : Mreal, transpose ? cout : cin, ktaps);
     long blocks = la_cdiv(n, 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(la_pack_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, (__bf16*)out, cout, cin, ktaps,
-                       transpose, nterm, scale, m_pad);
+                       transpose, 3, scale, m_pad);
+    char* base = static_cast<char*>(out);
+    float* wscale = reinterpret_cast<float*>(base + pack_wscale_offset(n));
+    unsigned* amax = reinterpret_cast<unsigned*>(wscale) + 1;
+    LA_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned), stream));
+    const long nw = (long)cout * cin * ktaps;
+    long b2 = la_cdiv(nw, 256); if (b2 > 1024) b2 = 1024;
+    hipLaunchKernelGGL(la_absmax_kernel, dim3((unsigned)b2), dim3(256), 0, stream, w, nw, scale, amax);
+    hipLaunchKernelGGL(la_pack_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, (_Float16*)(base + pack_f16_offset(n)), amax,
+                       wscale, cout, cin, ktaps, transpose, scale, m_pad);
     LA_CHECK_LAUNCH();
     return LA_OK;
 }
@@ -99,23 +178,88 @@ __global__ __launch_bounds__(256) void la_presplit_kernel(const float* __restric
     }
 }
 
-size_t la_conv_presplit_bytes(int B, int C, int Hin, int Win) { return (size_t)B * C * Hin * Win * 8 + 16; }
+// fp16 path, pass 1: max |x * scale| of every (b, c) plane, one workgroup per plane (no atomics);
+// pass 2: each workgroup reduces its sample's plane maxima, derives the power-of-two scale and splits.
+__global__ __launch_bounds__(256) void la_plane_absmax_kernel(const float* __restrict__ in, long in_bstride,
+                                                             const float* __restrict__ scale, int scale_stride,
+                                                             float* __restrict__ pm, int C, long HW) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float sc = scale ? scale[(long)b * scale_stride + c] : 1.f;
+    const float* ip = in + (long)b * in_bstride + (long)c * HW;
+    float m = 0.f;
+    for (long p = threadIdx.x; p < HW; p += blockDim.x) m = fmaxf(m, fabsf(ip[p] * sc));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) pm[(long)b * C + c] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
 
-int la_conv_presplit(const float* in, long in_bstride, const float* scale, int scale_stride, void* out, int B, int C,
-                     long HW, hipStream_t stream) {
-    LA_CHECK_ARG(in && out && B >= 1 && C >= 1 && HW >= 1, "presplit: bad arguments");
-    LA_CHECK_ARG(((size_t)out & 15) == 0, "presplit: output must be 16-byte aligned");
+__global__ __launch_bounds__(256) void la_presplit_f16_kernel(const float* __restrict__ in, long in_bstride,
+                                                             const float* __restrict__ scale, int scale_stride,
+                                                             const float* __restrict__ pm, float* __restrict__ xscale,
+                                                             unsigned* __restrict__ out, int C, long HW) {
+    __shared__ float red[4];
+    const int c = blockIdx.y, b = blockIdx.z;
+    float m = 0.f;
+    for (int k = threadIdx.x; k < C; k += blockDim.x) m = fmaxf(m, pm[(long)b * C + k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const float xs = la_pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (blockIdx.x == 0 && c == 0 && threadIdx.x == 0) xscale[b] = xs;
+    const float sc = (scale ? scale[(long)b * scale_stride + c] : 1.f);
+    const float* ip = in + (long)b * in_bstride + (long)c * HW;
+    unsigned* op = out + ((long)b * C + c) * HW;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+        const float v = ip[p] * sc * xs;
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = (_Float16)(v - (float)h);
+        op[p] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+    }
+}
+
+static inline size_t presplit_hdr_bytes(int B, int C) { return (PRESPLIT_HDR + (size_t)B * C * 4 + 255) & ~(size_t)255; }
+size_t la_conv_presplit_bytes(int B, int C, int Hin, int Win) { return (size_t)B * C * Hin * Win * 8 + 16 + presplit_hdr_bytes(B, C); }
+
+int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
+    if (a.precision == LA_PREC_F32 || a.in_q) return LA_OK;
+    const long HW = (long)a.Hin * a.Win;
+    const size_t qb = la_conv_presplit_bytes(a.B, a.C, a.Hin, a.Win);
+    LA_CHECK_ARG(a.ws && a.ws_bytes >= qb, "conv: split precisions need a workspace (la_modconv_workspace_bytes)");
+    LA_CHECK_ARG(((size_t)a.ws & 15) == 0, "conv: workspace must be 16-byte aligned");
+    LA_CHECK_ARG(a.B <= 64, "conv: split precisions support at most 64 samples per launch");
+    char* base = static_cast<char*>(a.ws);
+    float* xscale = reinterpret_cast<float*>(base);
+    float* pm = reinterpret_cast<float*>(base + PRESPLIT_HDR);       // per-plane maxima [B][C]
+    void* q = base + presplit_hdr_bytes(a.B, a.C);
     int gx = la_cdiv(HW, 512);
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(la_presplit_kernel, dim3(gx, C, B), dim3(256), 0, stream, in, in_bstride, scale, scale_stride,
-                       (uint2*)out, C, HW);
+    if (a.precision == LA_PREC_F16X2) {
+        hipLaunchKernelGGL(la_plane_absmax_kernel, dim3(a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
+                           a.scale_stride, pm, a.C, HW);
+        hipLaunchKernelGGL(la_presplit_f16_kernel, dim3(gx, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
+                           a.scale_stride, pm, xscale, (unsigned*)q, a.C, HW);
+        a.acc_scale_x = xscale;
+    } else {
+        hipLaunchKernelGGL(la_presplit_kernel, dim3(gx, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
+                           a.scale_stride, (uint2*)q, a.C, HW);
+    }
     LA_CHECK_LAUNCH();
+    a.in_q = q;
+    const size_t off = (qb + 255) & ~(size_t)255;
+    a.ws = a.ws_bytes > off ? base + off : nullptr;
+    a.ws_bytes = a.ws_bytes > off ? a.ws_bytes - off : 0;
     return LA_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------
-template <int MT, bool SPLIT, int NTERM>
+template <int MT, bool SPLIT, int FMT>
 __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
+    constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
+    constexpr bool F16 = FMT == FMT_F16X2;
     constexpr int TM = MT / 64;
     constexpr int A_U = (MT * 4) / 256;            // 16-byte units of one term's A slab per thread (2 for MT=128, 1 for 64)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -155,9 +299,10 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
     }
     const int ci_beg = ck_beg * a.ntaps, ci_end = ck_end * a.ntaps;
     const long term_elems = a.wgt_bf16_term_elems;    // elements per term in the packed weights
-    const __bf16* wbase = reinterpret_cast<const __bf16*>(a.wgt_bf16);
+    const __bf16* wbase = reinterpret_cast<const __bf16*>(static_cast<const char*>(a.wgt_bf16) + (F16 ? pack_f16_offset(term_elems) : 0));
 
     const uint2* inq_b = reinterpret_cast<const uint2*>(a.in_q) + (long)b_l * a.C * HWin;
+    const unsigned* inq16_b = reinterpret_cast<const unsigned*>(a.in_q) + (long)b_l * a.C * HWin;
     uint2 breg[16];
     uint4 areg[NTERM][A_U];
 
@@ -172,7 +317,10 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
         for (int j = 0; j < 16; ++j) {
             const int c = c0 + j;
             uint2 v = make_uint2(0u, 0u);
-            if (ok && c < a.C) v = inq_b[(long)c * HWin + off];
+            if (ok && c < a.C) {
+                if (F16) v.x = inq16_b[(long)c * HWin + off];
+                else v = inq_b[(long)c * HWin + off];
+            }
             breg[j] = v;
         }
         // A: contiguous [M][32] bf16 slab of (tap slab, channel chunk); rows m0 .. m0+MT
@@ -242,15 +390,29 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     // smallest products first, so they are not swamped by the leading term inside the accumulator
-                    if (NTERM == 3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);   // lh
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);   // hl
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);   // mm
+                    if constexpr (NTERM == 3) {
+                        acc[i][j] = la_mma<F16>(af[2][i], bf[0][j], acc[i][j]);   // lh
+                        acc[i][j] = la_mma<F16>(af[0][i], bf[2][j], acc[i][j]);   // hl
+                        acc[i][j] = la_mma<F16>(af[1][i], bf[1][j], acc[i][j]);   // mm
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);   // mh
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);   // hm
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);   // hh
+                    acc[i][j] = la_mma<F16>(af[1][i], bf[0][j], acc[i][j]);   // mh
+                    acc[i][j] = la_mma<F16>(af[0][i], bf[1][j], acc[i][j]);   // hm
+                    acc[i][j] = la_mma<F16>(af[0][i], bf[0][j], acc[i][j]);   // hh
                 }
+        }
+    }
+    if (F16) {
+        // undo the power-of-two operand scales (exact)
+        const float iw = 1.f / a.acc_scale_w[0];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int bb = blockIdx.z;
+            if (SPLIT) { const int nidx = ntile * NT + wn * 64 + j * 32 + l31; bb = nidx < Ntot ? nidx / G : 0; }
+            const float inv = iw / a.acc_scale_x[bb];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
         }
     }
     __syncthreads();     // LDS is reused by the epilogue's reduction scratch
@@ -265,8 +427,10 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
 // = 79.7 KB (x3) -> two workgroups per CU.
 #define HALO_W 34
 #define HALO_PX (6 * HALO_W)
-template <int MT, int NTERM>
+template <int MT, int FMT>
 __global__ __launch_bounds__(256) void la_conv_bf16_halo_kernel(LaConvArgs a) {
+    constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
+    constexpr bool F16 = FMT == FMT_F16X2;
     constexpr int TM = MT / 64;
     constexpr int A_U = (MT * 4) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -287,9 +451,10 @@ __global__ __launch_bounds__(256) void la_conv_bf16_halo_kernel(LaConvArgs a) {
     const int y0 = tyb * 4 - 1, x0 = txb * 32 - 1;              // grid coordinates of halo pixel (0, 0)
     const long HWin = (long)a.Hin * a.Win;
     const uint2* inq_b = reinterpret_cast<const uint2*>(a.in_q) + (long)b * a.C * HWin;
+    const unsigned* inq16_b = reinterpret_cast<const unsigned*>(a.in_q) + (long)b * a.C * HWin;
     const int nck = (a.C + KCB - 1) / KCB;
     const long term_elems = a.wgt_bf16_term_elems;
-    const __bf16* wbase = reinterpret_cast<const __bf16*>(a.wgt_bf16);
+    const __bf16* wbase = reinterpret_cast<const __bf16*>(static_cast<const char*>(a.wgt_bf16) + (F16 ? pack_f16_offset(term_elems) : 0));
 
     uint4 areg[NTERM][A_U];
     auto prefetch_a = [&](int cc, int t) {
@@ -326,7 +491,10 @@ __global__ __launch_bounds__(256) void la_conv_bf16_halo_kernel(LaConvArgs a) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 uint2 v = make_uint2(0u, 0u);
-                if (ok && c0 + j < a.C) v = inq_b[(long)(c0 + j) * HWin + off];
+                if (ok && c0 + j < a.C) {
+                    if (F16) v.x = inq16_b[(long)(c0 + j) * HWin + off];
+                    else v = inq_b[(long)(c0 + j) * HWin + off];
+                }
                 e[j] = v;
             }
 #pragma unroll
@@ -381,17 +549,26 @@ __global__ __launch_bounds__(256) void la_conv_bf16_halo_kernel(LaConvArgs a) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        if (NTERM == 3) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);   // lh
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);   // hl
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);   // mm
+                        if constexpr (NTERM == 3) {
+                            acc[i][j] = la_mma<F16>(af[2][i], bf[0][j], acc[i][j]);   // lh
+                            acc[i][j] = la_mma<F16>(af[0][i], bf[2][j], acc[i][j]);   // hl
+                            acc[i][j] = la_mma<F16>(af[1][i], bf[1][j], acc[i][j]);   // mm
                         }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);   // mh
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);   // hm
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);   // hh
+                        acc[i][j] = la_mma<F16>(af[1][i], bf[0][j], acc[i][j]);   // mh
+                        acc[i][j] = la_mma<F16>(af[0][i], bf[1][j], acc[i][j]);   // hm
+                        acc[i][j] = la_mma<F16>(af[0][i], bf[0][j], acc[i][j]);   // hh
                     }
             }
         }
+    }
+    if (F16) {
+        const float inv = 1.f / (a.acc_scale_w[0] * a.acc_scale_x[b]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
     }
     __syncthreads();     // LDS is reused by the epilogue's reduction scratch
     la_conv_epilogue<MT, false, true>(a, acc, red, ntile, m0, G, G);
@@ -406,31 +583,36 @@ static bool halo_ok(const LaConvArgs& a) {
     return true;
 }
 
-template <int NTERM>
+template <int FMT>
 static void launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, hipStream_t stream) {
+    constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     const size_t lds128 = (size_t)NTERM * (128 + NT) * ROWB, lds64 = (size_t)NTERM * (64 + NT) * ROWB;
     if (!split && halo_ok(as)) {
         const size_t h128 = (size_t)NTERM * (128 + HALO_PX) * ROWB, h64 = (size_t)NTERM * (64 + HALO_PX) * ROWB;
         static bool attr_done = false;
         if (!attr_done) {      // > 64 KB of dynamic LDS needs the opt-in (idempotent)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, NTERM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h128);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<64, NTERM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h64);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h128);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<64, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h64);
             attr_done = true;
         }
-        if (MTsel == 128) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, NTERM>), grid, dim3(256), h128, stream, as);
-        else hipLaunchKernelGGL((la_conv_bf16_halo_kernel<64, NTERM>), grid, dim3(256), h64, stream, as);
+        if (MTsel == 128) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, FMT>), grid, dim3(256), h128, stream, as);
+        else hipLaunchKernelGGL((la_conv_bf16_halo_kernel<64, FMT>), grid, dim3(256), h64, stream, as);
         return;
     }
     if (MTsel == 128) {
-        if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, NTERM>), grid, dim3(256), lds128, stream, as);
-        else hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, NTERM>), grid, dim3(256), lds128, stream, as);
+        if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT>), grid, dim3(256), lds128, stream, as);
+        else hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT>), grid, dim3(256), lds128, stream, as);
     } else {
-        if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<64, true, NTERM>), grid, dim3(256), lds64, stream, as);
-        else hipLaunchKernelGGL((la_conv_bf16_kernel<64, false, NTERM>), grid, dim3(256), lds64, stream, as);
+        if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<64, true, FMT>), grid, dim3(256), lds64, stream, as);
+        else hipLaunchKernelGGL((la_conv_bf16_kernel<64, false, FMT>), grid, dim3(256), lds64, stream, as);
     }
 }
 
-void la_conv_bf16_dispatch(const LaConvArgs& as, int MTsel, dim3 grid, bool split, hipStream_t stream) {
-    if (as.precision == LA_PREC_BF16X3) launch_bf16<3>(as, MTsel, grid, split, stream);
-    else launch_bf16<2>(as, MTsel, grid, split, stream);
+void la_conv_bf16_dispatch(const LaConvArgs& args, int MTsel, dim3 grid, bool split, hipStream_t stream) {
+    LaConvArgs as = args;
+    if (as.precision == LA_PREC_F16X2)      // the fp16 weight scale lives behind the terms of the pack
+        as.acc_scale_w = reinterpret_cast<const float*>(static_cast<const char*>(as.wgt_bf16) + pack_wscale_offset(as.wgt_bf16_term_elems));
+    if (as.precision == LA_PREC_BF16X3) launch_bf16<FMT_BF16X3>(as, MTsel, grid, split, stream);
+    else if (as.precision == LA_PREC_F16X2) launch_bf16<FMT_F16X2>(as, MTsel, grid, split, stream);
+    else launch_bf16<FMT_BF16X2>(as, MTsel, grid, split, stream);
 }

@@ -61,8 +61,8 @@ static void dconv_layout(DCarver& c, DConv& L) {
     L.mb_ = (L.cin + 3) & ~3;
     const size_t kk = (size_t)L.k * L.k;
     L.wf = c.take((size_t)L.cin * L.cout * kk); L.wb = c.take((size_t)L.mb_ * L.cout * kk);
-    L.wqf = c.take((3 * (size_t)la_conv_bf16_pack_elems(L.cout, L.cin, (int)kk) * 2 + 64 + 3) / 4);
-    L.wqb = c.take((3 * (size_t)la_conv_bf16_pack_elems(L.mb_, L.cout, (int)kk) * 2 + 64 + 3) / 4);
+    L.wqf = c.take((la_conv_split_pack_bytes(L.cout, L.cin, (int)kk) + 3) / 4);
+    L.wqb = c.take((la_conv_split_pack_bytes(L.mb_, L.cout, (int)kk) + 3) / 4);
 }
 
 static int d_describe(la_disc* h, int R, int imgc, const int* channels, int maxB) {
@@ -197,7 +197,7 @@ extern "C" int la_disc_create(int img_resolution, int img_channels, const int* c
 
 extern "C" void la_disc_destroy(la_disc* h) { free(h); }
 extern "C" int la_disc_set_precision(la_disc* h, int precision) {
-    LA_CHECK_ARG(h && precision >= 0 && precision <= 2, "disc_set_precision: precision must be 0, 1 or 2");
+    LA_CHECK_ARG(h && precision >= 0 && precision <= 3, "disc_set_precision: precision must be 0..3");
     h->precision = precision;
     return LA_OK;
 }
@@ -435,13 +435,7 @@ extern "C" int la_disc_backward(la_disc* h, const float* dlogits, float* g_img, 
             a.in = h->scrB; a.in_bstride = (long)b.cout * hq * hq; a.out = h->scrA;
             a.B = B; a.C = b.cout; a.M = b.cin; a.Hin = a.Win = hq; a.Hout = a.Wout = res + 1;
             a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW;
-            if (h->precision != LA_PREC_F32) {   // split the input once for the four phases
-                const size_t qb = la_conv_presplit_bytes(B, b.cout, hq, hq);
-                LA_CHECK_ARG(h->cws_bytes >= qb, "disc_backward: workspace too small");
-                if ((rc = la_conv_presplit(h->scrB, a.in_bstride, nullptr, 0, h->cws, B, b.cout, (long)hq * hq, stream))) return rc;
-                const size_t off = (qb + 255) & ~(size_t)255;
-                a.in_q = h->cws; a.ws = h->cws_bytes > off ? (char*)h->cws + off : nullptr; a.ws_bytes = h->cws_bytes > off ? h->cws_bytes - off : 0;
-            }
+            if (h->precision != LA_PREC_F32 && (rc = la_conv_prepare_input(a, stream))) return rc;   // split once for the four phases
             for (int py = 0; py < 2; ++py)
                 for (int px = 0; px < 2; ++px) {
                     a.out_oy = py; a.out_ox = px; a.Gy = py ? hq : hq + 1; a.Gx = px ? hq : hq + 1;

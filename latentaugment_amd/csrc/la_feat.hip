@@ -83,8 +83,8 @@ static size_t f_layout(la_feat* h, void* ws) {
         if (o.kind == LA_FEAT_CONV_RELU) {
             o.mb_ = (o.cin + 3) & ~3;
             o.wf = c.take((size_t)o.cin * o.cout * 9); o.wb = c.take((size_t)o.mb_ * o.cout * 9);
-            o.wqf = c.take((3 * (size_t)la_conv_bf16_pack_elems(o.cout, o.cin, 9) * 2 + 64 + 3) / 4);
-            o.wqb = c.take((3 * (size_t)la_conv_bf16_pack_elems(o.mb_, o.cout, 9) * 2 + 64 + 3) / 4);
+            o.wqf = c.take((la_conv_split_pack_bytes(o.cout, o.cin, 9) + 3) / 4);
+            o.wqb = c.take((la_conv_split_pack_bytes(o.mb_, o.cout, 9) + 3) / 4);
             size_t w = la_modconv_workspace_bytes((int)mn, o.mb_ > o.cout ? o.mb_ : o.cout, o.mb_ > o.cout ? o.mb_ : o.cout, o.res_in, 0);
             if (w > cw) cw = w;
             const size_t gin = mn * o.mb_ * (size_t)o.res_in * o.res_in;
@@ -138,7 +138,7 @@ extern "C" int la_feat_create(int nops, const la_feat_op* ops, const float* cons
 extern "C" void la_feat_destroy(la_feat* h) { free(h); }
 extern "C" int la_feat_num_features(const la_feat* h) { return h ? h->F : 0; }
 extern "C" int la_feat_set_precision(la_feat* h, int precision) {
-    LA_CHECK_ARG(h && precision >= 0 && precision <= 2, "feat_set_precision: precision must be 0, 1 or 2");
+    LA_CHECK_ARG(h && precision >= 0 && precision <= 3, "feat_set_precision: precision must be 0..3");
     h->precision = precision;
     return LA_OK;
 }

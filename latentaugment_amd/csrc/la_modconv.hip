@@ -59,14 +59,8 @@ extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const f
     a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW;
     if (precision != LA_PREC_F32) {
         // split the (modulated) input once for the four phase launches
-        const size_t qb = la_conv_presplit_bytes(B, cin, hin, hin);
-        LA_CHECK_ARG(ws && ws_bytes >= qb, "modconv_up2_fwd: split-bf16 precision needs a workspace");
-        int rc = la_conv_presplit(x, x_bstride, s, s_stride, ws, B, cin, (long)hin * hin, stream);
+        int rc = la_conv_prepare_input(a, stream);
         if (rc) return rc;
-        const size_t off = (qb + 255) & ~(size_t)255;
-        a.in_q = ws;
-        a.ws = ws_bytes > off ? static_cast<char*>(ws) + off : nullptr;
-        a.ws_bytes = ws_bytes > off ? ws_bytes - off : 0;
     }
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
@@ -134,7 +128,7 @@ extern "C" int la_modconv_ds_tiles(int grid_res) { return la_conv_tiles_per_samp
 extern "C" size_t la_modconv_workspace_bytes(int B, int cin, int cout, int res, int up) {
     size_t need = 0;
     const int hin = up ? res / 2 : res;
-    for (int prec = 0; prec <= 2; ++prec) {
+    for (int prec = 0; prec <= 3; ++prec) {
         long f, b;
         size_t qf = 0, qb = 0;
         if (up) {
@@ -155,7 +149,8 @@ extern "C" size_t la_modconv_workspace_bytes(int B, int cin, int cout, int res, 
 
 // split-bf16 weight packs: bytes for one direction (forward: transpose = 0, backward: transpose = 1), nterm terms
 extern "C" size_t la_modconv_bf16_pack_bytes(int cin, int cout, int transpose, int nterm) {
-    return (size_t)nterm * (size_t)la_conv_bf16_pack_elems(transpose ? cin : cout, transpose ? cout : cin, 9) * 2;
+    (void)nterm;      // one pack serves every split precision (3 bf16 terms + 2 fp16 terms + the fp16 weight scale)
+    return la_conv_split_pack_bytes(transpose ? cin : cout, transpose ? cout : cin, 9);
 }
 
 extern "C" int la_pack_conv_weights_bf16_f32(const float* w, void* out, int cout, int cin, int ktaps, int transpose,

@@ -239,7 +239,7 @@ extern "C" void la_synth_destroy(la_synth* h) { free(h); }
 
 // contraction arithmetic of every modulated conv of the engine: 0 fp32 MFMA, 1 split-bf16 x3 (fp32-class), 2 split-bf16 x2
 extern "C" int la_synth_set_precision(la_synth* h, int precision) {
-    LA_CHECK_ARG(h && precision >= 0 && precision <= 2, "synth_set_precision: precision must be 0, 1 or 2");
+    LA_CHECK_ARG(h && precision >= 0 && precision <= 3, "synth_set_precision: precision must be 0..3");
     h->precision = precision;
     return LA_OK;
 }

@@ -16,7 +16,7 @@ from . import _lib
 _CONV_KEYS = ('affine.weight', 'affine.bias', 'weight', 'bias', 'noise_const')
 _RGB_KEYS = ('affine.weight', 'affine.bias', 'weight', 'bias')
 NOISE_MODES = {'none': 0, 'const': 1, 'random': 2}
-PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16x2': 2}
+PRECISIONS = {'f32': 0, 'bf16x3': 1, 'bf16x2': 2, 'f16x2': 3}
 
 
 def _state_dict_of(G):
@@ -96,7 +96,8 @@ class SynthesisEngine:
         self.set_precision(precision)
 
     def set_precision(self, precision):
-        """'f32' exact fp32 MFMA | 'bf16x3' split-bf16, 6 MFMAs (fp32-class error) | 'bf16x2' split-bf16, 3 MFMAs."""
+        """'f32' exact fp32 MFMA | 'f16x2' scaled split-fp16, 3 MFMAs (fp32-class error) | 'bf16x3' split-bf16, 6 MFMAs
+        (fp32-class error) | 'bf16x2' split-bf16, 3 MFMAs (approximate)."""
         _lib.check(self._lib.la_synth_set_precision(self._h, PRECISIONS[precision]), 'la_synth_set_precision')
         self.precision = precision
 
