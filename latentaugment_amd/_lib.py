@@ -117,11 +117,12 @@ def load():
     # streams and allocations (loading ours first leaves two runtimes in the process and HIP calls fail with
     # "no ROCm-capable device is detected")
     import torch  # noqa: F401
-    if not os.path.isfile(LIB_PATH):
+    path = os.environ.get('LATENTAUG_HIP_LIB') or LIB_PATH      # override: alternative builds for kernel experiments
+    if not os.path.isfile(path):
         raise LatentAugHipError(
-            f'{LIB_PATH} not found: build it with `make -C latentaugment_amd/csrc` (or __graft_entry__.build()). '
+            f'{path} not found: build it with `make -C latentaugment_amd/csrc` (or __graft_entry__.build()). '
             'There is no CPU fallback for the latent-augmentation hot path.')
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

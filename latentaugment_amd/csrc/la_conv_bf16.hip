@@ -20,11 +20,18 @@
 // terms k-contiguous with v_perm_b32 and writes them to LDS ([pixel][32] bf16, 80-byte row stride: conflict-free for
 // ds_read_b128 fragments and ds_write_b128 staging).
 #include "la_conv_device.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // FMT template parameter of the kernels below
+#ifndef LA_ABLATE
+#define LA_ABLATE 0      // dev builds only: knock out one pipeline stage of the halo kernel to time the rest
+#endif
+#ifndef LA_HALO_SB
+#define LA_HALO_SB 0
+#endif
 #define FMT_BF16X3 3
 #define FMT_BF16X2 2
 #define FMT_F16X2 16
@@ -40,18 +47,26 @@ __device__ __forceinline__ f32x16 la_mma(bf16x8 a, bf16x8 b, f32x16 c) {
 #define ROWB 80                // LDS bytes per (row, 32 bf16) incl. 16 B pad
 
 // ------------------------------------------------------------------------------------------------------------
-// weight packing: W[o][i][t] (fp32) -> out[term][t][cc][m][32] bf16 with (m,k) = (o,i) forward or (i,o) backward
+// weight packing: W[o][i][t] (fp32) -> out[term][t][cc][m/32][k/16][lane][8] with (m,k) = (o,i) forward or (i,o) backward.
+// Inside a (tap, 32-channel chunk) slab the 32-row x 16-channel blocks are stored in MFMA A-FRAGMENT order: lane
+// (r = m%32, h = (k/8)%2) holds A[r][8h .. 8h+7] as 16 contiguous bytes, lanes contiguous -- so a wave fetches one
+// fragment with a single fully coalesced 1 KB load, no LDS staging.  M is padded to a multiple of 32 with zero rows.
+__host__ __device__ static inline int pack_mp(int M) { return (M + 31) & ~31; }
+__device__ __forceinline__ long pack_slab_offset(int m, int k) {      // element offset of (row m, channel k) inside a slab
+    return ((((long)(m >> 5) * 2 + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (m & 31)) << 3) + (k & 7);
+}
 __global__ void la_pack_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int cout, int cin, int ktaps,
                                     int transpose, int nterm, float scale, int m_pad) {
     const int Mreal = transpose ? cin : cout, C = transpose ? cout : cin;
-    const int M = m_pad > Mreal ? m_pad : Mreal;
+    const int M = pack_mp(m_pad > Mreal ? m_pad : Mreal);
     const int nck = (C + KCB - 1) / KCB;
     const long per_term = (long)ktaps * nck * M * KCB;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < per_term; idx += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(idx % KCB);
-        const int m = (int)((idx / KCB) % M);
-        const int cc = (int)((idx / ((long)KCB * M)) % nck);
-        const int t = (int)(idx / ((long)KCB * M * nck));
+    for (long lin = blockIdx.x * (long)blockDim.x + threadIdx.x; lin < per_term; lin += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(lin % KCB);
+        const int m = (int)((lin / KCB) % M);
+        const int cc = (int)((lin / ((long)KCB * M)) % nck);
+        const int t = (int)(lin / ((long)KCB * M * nck));
+        const long idx = ((long)t * nck + cc) * M * KCB + pack_slab_offset(m, k);
         const int c = cc * KCB + k;
         float v = 0.f;
         if (c < C && m < Mreal) {
@@ -66,7 +81,7 @@ __global__ void la_pack_bf16_kernel(const float* __restrict__ w, __bf16* __restr
     }
 }
 
-long la_conv_bf16_pack_elems(int M, int C, int ktaps) { return (long)ktaps * la_cdiv(C, KCB) * M * KCB; }
+long la_conv_bf16_pack_elems(int M, int C, int ktaps) { return (long)ktaps * la_cdiv(C, KCB) * pack_mp(M) * KCB; }
 
 // pack layout: [3 bf16 terms][2 fp16 terms][pad to 16 B][wscale float]
 size_t la_conv_split_pack_bytes(int M, int C, int ktaps) {
@@ -101,16 +116,17 @@ __global__ void la_pack_f16_kernel(const float* __restrict__ w, _Float16* __rest
                                    float* __restrict__ wscale_out, int cout, int cin, int ktaps, int transpose, float scale,
                                    int m_pad) {
     const int Mreal = transpose ? cin : cout, C = transpose ? cout : cin;
-    const int M = m_pad > Mreal ? m_pad : Mreal;
+    const int M = pack_mp(m_pad > Mreal ? m_pad : Mreal);
     const int nck = (C + KCB - 1) / KCB;
     const long per_term = (long)ktaps * nck * M * KCB;
     const float ws = la_pow2_scale(__uint_as_float(*amax_bits));
     if (blockIdx.x == 0 && threadIdx.x == 0) *wscale_out = ws;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < per_term; idx += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(idx % KCB);
-        const int m = (int)((idx / KCB) % M);
-        const int cc = (int)((idx / ((long)KCB * M)) % nck);
-        const int t = (int)(idx / ((long)KCB * M * nck));
+    for (long lin = blockIdx.x * (long)blockDim.x + threadIdx.x; lin < per_term; lin += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(lin % KCB);
+        const int m = (int)((lin / KCB) % M);
+        const int cc = (int)((lin / ((long)KCB * M)) % nck);
+        const int t = (int)(lin / ((long)KCB * M * nck));
+        const long idx = ((long)t * nck + cc) * M * KCB + pack_slab_offset(m, k);
         const int c = cc * KCB + k;
         float v = 0.f;
         if (c < C && m < Mreal) {
@@ -178,32 +194,53 @@ __global__ __launch_bounds__(256) void la_presplit_kernel(const float* __restric
     }
 }
 
-// fp16 path, pass 1: max |x * scale| of every (b, c) plane, one workgroup per plane (no atomics);
-// pass 2: each workgroup reduces its sample's plane maxima, derives the power-of-two scale and splits.
+// fp16 path, pass 1: max |x * scale| of every (b, c) plane in PM_NS segments, one workgroup per segment (no atomics);
+// pass 2: each workgroup reduces its sample's segment maxima, derives the power-of-two scale and splits.
+#define PM_NS 8
 __global__ __launch_bounds__(256) void la_plane_absmax_kernel(const float* __restrict__ in, long in_bstride,
                                                              const float* __restrict__ scale, int scale_stride,
-                                                             float* __restrict__ pm, int C, long HW) {
+                                                             float* __restrict__ pm, int C, long HW, int ns) {
     __shared__ float red[4];
-    const int c = blockIdx.x, b = blockIdx.y;
-    const float sc = scale ? scale[(long)b * scale_stride + c] : 1.f;
+    const int seg = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
     const float* ip = in + (long)b * in_bstride + (long)c * HW;
+    const long per = ((HW + ns - 1) / ns + 3) & ~3l;
+    const long p0 = seg * per, p1 = p0 + per < HW ? p0 + per : HW;
     float m = 0.f;
-    for (long p = threadIdx.x; p < HW; p += blockDim.x) m = fmaxf(m, fabsf(ip[p] * sc));
+    if ((((size_t)ip | (size_t)(HW * 4)) & 15) == 0) {          // 16-byte aligned plane: float4 stream, 4 loads in flight
+        const float4* ip4 = reinterpret_cast<const float4*>(ip);
+        long q = p0 / 4 + threadIdx.x;
+        const long q1 = p1 / 4;
+        for (; q + 768 < q1; q += 1024) {
+            const float4 v0 = ip4[q], v1 = ip4[q + 256], v2 = ip4[q + 512], v3 = ip4[q + 768];
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))),
+                               fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)))));
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w))),
+                               fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w)))));
+        }
+        for (; q < q1; q += 256) {
+            const float4 v = ip4[q];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        for (long p = q1 * 4 + threadIdx.x; p < p1; p += 256) m = fmaxf(m, fabsf(ip[p]));
+    } else {
+        for (long p = p0 + threadIdx.x; p < p1; p += 256) m = fmaxf(m, fabsf(ip[p]));
+    }
+    m *= fabsf(scale ? scale[(long)b * scale_stride + c] : 1.f);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) pm[(long)b * C + c] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (threadIdx.x == 0) pm[((long)b * C + c) * ns + seg] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 __global__ __launch_bounds__(256) void la_presplit_f16_kernel(const float* __restrict__ in, long in_bstride,
                                                              const float* __restrict__ scale, int scale_stride,
                                                              const float* __restrict__ pm, float* __restrict__ xscale,
-                                                             unsigned* __restrict__ out, int C, long HW) {
+                                                             unsigned* __restrict__ out, int C, long HW, int ns) {
     __shared__ float red[4];
     const int c = blockIdx.y, b = blockIdx.z;
     float m = 0.f;
-    for (int k = threadIdx.x; k < C; k += blockDim.x) m = fmaxf(m, pm[(long)b * C + k]);
+    for (int k = threadIdx.x; k < C * ns; k += blockDim.x) m = fmaxf(m, pm[(long)b * C * ns + k]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -221,7 +258,7 @@ __global__ __launch_bounds__(256) void la_presplit_f16_kernel(const float* __res
     }
 }
 
-static inline size_t presplit_hdr_bytes(int B, int C) { return (PRESPLIT_HDR + (size_t)B * C * 4 + 255) & ~(size_t)255; }
+static inline size_t presplit_hdr_bytes(int B, int C) { return (PRESPLIT_HDR + (size_t)B * C * PM_NS * 4 + 255) & ~(size_t)255; }
 size_t la_conv_presplit_bytes(int B, int C, int Hin, int Win) { return (size_t)B * C * Hin * Win * 8 + 16 + presplit_hdr_bytes(B, C); }
 
 int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
@@ -238,10 +275,12 @@ int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
     int gx = la_cdiv(HW, 512);
     if (gx > 64) gx = 64;
     if (a.precision == LA_PREC_F16X2) {
-        hipLaunchKernelGGL(la_plane_absmax_kernel, dim3(a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
-                           a.scale_stride, pm, a.C, HW);
+        int ns = (int)(HW / 8192);
+        ns = ns < 1 ? 1 : (ns > PM_NS ? PM_NS : ns);
+        hipLaunchKernelGGL(la_plane_absmax_kernel, dim3(ns, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
+                           a.scale_stride, pm, a.C, HW, ns);
         hipLaunchKernelGGL(la_presplit_f16_kernel, dim3(gx, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
-                           a.scale_stride, pm, xscale, (unsigned*)q, a.C, HW);
+                           a.scale_stride, pm, xscale, (unsigned*)q, a.C, HW, ns);
         a.acc_scale_x = xscale;
     } else {
         hipLaunchKernelGGL(la_presplit_kernel, dim3(gx, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
@@ -323,16 +362,17 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
             }
             breg[j] = v;
         }
-        // A: contiguous [M][32] bf16 slab of (tap slab, channel chunk); rows m0 .. m0+MT
-        const __bf16* slab = wbase + (((long)a.tap_w[t] * nck + cc) * a.M + m0) * KCB;
+        // A: (tap slab, channel chunk) slab in fragment order (pack_slab_offset); rows m0 .. m0+MT
+        const int Mp = pack_mp(a.M);
+        const __bf16* slab = wbase + ((long)a.tap_w[t] * nck + cc) * Mp * KCB;
 #pragma unroll
         for (int q = 0; q < NTERM; ++q)
 #pragma unroll
             for (int u = 0; u < A_U; ++u) {
-                const int unit = tid + 256 * u;          // 16-byte unit: row = unit/4, piece = unit%4
-                const int row = unit >> 2;
+                const int unit = tid + 256 * u;          // 16-byte unit of the LDS image: row = unit/4, piece = unit%4
+                const int row = m0 + (unit >> 2), piece = unit & 3;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (m0 + row < a.M) v = *reinterpret_cast<const uint4*>(slab + (long)q * term_elems + (long)unit * 8);
+                if (row < Mp) v = *reinterpret_cast<const uint4*>(slab + (long)q * term_elems + pack_slab_offset(row, piece * 8));
                 areg[q][u] = v;
             }
     };
@@ -422,20 +462,26 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 // Halo variant for dense stride-1 3x3 launches on grids that tile exactly into 4 x 32 pixel tiles (the >= 64x64 layers,
 // i.e. the bulk of the FLOPs).  The flat kernel above re-gathers every input element once per tap (9x) from L2; here the
-// (4+2) x (32+2) halo of a 32-channel chunk is staged in LDS ONCE and the 9 taps read shifted fragments from it, so the
-// per-tap work of the loader shrinks to the 30 KB weight slab.  LDS: halo 204 px x 80 B x NTERM + A 128 x 80 B x NTERM
-// = 79.7 KB (x3) -> two workgroups per CU.
+// (4+2) x (32+2) halo of a 32-channel chunk is staged in LDS ONCE and the 9 taps read shifted fragments from it.
+//   * B (pixels): next chunk's halo is loaded into registers while the current chunk computes; two barriers per CHUNK
+//     (216 / 432 MFMAs per wave between them), none per tap.
+//   * A (weights): never touches LDS.  The pack is [tap][chunk][M][32] with K contiguous, which is exactly the MFMA A
+//     fragment (lane (r, h) <- 16 B at row r, byte ks*32 + h*16), so every wave loads its own fragments straight from
+//     global/L2 into a register ring, RING-1 steps (one step = one tap x 16 channels) ahead of the MFMAs that use them.
+// LDS: 204 px x 80 B x NTERM = 32 / 48 KB; registers: 64 acc + RING x NTERM x 8 (A ring) + 32 / 64 (halo prefetch).
 #define HALO_W 34
 #define HALO_PX (6 * HALO_W)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 template <int MT, int FMT>
-__global__ __launch_bounds__(256) void la_conv_bf16_halo_kernel(LaConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void la_conv_bf16_halo_kernel(LaConvArgs a) {
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     constexpr bool F16 = FMT == FMT_F16X2;
     constexpr int TM = MT / 64;
-    constexpr int A_U = (MT * 4) / 256;
+    constexpr int EB = F16 ? 4 : 8;                // bytes per pre-split element
+    constexpr bool TAPPF = NTERM == 2;             // A fragments one whole tap ahead (else one 16-channel step ahead)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                                   // [NTERM][MT][ROWB]
-    unsigned char* Bs = smem + NTERM * MT * ROWB;               // [NTERM][HALO_PX][ROWB]
+    unsigned char* Bs = smem;                                   // [NTERM][HALO_PX][ROWB]
     float (*red)[MT] = reinterpret_cast<float (*)[MT]>(smem);
 
     const int tid = threadIdx.x;
@@ -449,68 +495,133 @@ __global__ __launch_bounds__(256) void la_conv_bf16_halo_kernel(LaConvArgs a) {
     const int tpr = a.Gx >> 5;
     const int tyb = ntile / tpr, txb = ntile - tyb * tpr;
     const int y0 = tyb * 4 - 1, x0 = txb * 32 - 1;              // grid coordinates of halo pixel (0, 0)
-    const long HWin = (long)a.Hin * a.Win;
-    const uint2* inq_b = reinterpret_cast<const uint2*>(a.in_q) + (long)b * a.C * HWin;
-    const unsigned* inq16_b = reinterpret_cast<const unsigned*>(a.in_q) + (long)b * a.C * HWin;
+    const unsigned HWin = (unsigned)(a.Hin * a.Win);
     const int nck = (a.C + KCB - 1) / KCB;
     const long term_elems = a.wgt_bf16_term_elems;
-    const __bf16* wbase = reinterpret_cast<const __bf16*>(static_cast<const char*>(a.wgt_bf16) + (F16 ? pack_f16_offset(term_elems) : 0));
+    const int l31 = lane & 31, lh = lane >> 5;
+    // buffer descriptors (wave-uniform): this sample's pre-split input, and the weight pack of this format
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(a.in_q)) + (size_t)b * a.C * HWin * EB, 0, (int)((unsigned)a.C * HWin * EB), 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(a.wgt_bf16)) + (F16 ? pack_f16_offset(term_elems) : 0), 0, (int)(NTERM * term_elems * 2),
+        0x00020000);
 
-    uint4 areg[NTERM][A_U];
-    auto prefetch_a = [&](int cc, int t) {
-        const __bf16* slab = wbase + (((long)a.tap_w[t] * nck + cc) * a.M + m0) * KCB;
+    // tap table -> two packed scalars, so the tap loop needs no indexed kernarg reads
+    unsigned long long shpack = 0ull, wpack = 0ull;
 #pragma unroll
-        for (int q = 0; q < NTERM; ++q)
+    for (int t = 0; t < 9; ++t) {
+        shpack |= (unsigned long long)((1 + a.tap_dy[t]) * HALO_W + (1 + a.tap_dx[t])) << (7 * t);
+        wpack |= (unsigned long long)a.tap_w[t] << (4 * t);
+    }
+
+    // ---- halo prefetch: work item = (halo pixel, 16-channel half); 2 * HALO_PX = 408 items, <= 2 per thread.  Every load
+    // is unconditional (clamped address; out-of-image pixels are zeroed when the registers are written to LDS, channels
+    // past C meet zero weights), so the loads of the next chunk stay in flight under this chunk's MFMAs.
+    unsigned ex[2][16], ey[NTERM == 3 ? 2 : 1][16];
+    unsigned hoff[2], hbase[2];
+    bool hok[2];
+    int hhalf[2];
 #pragma unroll
-            for (int u = 0; u < A_U; ++u) {
-                const int unit = tid + 256 * u;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (m0 + (unit >> 2) < a.M) v = *reinterpret_cast<const uint4*>(slab + (long)q * term_elems + (long)unit * 8);
-                areg[q][u] = v;
-            }
-    };
-    auto stage_a = [&]() {
+    for (int it = 0; it < 2; ++it) {
+        const int item = tid + 256 * it;
+        const int itc = item < 2 * HALO_PX ? item : 2 * HALO_PX - 1;
+        const int hp = itc >> 1, half = itc & 1;
+        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+        const int iy = y0 + hy, ix = x0 + hx;
+        hok[it] = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
+        hoff[it] = (unsigned)(iyc * a.Win + ixc) * EB;
+        hbase[it] = (unsigned)(half * 16) * HWin * EB + hoff[it];
+        hhalf[it] = half;
+    }
+    auto load_halo = [&](int cc, auto fast) {
+        const unsigned sbase = (unsigned)(cc * KCB) * HWin * EB;
+        const int cmax = a.C - 1 - cc * KCB;         // last valid channel of this chunk (ragged last chunk only)
 #pragma unroll
-        for (int q = 0; q < NTERM; ++q)
-#pragma unroll
-            for (int u = 0; u < A_U; ++u) {
-                const int unit = tid + 256 * u;
-                *reinterpret_cast<uint4*>(As + ((long)q * MT + (unit >> 2)) * ROWB + (unit & 3) * 16) = areg[q][u];
-            }
-    };
-    // halo staging: work item = (halo pixel, 16-channel half); 2 * HALO_PX = 408 items over 256 threads
-    auto stage_b = [&](int cc) {
-        for (int item = tid; item < 2 * HALO_PX; item += 256) {
-            const int hp = item >> 1, half = item & 1;
-            const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-            const int iy = y0 + hy, ix = x0 + hx;
-            const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            const long off = (long)iy * a.Win + ix;
-            const int c0 = cc * KCB + half * 16;
-            uint2 e[16];
+        for (int it = 0; it < 2; ++it)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                uint2 v = make_uint2(0u, 0u);
-                if (ok && c0 + j < a.C) {
-                    if (F16) v.x = inq16_b[(long)(c0 + j) * HWin + off];
-                    else v = inq_b[(long)(c0 + j) * HWin + off];
+                unsigned vo, so;
+                if (decltype(fast)::value) { vo = hbase[it]; so = sbase + (unsigned)j * HWin * EB; }
+                else {
+                    const int c = hhalf[it] * 16 + j;
+                    vo = (unsigned)(c < cmax ? c : cmax) * HWin * EB + hoff[it];
+                    so = sbase;
                 }
-                e[j] = v;
+#if LA_ABLATE == 1 || LA_ABLATE == 3 || LA_ABLATE == 5
+                ex[it][j] = vo + so; if (NTERM == 3) ey[NTERM == 3 ? it : 0][j] = vo; continue;
+#endif
+                if (NTERM == 3) {
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_in, vo, so, 0);
+                    ex[it][j] = v.x;
+                    ey[NTERM == 3 ? it : 0][j] = v.y;
+                } else ex[it][j] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, so, 0);
             }
+    };
+    auto load_halo_any = [&](int cc) {
+        if (cc * KCB + KCB <= a.C) load_halo(cc, std::true_type{});
+        else load_halo(cc, std::false_type{});
+    };
+    auto write_halo = [&]() {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = tid + 256 * it;
+            const int hp = item >> 1, half = item & 1;
 #pragma unroll
             for (int q = 0; q < NTERM; ++q) {
                 unsigned w[8];
 #pragma unroll
                 for (int d = 0; d < 8; ++d) {
-                    const unsigned e0 = q == 2 ? e[2 * d].y : e[2 * d].x;
-                    const unsigned e1 = q == 2 ? e[2 * d + 1].y : e[2 * d + 1].x;
-                    w[d] = __builtin_amdgcn_perm(e1, e0, q == 1 ? 0x07060302u : 0x05040100u);
+                    const unsigned e0 = q == 2 ? ey[NTERM == 3 ? it : 0][2 * d] : ex[it][2 * d];
+                    const unsigned e1 = q == 2 ? ey[NTERM == 3 ? it : 0][2 * d + 1] : ex[it][2 * d + 1];
+                    const unsigned v = __builtin_amdgcn_perm(e1, e0, q == 1 ? 0x07060302u : 0x05040100u);
+                    w[d] = hok[it] ? v : 0u;
                 }
-                unsigned char* p = Bs + ((long)q * HALO_PX + hp) * ROWB + half * 32;
-                *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
-                *reinterpret_cast<uint4*>(p + 16) = make_uint4(w[4], w[5], w[6], w[7]);
+                if (item < 2 * HALO_PX) {
+                    unsigned char* p = Bs + ((long)q * HALO_PX + hp) * ROWB + half * 32;
+                    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+                    *reinterpret_cast<uint4*>(p + 16) = make_uint4(w[4], w[5], w[6], w[7]);
+                }
             }
         }
+    };
+
+    // ---- A fragments straight from the pack (rows past M are clamped: their accumulator rows are never stored)
+    // (fragment-order pack: one fully coalesced 1 KB load per 32-row x 16-channel fragment)
+    const int Mp = pack_mp(a.M);
+    unsigned a_off[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int mblk = (m0 + wm * (MT / 2) + i * 32) >> 5;
+        mblk = mblk < (Mp >> 5) ? mblk : (Mp >> 5) - 1;
+        a_off[i] = (unsigned)mblk * 2048u + (unsigned)lane * 16u;
+    }
+    const unsigned slab_bytes = (unsigned)Mp * KCB * 2u;         // one (tap, chunk) slab of one term
+    const unsigned term_bytes = (unsigned)term_elems * 2u;
+    auto load_a = [&](int cc, int t, int ks, bf16x8 (&dst)[NTERM][TM]) {
+        const unsigned tw = (unsigned)((wpack >> (4 * t)) & 15u);
+        const unsigned so = (tw * nck + cc) * slab_bytes + ks * 1024;
+#pragma unroll
+        for (int q = 0; q < NTERM; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#if LA_ABLATE == 2 || LA_ABLATE == 3 || LA_ABLATE == 5
+                { u32x4 u = {a_off[i], so, (unsigned)q, (unsigned)i}; dst[q][i] = __builtin_bit_cast(bf16x8, u); }
+#else
+                dst[q][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_off[i], so + q * term_bytes, 0));
+#endif
+    };
+    const int b_lane = ((wn * 2) * HALO_W + l31) * ROWB + lh * 16;
+    auto read_b = [&](int shift, int ks, bf16x8 (&dst)[NTERM][2]) {
+#pragma unroll
+        for (int q = 0; q < NTERM; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#if LA_ABLATE == 5
+                { u32x4 u = {(unsigned)shift, (unsigned)ks, (unsigned)q, (unsigned)lane}; dst[q][j] = __builtin_bit_cast(bf16x8, u); }
+#else
+                dst[q][j] = *reinterpret_cast<const bf16x8*>(Bs + ((long)q * HALO_PX + j * HALO_W + shift) * ROWB + b_lane + ks * 32);
+#endif
     };
 
     f32x16 acc[TM][2];
@@ -520,44 +631,57 @@ __global__ __launch_bounds__(256) void la_conv_bf16_halo_kernel(LaConvArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mma_step = [&](bf16x8 (&af)[NTERM][TM], bf16x8 (&bf)[NTERM][2]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // smallest products first, so they are not swamped by the leading term inside the accumulator
+                if constexpr (NTERM == 3) {
+                    acc[i][j] = la_mma<F16>(af[2][i], bf[0][j], acc[i][j]);   // lh
+                    acc[i][j] = la_mma<F16>(af[0][i], bf[2][j], acc[i][j]);   // hl
+                    acc[i][j] = la_mma<F16>(af[1][i], bf[1][j], acc[i][j]);   // mm
+                }
+                acc[i][j] = la_mma<F16>(af[1][i], bf[0][j], acc[i][j]);   // mh
+                acc[i][j] = la_mma<F16>(af[0][i], bf[1][j], acc[i][j]);   // hm
+                acc[i][j] = la_mma<F16>(af[0][i], bf[0][j], acc[i][j]);   // hh
+            }
+    };
 
-    const int l31 = lane & 31, lh = lane >> 5;
-    prefetch_a(0, 0);
+    bf16x8 acur[2][NTERM][TM], anxt[TAPPF ? 2 : 1][NTERM][TM];
+    bf16x8 bf0[NTERM][2], bf1[NTERM][2];
+    load_halo_any(0);
+    load_a(0, 0, 0, acur[0]);
+    if (TAPPF) load_a(0, 0, 1, acur[1]);
     for (int cc = 0; cc < nck; ++cc) {
         __syncthreads();                       // previous chunk's MFMAs are done with the halo
-        stage_b(cc);
-        for (int t = 0; t < a.ntaps; ++t) {
-            if (t > 0) __syncthreads();        // previous tap's MFMAs are done with the A slab
-            stage_a();
-            __syncthreads();
-            if (t + 1 < a.ntaps) prefetch_a(cc, t + 1);
-            else if (cc + 1 < nck) prefetch_a(cc + 1, 0);
-            const int shift = (1 + a.tap_dy[t]) * HALO_W + (1 + a.tap_dx[t]);
+        write_halo();
+        __syncthreads();
+        if (cc + 1 < nck) load_halo_any(cc + 1);
+        read_b((int)(shpack & 127u), 0, bf0);
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            const int shift = (int)((shpack >> (7 * t)) & 127u);
+            // the tap after this one: next tap, else first tap of the next chunk (the final one re-reads a valid slab)
+            const int tn = t + 1 < 9 ? t + 1 : 0;
+            const int ccn = t + 1 < 9 ? cc : (cc + 1 < nck ? cc + 1 : 0);
+            const int shift_n = (int)((shpack >> (7 * (t + 1 < 9 ? t + 1 : 8))) & 127u);   // (last tap: harmless re-read)
+            // ---- K-step 0: next fragments are issued first and fly under the MFMAs
+            if (TAPPF) { load_a(ccn, tn, 0, anxt[0]); load_a(ccn, tn, 1, anxt[TAPPF ? 1 : 0]); }
+            else load_a(cc, t, 1, acur[1]);
+            read_b(shift, 1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(acur[0], bf0);
+            // ---- K-step 1
+            if (!TAPPF) load_a(ccn, tn, 0, acur[0]);
+            read_b(shift_n, 0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(acur[1], bf1);
+            if (TAPPF) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 af[NTERM][TM], bf[NTERM][2];
+                for (int q = 0; q < NTERM; ++q)
 #pragma unroll
-                for (int q = 0; q < NTERM; ++q) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        af[q][i] = *reinterpret_cast<const bf16x8*>(As + ((long)q * MT + wm * (MT / 2) + i * 32 + l31) * ROWB + ks * 32 + lh * 16);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        bf[q][j] = *reinterpret_cast<const bf16x8*>(Bs + ((long)q * HALO_PX + (wn * 2 + j) * HALO_W + l31 + shift) * ROWB + ks * 32 + lh * 16);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if constexpr (NTERM == 3) {
-                            acc[i][j] = la_mma<F16>(af[2][i], bf[0][j], acc[i][j]);   // lh
-                            acc[i][j] = la_mma<F16>(af[0][i], bf[2][j], acc[i][j]);   // hl
-                            acc[i][j] = la_mma<F16>(af[1][i], bf[1][j], acc[i][j]);   // mm
-                        }
-                        acc[i][j] = la_mma<F16>(af[1][i], bf[0][j], acc[i][j]);   // mh
-                        acc[i][j] = la_mma<F16>(af[0][i], bf[1][j], acc[i][j]);   // hm
-                        acc[i][j] = la_mma<F16>(af[0][i], bf[0][j], acc[i][j]);   // hh
-                    }
+                    for (int i = 0; i < TM; ++i) { acur[0][q][i] = anxt[0][q][i]; acur[1][q][i] = anxt[TAPPF ? 1 : 0][q][i]; }
             }
         }
     }
@@ -571,13 +695,21 @@ __global__ __launch_bounds__(256) void la_conv_bf16_halo_kernel(LaConvArgs a) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
     }
     __syncthreads();     // LDS is reused by the epilogue's reduction scratch
+#if LA_ABLATE == 4
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
+#else
     la_conv_epilogue<MT, false, true>(a, acc, red, ntile, m0, G, G);
+#endif
 }
 
 // can this launch use the halo kernel?  dense stride-1 taps within +-1, grid = whole 4x32 tiles, not a split-K candidate
 static bool halo_ok(const LaConvArgs& a) {
     if (a.in_sy != 1 || a.in_sx != 1 || a.out_sy != 1 || a.out_sx != 1 || a.out_oy != 0 || a.out_ox != 0) return false;
-    if ((a.Gx & 31) != 0 || (a.Gy & 3) != 0 || a.Gy != a.Hout || a.Gx != a.Wout) return false;
+    if ((a.Gx & 31) != 0 || (a.Gy & 3) != 0 || a.Gy != a.Hout || a.Gx != a.Wout || a.ntaps != 9) return false;
+    if ((long)a.C * a.Hin * a.Win >= (1l << 27)) return false;      // 32-bit byte offsets inside one sample
     for (int t = 0; t < a.ntaps; ++t)
         if (a.tap_dy[t] < -1 || a.tap_dy[t] > 1 || a.tap_dx[t] < -1 || a.tap_dx[t] > 1) return false;
     return true;
@@ -588,7 +720,7 @@ static void launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, 
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     const size_t lds128 = (size_t)NTERM * (128 + NT) * ROWB, lds64 = (size_t)NTERM * (64 + NT) * ROWB;
     if (!split && halo_ok(as)) {
-        const size_t h128 = (size_t)NTERM * (128 + HALO_PX) * ROWB, h64 = (size_t)NTERM * (64 + HALO_PX) * ROWB;
+        const size_t h128 = (size_t)NTERM * HALO_PX * ROWB, h64 = h128;      // >= the epilogue's 2 * MT floats
         static bool attr_done = false;
         if (!attr_done) {      // > 64 KB of dynamic LDS needs the opt-in (idempotent)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h128);
