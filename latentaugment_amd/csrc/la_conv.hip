@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void la_conv_igemm_kernel(LaConvArgs a) {
     constexpr int A_F4 = (KC * MT / 4) / 256;  // float4 loads of the A slab per thread (2 for MT=128, 1 for MT=64)
     __shared__ __attribute__((aligned(16))) float As[2][KC][MT];
     __shared__ __attribute__((aligned(16))) float Bs[2][KC][NT];
-    __shared__ float red[2][MT];
+    __shared__ float red[4][MT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;

@@ -29,6 +29,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef LA_ABLATE
 #define LA_ABLATE 0      // dev builds only: knock out one pipeline stage of the halo kernel to time the rest
 #endif
+#ifndef LA_STAMP
+#define LA_STAMP 0
+#endif
 #ifndef LA_HALO_SB
 #define LA_HALO_SB 0
 #endif
@@ -463,14 +466,31 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
 // Halo variant for dense stride-1 3x3 launches on grids that tile exactly into 4 x 32 pixel tiles (the >= 64x64 layers,
 // i.e. the bulk of the FLOPs).  The flat kernel above re-gathers every input element once per tap (9x) from L2; here the
 // (4+2) x (32+2) halo of a 32-channel chunk is staged in LDS ONCE and the 9 taps read shifted fragments from it.
-//   * B (pixels): next chunk's halo is loaded into registers while the current chunk computes; two barriers per CHUNK
-//     (216 / 432 MFMAs per wave between them), none per tap.
-//   * A (weights): never touches LDS.  The pack is [tap][chunk][M][32] with K contiguous, which is exactly the MFMA A
-//     fragment (lane (r, h) <- 16 B at row r, byte ks*32 + h*16), so every wave loads its own fragments straight from
-//     global/L2 into a register ring, RING-1 steps (one step = one tap x 16 channels) ahead of the MFMAs that use them.
-// LDS: 204 px x 80 B x NTERM = 32 / 48 KB; registers: 64 acc + RING x NTERM x 8 (A ring) + 32 / 64 (halo prefetch).
+//   * B (pixels): two halo buffers.  While chunk cc computes, chunk cc+1 streams in, one ninth per tap: each thread loads a
+//     4-channel unit, holds it for one tap (4 / 8 registers) and writes it to the other buffer during the next tap, so an
+//     HBM miss has a whole tap of MFMAs to land and no wait ever covers more than one tap's loads.  ONE barrier per chunk.
+//     Rows are 64 B (32 channels of one term) with the 16-byte slots XOR-swizzled by (pixel >> 2) & 3: conflict-free
+//     ds_read_b128 fragments at any tap shift, no padding.
+//   * A (weights): never touches LDS.  The pack stores every 32-row x 16-channel block in MFMA fragment order, so a wave
+//     loads a fragment with one coalesced 1 KB buffer load; each fragment register is re-loaded for the next tap right
+//     after the MFMAs that read it have issued.
+// LDS: 2 x 204 px x 64 B x NTERM = 51 / 76.5 KB; registers <= 168 (NTERM = 2: three waves per SIMD) / <= 256.
+#if LA_STAMP
+// dev builds only: s_memtime stamps of wave 0 of the first 4096 workgroups (la_debug_stamps reads them back)
+#define LA_NSTAMP 48
+__device__ unsigned long long la_stamps[4096 * LA_NSTAMP];
+#define STAMP(k) do { if (lane == 0 && wid == 0 && sblk < 4096) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); la_stamps[sblk * LA_NSTAMP + (k)] = t_; } } while (0)
+extern "C" int la_debug_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(la_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#else
+#define STAMP(k) do {} while (0)
+#endif
 #define HALO_W 34
 #define HALO_PX (6 * HALO_W)
+#define HPITCH 64
+#define H_UNITS (8 * HALO_PX)          // (4-channel group, halo pixel) load units per chunk
+#define H_UPT 182                      // units per tap (9 x 182 >= 1632)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 template <int MT, int FMT>
@@ -479,9 +499,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     constexpr bool F16 = FMT == FMT_F16X2;
     constexpr int TM = MT / 64;
     constexpr int EB = F16 ? 4 : 8;                // bytes per pre-split element
-    constexpr bool TAPPF = NTERM == 2;             // A fragments one whole tap ahead (else one 16-channel step ahead)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Bs = smem;                                   // [NTERM][HALO_PX][ROWB]
+    constexpr int HPLANE = HALO_PX * HPITCH;       // one term of one halo buffer
+    constexpr int HBUF = NTERM * HPLANE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][NTERM][HALO_PX][HPITCH]
     float (*red)[MT] = reinterpret_cast<float (*)[MT]>(smem);
 
     const int tid = threadIdx.x;
@@ -499,6 +519,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     const int nck = (a.C + KCB - 1) / KCB;
     const long term_elems = a.wgt_bf16_term_elems;
     const int l31 = lane & 31, lh = lane >> 5;
+#if LA_STAMP
+    const int sblk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#endif
+    STAMP(0);
     // buffer descriptors (wave-uniform): this sample's pre-split input, and the weight pack of this format
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(static_cast<const char*>(a.in_q)) + (size_t)b * a.C * HWin * EB, 0, (int)((unsigned)a.C * HWin * EB), 0x00020000);
@@ -514,80 +538,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
         wpack |= (unsigned long long)a.tap_w[t] << (4 * t);
     }
 
-    // ---- halo prefetch: work item = (halo pixel, 16-channel half); 2 * HALO_PX = 408 items, <= 2 per thread.  Every load
-    // is unconditional (clamped address; out-of-image pixels are zeroed when the registers are written to LDS, channels
-    // past C meet zero weights), so the loads of the next chunk stay in flight under this chunk's MFMAs.
-    unsigned ex[2][16], ey[NTERM == 3 ? 2 : 1][16];
-    unsigned hoff[2], hbase[2];
-    bool hok[2];
-    int hhalf[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int item = tid + 256 * it;
-        const int itc = item < 2 * HALO_PX ? item : 2 * HALO_PX - 1;
-        const int hp = itc >> 1, half = itc & 1;
+    // ---- halo slices.  Every load is unconditional (clamped address; out-of-image pixels are zeroed on the way to LDS,
+    // channels past C meet zero weights), so the compiler can count them: no wait in the tap loop is a vmcnt(0).
+    struct Slice { unsigned x[4], y[NTERM == 3 ? 4 : 1]; int wr; bool ok; };
+    auto slice_load = [&](int cc, int t, Slice& sl) {
+        const int lt = (tid + 64 * t) & 255;                      // the idle lanes rotate over the waves
+        int u = t * H_UPT + (lt < H_UPT ? lt : H_UPT - 1);
+        const bool valid = lt < H_UPT && u < H_UNITS;
+        u = u < H_UNITS ? u : H_UNITS - 1;
+        const int c4 = u / HALO_PX, hp = u - c4 * HALO_PX;
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
         const int iy = y0 + hy, ix = x0 + hx;
-        hok[it] = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        sl.ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
         const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
-        hoff[it] = (unsigned)(iyc * a.Win + ixc) * EB;
-        hbase[it] = (unsigned)(half * 16) * HWin * EB + hoff[it];
-        hhalf[it] = half;
-    }
-    auto load_halo = [&](int cc, auto fast) {
-        const unsigned sbase = (unsigned)(cc * KCB) * HWin * EB;
-        const int cmax = a.C - 1 - cc * KCB;         // last valid channel of this chunk (ragged last chunk only)
+        const unsigned off = (unsigned)(iyc * a.Win + ixc) * EB;
+        sl.wr = valid ? hp * HPITCH + ((((c4 >> 1) ^ (hp >> 2)) & 3) << 4) + (c4 & 1) * 8 : -1;
+        const bool fast = cc * KCB + KCB <= a.C;                  // uniform: only a ragged last chunk clamps channels
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                unsigned vo, so;
-                if (decltype(fast)::value) { vo = hbase[it]; so = sbase + (unsigned)j * HWin * EB; }
-                else {
-                    const int c = hhalf[it] * 16 + j;
-                    vo = (unsigned)(c < cmax ? c : cmax) * HWin * EB + hoff[it];
-                    so = sbase;
-                }
-#if LA_ABLATE == 1 || LA_ABLATE == 3 || LA_ABLATE == 5
-                ex[it][j] = vo + so; if (NTERM == 3) ey[NTERM == 3 ? it : 0][j] = vo; continue;
-#endif
-                if (NTERM == 3) {
-                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_in, vo, so, 0);
-                    ex[it][j] = v.x;
-                    ey[NTERM == 3 ? it : 0][j] = v.y;
-                } else ex[it][j] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, so, 0);
+        for (int j = 0; j < 4; ++j) {
+            unsigned vo, so;
+            if (fast) { vo = (unsigned)(c4 * 4) * HWin * EB + off; so = (unsigned)(cc * KCB + j) * HWin * EB; }
+            else {
+                const int c = cc * KCB + c4 * 4 + j;
+                vo = (unsigned)(c < a.C ? c : a.C - 1) * HWin * EB + off;
+                so = 0u;
             }
+            if (NTERM == 3) {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_in, vo, so, 0);
+                sl.x[j] = v.x;
+                sl.y[NTERM == 3 ? j : 0] = v.y;
+            } else sl.x[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, so, 0);
+        }
     };
-    auto load_halo_any = [&](int cc) {
-        if (cc * KCB + KCB <= a.C) load_halo(cc, std::true_type{});
-        else load_halo(cc, std::false_type{});
-    };
-    auto write_halo = [&]() {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int item = tid + 256 * it;
-            const int hp = item >> 1, half = item & 1;
+    auto slice_write = [&](unsigned char* buf, const Slice& sl) {
+        if (sl.wr >= 0) {
 #pragma unroll
             for (int q = 0; q < NTERM; ++q) {
-                unsigned w[8];
-#pragma unroll
-                for (int d = 0; d < 8; ++d) {
-                    const unsigned e0 = q == 2 ? ey[NTERM == 3 ? it : 0][2 * d] : ex[it][2 * d];
-                    const unsigned e1 = q == 2 ? ey[NTERM == 3 ? it : 0][2 * d + 1] : ex[it][2 * d + 1];
-                    const unsigned v = __builtin_amdgcn_perm(e1, e0, q == 1 ? 0x07060302u : 0x05040100u);
-                    w[d] = hok[it] ? v : 0u;
+                const unsigned sel = q == 1 ? 0x07060302u : 0x05040100u;
+                unsigned w0, w1;
+                if (q == 2) {
+                    w0 = __builtin_amdgcn_perm(sl.y[NTERM == 3 ? 1 : 0], sl.y[0], sel);
+                    w1 = __builtin_amdgcn_perm(sl.y[NTERM == 3 ? 3 : 0], sl.y[NTERM == 3 ? 2 : 0], sel);
+                } else {
+                    w0 = __builtin_amdgcn_perm(sl.x[1], sl.x[0], sel);
+                    w1 = __builtin_amdgcn_perm(sl.x[3], sl.x[2], sel);
                 }
-                if (item < 2 * HALO_PX) {
-                    unsigned char* p = Bs + ((long)q * HALO_PX + hp) * ROWB + half * 32;
-                    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
-                    *reinterpret_cast<uint4*>(p + 16) = make_uint4(w[4], w[5], w[6], w[7]);
-                }
+                *reinterpret_cast<uint2*>(buf + q * HPLANE + sl.wr) = sl.ok ? make_uint2(w0, w1) : make_uint2(0u, 0u);
             }
         }
     };
 
-    // ---- A fragments straight from the pack (rows past M are clamped: their accumulator rows are never stored)
-    // (fragment-order pack: one fully coalesced 1 KB load per 32-row x 16-channel fragment)
+    // ---- A fragments straight from the fragment-order pack (blocks past M are clamped: their rows are never stored)
     const int Mp = pack_mp(a.M);
     unsigned a_off[TM];
 #pragma unroll
@@ -605,23 +606,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
         for (int q = 0; q < NTERM; ++q)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-#if LA_ABLATE == 2 || LA_ABLATE == 3 || LA_ABLATE == 5
-                { u32x4 u = {a_off[i], so, (unsigned)q, (unsigned)i}; dst[q][i] = __builtin_bit_cast(bf16x8, u); }
-#else
                 dst[q][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_off[i], so + q * term_bytes, 0));
-#endif
     };
-    const int b_lane = ((wn * 2) * HALO_W + l31) * ROWB + lh * 16;
-    auto read_b = [&](int shift, int ks, bf16x8 (&dst)[NTERM][2]) {
+    // B fragments: lane (l31, lh) of N-subtile j reads slot ks*2 + lh of halo pixel (wn*2 + j) * 34 + shift + l31
+    auto read_b = [&](const unsigned char* buf, int shift, int ks, bf16x8 (&dst)[NTERM][2]) {
 #pragma unroll
-        for (int q = 0; q < NTERM; ++q)
+        for (int j = 0; j < 2; ++j) {
+            const int p = (wn * 2 + j) * HALO_W + shift + l31;
+            const int o = p * HPITCH + ((((ks * 2 + lh) ^ (p >> 2)) & 3) << 4);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#if LA_ABLATE == 5
-                { u32x4 u = {(unsigned)shift, (unsigned)ks, (unsigned)q, (unsigned)lane}; dst[q][j] = __builtin_bit_cast(bf16x8, u); }
-#else
-                dst[q][j] = *reinterpret_cast<const bf16x8*>(Bs + ((long)q * HALO_PX + j * HALO_W + shift) * ROWB + b_lane + ks * 32);
-#endif
+            for (int q = 0; q < NTERM; ++q) dst[q][j] = *reinterpret_cast<const bf16x8*>(buf + q * HPLANE + o);
+        }
     };
 
     f32x16 acc[TM][2];
@@ -648,42 +643,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
             }
     };
 
-    bf16x8 acur[2][NTERM][TM], anxt[TAPPF ? 2 : 1][NTERM][TM];
+    // ---- prologue: chunk 0's halo (all nine slices in flight at once) and the first tap's weights
+    bf16x8 acur[2][NTERM][TM];
+    {
+        Slice pre[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) slice_load(0, t, pre[t]);
+        load_a(0, 0, 0, acur[0]);
+        load_a(0, 0, 1, acur[1]);
+#pragma unroll
+        STAMP(1);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) slice_write(smem, pre[t]);
+    }
+    STAMP(2);
+    __syncthreads();
+    STAMP(3);
+
     bf16x8 bf0[NTERM][2], bf1[NTERM][2];
-    load_halo_any(0);
-    load_a(0, 0, 0, acur[0]);
-    if (TAPPF) load_a(0, 0, 1, acur[1]);
-    for (int cc = 0; cc < nck; ++cc) {
-        __syncthreads();                       // previous chunk's MFMAs are done with the halo
-        write_halo();
-        __syncthreads();
-        if (cc + 1 < nck) load_halo_any(cc + 1);
-        read_b((int)(shpack & 127u), 0, bf0);
+    auto chunk = [&](int cc, auto has_next) {
+        constexpr bool NEXT = decltype(has_next)::value;
+        const unsigned char* cur = smem + (cc & 1) * HBUF;
+        unsigned char* nxt = smem + ((cc + 1) & 1) * HBUF;
+        Slice sl;
+        sl.wr = -1;
+        sl.ok = false;
+        read_b(cur, (int)(shpack & 127u), 0, bf0);
 #pragma unroll 1
         for (int t = 0; t < 9; ++t) {
             const int shift = (int)((shpack >> (7 * t)) & 127u);
             // the tap after this one: next tap, else first tap of the next chunk (the final one re-reads a valid slab)
             const int tn = t + 1 < 9 ? t + 1 : 0;
-            const int ccn = t + 1 < 9 ? cc : (cc + 1 < nck ? cc + 1 : 0);
+            const int ccn = t + 1 < 9 ? cc : (NEXT ? cc + 1 : 0);
             const int shift_n = (int)((shpack >> (7 * (t + 1 < 9 ? t + 1 : 8))) & 127u);   // (last tap: harmless re-read)
-            // ---- K-step 0: next fragments are issued first and fly under the MFMAs
-            if (TAPPF) { load_a(ccn, tn, 0, anxt[0]); load_a(ccn, tn, 1, anxt[TAPPF ? 1 : 0]); }
-            else load_a(cc, t, 1, acur[1]);
-            read_b(shift, 1, bf1);
-            __builtin_amdgcn_sched_barrier(0);
+            read_b(cur, shift, 1, bf1);
             mma_step(acur[0], bf0);
-            // ---- K-step 1
-            if (!TAPPF) load_a(ccn, tn, 0, acur[0]);
-            read_b(shift_n, 0, bf0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_step(acur[1], bf1);
-            if (TAPPF) {
-#pragma unroll
-                for (int q = 0; q < NTERM; ++q)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) { acur[0][q][i] = anxt[0][q][i]; acur[1][q][i] = anxt[TAPPF ? 1 : 0][q][i]; }
+            load_a(ccn, tn, 0, acur[0]);           // re-loaded as soon as its MFMAs have issued
+            if (NEXT) {
+                slice_write(nxt, sl);              // the slice loaded one tap ago
+                slice_load(cc + 1, t, sl);
             }
+            read_b(cur, shift_n, 0, bf0);
+            mma_step(acur[1], bf1);
+            load_a(ccn, tn, 1, acur[1]);
+#if LA_STAMP
+            if (cc < 4) STAMP(4 + cc * 10 + t);
+#endif
         }
+        if (NEXT) slice_write(nxt, sl);
+    };
+    for (int cc = 0; cc < nck; ++cc) {
+        if (cc + 1 < nck) chunk(cc, std::true_type{});
+        else chunk(cc, std::false_type{});
+#if LA_STAMP
+        if (cc < 4) STAMP(4 + cc * 10 + 9);
+#endif
+        __syncthreads();       // next halo complete, everyone done with this one (and, at the end, LDS free for the epilogue)
     }
     if (F16) {
         const float inv = 1.f / (a.acc_scale_w[0] * a.acc_scale_x[b]);
@@ -694,15 +709,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
     }
-    __syncthreads();     // LDS is reused by the epilogue's reduction scratch
-#if LA_ABLATE == 4
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
-#else
+    STAMP(44);
     la_conv_epilogue<MT, false, true>(a, acc, red, ntile, m0, G, G);
-#endif
+    STAMP(45);
 }
 
 // can this launch use the halo kernel?  dense stride-1 taps within +-1, grid = whole 4x32 tiles, not a split-K candidate
@@ -720,7 +729,7 @@ static void launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, 
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     const size_t lds128 = (size_t)NTERM * (128 + NT) * ROWB, lds64 = (size_t)NTERM * (64 + NT) * ROWB;
     if (!split && halo_ok(as)) {
-        const size_t h128 = (size_t)NTERM * HALO_PX * ROWB, h64 = h128;      // >= the epilogue's 2 * MT floats
+        const size_t h128 = (size_t)2 * NTERM * HALO_PX * HPITCH, h64 = h128;      // two halo buffers (>= the epilogue's 2 * MT floats)
         static bool attr_done = false;
         if (!attr_done) {      // > 64 KB of dynamic LDS needs the opt-in (idempotent)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h128);

@@ -15,7 +15,7 @@ __device__ __forceinline__ float la_conv_epi_fwd(const LaConvArgs& a, float v, f
 // TILE2D: the 128 pixels of a tile are 4 rows x 32 columns of the output grid (halo kernel) instead of 128 consecutive
 // grid positions; wave N-subtile (wn, j) is then row wn*2 + j of the tile.
 template <int MT, bool SPLIT, bool TILE2D = false>
-__device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&acc)[MT / 64][2], float (*red)[MT],
+__device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&acc)[MT / 64][2], float (*red)[MT],   // red: [4][MT] LDS floats
                                                  int ntile, int m0, int G, int Ntot) {
     constexpr int TM = MT / 64;
     const int tid = threadIdx.x;
@@ -42,6 +42,116 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
     }
 
     const int b = blockIdx.z;
+    // ---- fast path: the whole MT x 128 tile is inside the output (block-uniform).  Straight-line code: per-row parameters
+    // come from LDS (staged with one coalesced load), every global load is unconditional and issued in one batch, so the
+    // 64 stores of a lane are not serialised behind 32 dependent round trips to L2/HBM.
+    if (m0 + MT <= a.M && (TILE2D || (ntile + 1) * NT <= G)) {
+        float* prm = &red[2][0];                         // [2][MT] row parameters (red[0..1] stay the ds_part scratch)
+        long np[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int gy, gx;
+            if (TILE2D) {
+                const int tpr = a.Gx >> 5;
+                const int tyb = ntile / tpr, txb = ntile - tyb * tpr;
+                gy = tyb * 4 + wn * 2 + j; gx = txb * 32 + l31;
+            } else {
+                const int g = ntile * NT + wn * 64 + j * 32 + l31;
+                gy = g / a.Gx; gx = g - gy * a.Gx;
+            }
+            np[j] = (long)(gy * a.out_sy + a.out_oy) * a.Wout + (gx * a.out_sx + a.out_ox);
+        }
+        const long HWo = (long)a.Hout * a.Wout;
+        const int mw = wm * (MT / 2) + 4 * lh;            // first row of this lane inside the tile
+        float* o0 = a.out + ((long)b * a.M + m0 + mw) * HWo;
+        if (a.epi == LA_EPI_BWD) {
+            const float* os_b = a.out_scale ? a.out_scale + (long)b * a.oscale_stride : nullptr;
+            if (tid < MT) prm[tid] = os_b ? os_b[m0 + tid] : 1.f;
+            const float* x0 = a.xin ? a.xin + (long)b * a.xin_bstride + (long)(m0 + mw) * HWo : nullptr;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float xv[16][2];
+                if (x0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) xv[r][j] = x0[(long)(i * 32 + (r & 3) + 8 * (r >> 2)) * HWo + np[j]];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mr = i * 32 + (r & 3) + 8 * (r >> 2);
+                    const float sc = prm[mw + mr];
+                    float part = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float v = acc[i][j][r];
+                        o0[(long)mr * HWo + np[j]] = v * sc;
+                        if (x0) part += v * xv[r][j];
+                    }
+                    if (a.ds_part) {
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                        if (l31 == 0) red[wn][mw + mr] = part;
+                    }
+                }
+            }
+            if (a.ds_part) {
+                __syncthreads();
+                if (tid < MT) a.ds_part[((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile] = red[0][tid] + red[1][tid];
+            }
+            return;
+        }
+        const bool fwd = a.epi == LA_EPI_FWD;
+        float nz[2] = {0.f, 0.f};
+        if (fwd) {
+            const float* dm_b = a.demod ? a.demod + (long)b * a.demod_stride : nullptr;
+            if (tid < MT) {
+                prm[tid] = dm_b ? dm_b[m0 + tid] : 1.f;
+                prm[MT + tid] = a.bias ? a.bias[m0 + tid] : 0.f;
+            }
+            if (a.noise) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) nz[j] = a.noise[(long)b * a.noise_bstride + np[j]] * a.noise_strength;
+            }
+            __syncthreads();
+        }
+        // activation as straight-line selects (same arithmetic as la_act_fwd)
+        const float slope = a.act == LA_ACT_LRELU ? a.alpha : (a.act == LA_ACT_RELU ? 0.f : 1.f);
+        const float cl = a.clamp >= 0.f ? a.clamp : __builtin_huge_valf();
+        float* o2 = (fwd && a.out2) ? a.out2 + ((long)b * a.M + m0 + mw) * HWo : nullptr;
+        const float* ad = (o2 && a.addend) ? a.addend + ((long)b * a.M + m0 + mw) * HWo : nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float av[16][2];
+            if (ad) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) av[r][j] = ad[(long)(i * 32 + (r & 3) + 8 * (r >> 2)) * HWo + np[j]];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = i * 32 + (r & 3) + 8 * (r >> 2);
+                const float dmv = fwd ? prm[mw + mr] : 1.f, bv = fwd ? prm[MT + mw + mr] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v = acc[i][j][r];
+                    if (fwd) {
+                        v = v * dmv + nz[j] + bv;
+                        v = v > 0.f ? v : v * slope + 0.f;
+                        v *= a.gain;
+                        v = fminf(fmaxf(v, -cl), cl);
+                    }
+                    o0[(long)mr * HWo + np[j]] = v;
+                    if (o2) o2[(long)mr * HWo + np[j]] = v + (ad ? av[r][j] : 0.f);
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- generic path (ragged tiles): every access guarded
     bool pix_ok[2];
     long npos[2];
 #pragma unroll
