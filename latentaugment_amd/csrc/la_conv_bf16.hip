@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void la_presplit_kernel(const float* __restric
 // fp16 path, pass 1: max |x * scale| of every (b, c) plane in PM_NS segments, one workgroup per segment (no atomics);
 // pass 2: each workgroup reduces its sample's segment maxima, derives the power-of-two scale and splits.
 #define PM_NS 8
+#define PS_SEG 8192                // elements per workgroup of the fp16 pre-split pass
 __global__ __launch_bounds__(256) void la_plane_absmax_kernel(const float* __restrict__ in, long in_bstride,
                                                              const float* __restrict__ scale, int scale_stride,
                                                              float* __restrict__ pm, int C, long HW, int ns) {
@@ -250,14 +251,34 @@ __global__ __launch_bounds__(256) void la_presplit_f16_kernel(const float* __res
     __syncthreads();
     const float xs = la_pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
     if (blockIdx.x == 0 && c == 0 && threadIdx.x == 0) xscale[b] = xs;
-    const float sc = (scale ? scale[(long)b * scale_stride + c] : 1.f);
+    const float sc = (scale ? scale[(long)b * scale_stride + c] : 1.f) * xs;
     const float* ip = in + (long)b * in_bstride + (long)c * HW;
     unsigned* op = out + ((long)b * C + c) * HW;
-    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
-        const float v = ip[p] * sc * xs;
+    auto split = [](float v) -> unsigned {
         const _Float16 h = (_Float16)v;
         const _Float16 l = (_Float16)(v - (float)h);
-        op[p] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+        return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+    };
+    // each workgroup owns PS_SEG consecutive elements of the plane
+    const long p0 = (long)blockIdx.x * PS_SEG, p1 = p0 + PS_SEG < HW ? p0 + PS_SEG : HW;
+    if ((((size_t)ip | (size_t)op | (size_t)(HW * 4)) & 15) == 0) {          // aligned plane: 16-byte loads and stores
+        const float4* ip4 = reinterpret_cast<const float4*>(ip);
+        uint4* op4 = reinterpret_cast<uint4*>(op);
+        long q = p0 / 4 + threadIdx.x;
+        const long q1 = p1 / 4;
+        for (; q + 768 < q1; q += 1024) {
+            const float4 v0 = ip4[q], v1 = ip4[q + 256], v2 = ip4[q + 512], v3 = ip4[q + 768];
+            op4[q] = make_uint4(split(v0.x * sc), split(v0.y * sc), split(v0.z * sc), split(v0.w * sc));
+            op4[q + 256] = make_uint4(split(v1.x * sc), split(v1.y * sc), split(v1.z * sc), split(v1.w * sc));
+            op4[q + 512] = make_uint4(split(v2.x * sc), split(v2.y * sc), split(v2.z * sc), split(v2.w * sc));
+            op4[q + 768] = make_uint4(split(v3.x * sc), split(v3.y * sc), split(v3.z * sc), split(v3.w * sc));
+        }
+        for (; q < q1; q += 256) {
+            const float4 v = ip4[q];
+            op4[q] = make_uint4(split(v.x * sc), split(v.y * sc), split(v.z * sc), split(v.w * sc));
+        }
+    } else {
+        for (long p = p0 + threadIdx.x; p < p1; p += 256) op[p] = split(ip[p] * sc);
     }
 }
 
@@ -282,8 +303,8 @@ int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
         ns = ns < 1 ? 1 : (ns > PM_NS ? PM_NS : ns);
         hipLaunchKernelGGL(la_plane_absmax_kernel, dim3(ns, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
                            a.scale_stride, pm, a.C, HW, ns);
-        hipLaunchKernelGGL(la_presplit_f16_kernel, dim3(gx, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
-                           a.scale_stride, pm, xscale, (unsigned*)q, a.C, HW, ns);
+        hipLaunchKernelGGL(la_presplit_f16_kernel, dim3(la_cdiv(HW, PS_SEG), a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride,
+                           a.in_scale, a.scale_stride, pm, xscale, (unsigned*)q, a.C, HW, ns);
         a.acc_scale_x = xscale;
     } else {
         hipLaunchKernelGGL(la_presplit_kernel, dim3(gx, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
@@ -298,16 +319,25 @@ int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Flat variant: 128 consecutive grid positions per tile, any stride / tap table / ragged grid, optional split-K.
+//   * B (pixels): thread (pixel, 16-channel half) gathers the tap-shifted inputs of one (chunk, tap) step with 16
+//     unconditional buffer loads (clamped addresses; out-of-image pixels are zeroed on the way to LDS), one step ahead,
+//     into the other of two swizzled LDS buffers (64-byte rows, slots XOR (row >> 2) & 3): ONE barrier per step.
+//   * A (weights): MFMA fragments straight from the fragment-order pack, re-loaded for the next step right after the
+//     MFMAs that read them have issued.  Never in LDS.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define BPITCH 64
 template <int MT, bool SPLIT, int FMT>
-__global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void la_conv_bf16_kernel(LaConvArgs a) {
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     constexpr bool F16 = FMT == FMT_F16X2;
     constexpr int TM = MT / 64;
-    constexpr int A_U = (MT * 4) / 256;            // 16-byte units of one term's A slab per thread (2 for MT=128, 1 for 64)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                                   // [NTERM][MT][ROWB]
-    unsigned char* Bs = smem + NTERM * MT * ROWB;               // [NTERM][NT][ROWB]
-    float (*red)[MT] = reinterpret_cast<float (*)[MT]>(smem);   // reused after the K loop (2*MT floats)
+    constexpr int EB = F16 ? 4 : 8;                // bytes per pre-split element
+    constexpr int BPLANE = NT * BPITCH;            // one term of one pixel buffer
+    constexpr int BBUF = NTERM * BPLANE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][NTERM][NT][BPITCH]
+    float (*red)[MT] = reinterpret_cast<float (*)[MT]>(smem);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -319,8 +349,9 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
     const int m0 = blockIdx.y * MT;
     const int G = a.Gy * a.Gx;
     const int Ntot = SPLIT ? a.B * G : G;
+    const int l31 = lane & 31, lh = lane >> 5;
 
-    // ---- loader roles: thread = (pixel n_l, 16-channel half khalf)
+    // ---- loader role: thread = (pixel n_l, 16-channel half khalf)
     const int n_l = tid & (NT - 1);
     const int khalf = tid >> 7;
     const int nidx_l = ntile * NT + n_l;
@@ -330,7 +361,7 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
     const int gy_l = nvalid ? g_l / a.Gx : 0;
     const int gx_l = nvalid ? g_l - gy_l * a.Gx : 0;
     const int iy0 = gy_l * a.in_sy, ix0 = gx_l * a.in_sx;
-    const long HWin = (long)a.Hin * a.Win;
+    const unsigned HWin = (unsigned)(a.Hin * a.Win);
 
     const int nck = (a.C + KCB - 1) / KCB;
     int ck_beg = 0, ck_end = nck;
@@ -339,66 +370,101 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
         ck_beg = blockIdx.z * per;
         ck_end = ck_beg + per < nck ? ck_beg + per : nck;
     }
-    const int ci_beg = ck_beg * a.ntaps, ci_end = ck_end * a.ntaps;
-    const long term_elems = a.wgt_bf16_term_elems;    // elements per term in the packed weights
-    const __bf16* wbase = reinterpret_cast<const __bf16*>(static_cast<const char*>(a.wgt_bf16) + (F16 ? pack_f16_offset(term_elems) : 0));
+    const int ntaps = a.ntaps;
+    const int nstep = ck_end > ck_beg ? (ck_end - ck_beg) * ntaps : 0;
+    const long term_elems = a.wgt_bf16_term_elems;
+    // buffer descriptors (wave-uniform).  Direct mode: this sample's pre-split input; split-K: the whole batch.
+    const unsigned samp_bytes = (unsigned)a.C * HWin * EB;
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(a.in_q)) + (SPLIT ? (size_t)0 : (size_t)blockIdx.z * samp_bytes), 0,
+        (int)(SPLIT ? samp_bytes * (unsigned)a.B : samp_bytes), 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(a.wgt_bf16)) + (F16 ? pack_f16_offset(term_elems) : 0), 0, (int)(NTERM * term_elems * 2),
+        0x00020000);
+    const unsigned lane_base = (SPLIT ? (unsigned)b_l * samp_bytes : 0u) + (unsigned)(khalf * 16) * HWin * EB;
 
-    const uint2* inq_b = reinterpret_cast<const uint2*>(a.in_q) + (long)b_l * a.C * HWin;
-    const unsigned* inq16_b = reinterpret_cast<const unsigned*>(a.in_q) + (long)b_l * a.C * HWin;
-    uint2 breg[16];
-    uint4 areg[NTERM][A_U];
+    // tap table -> packed scalars (offsets are within +-7), so the step loop needs no indexed kernarg reads
+    unsigned long long dypack = 0ull, dxpack = 0ull, wpack = 0ull;
+#pragma unroll
+    for (int t = 0; t < LA_CONV_MAX_TAPS; ++t) {
+        dypack |= (unsigned long long)((a.tap_dy[t] + 8) & 15) << (4 * t);
+        dxpack |= (unsigned long long)((a.tap_dx[t] + 8) & 15) << (4 * t);
+        wpack |= (unsigned long long)(a.tap_w[t] & 15) << (4 * t);
+    }
 
-    auto prefetch = [&](int ci) {
-        const int cc = ci / a.ntaps;
-        const int t = ci - cc * a.ntaps;
-        const int c0 = cc * KCB + khalf * 16;
-        const int iy = iy0 + a.tap_dy[t], ix = ix0 + a.tap_dx[t];
-        const bool ok = nvalid && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        const long off = (long)iy * a.Win + ix;
+    // ---- B gather of one step: 16 channels of this thread's pixel
+    unsigned ex[16], ey[NTERM == 3 ? 16 : 1];
+    bool ok_r = false;
+    auto load_b = [&](int cc, int t) {
+        const int iy = iy0 + (int)((dypack >> (4 * t)) & 15u) - 8, ix = ix0 + (int)((dxpack >> (4 * t)) & 15u) - 8;
+        ok_r = nvalid && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
+        const unsigned off = (unsigned)(iyc * a.Win + ixc) * EB;
+        const bool fast = cc * KCB + KCB <= a.C;                  // uniform: only a ragged last chunk clamps channels
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int c = c0 + j;
-            uint2 v = make_uint2(0u, 0u);
-            if (ok && c < a.C) {
-                if (F16) v.x = inq16_b[(long)c * HWin + off];
-                else v = inq_b[(long)c * HWin + off];
+            unsigned vo, so;
+            if (fast) { vo = lane_base + off; so = (unsigned)(cc * KCB + j) * HWin * EB; }
+            else {
+                const int c = cc * KCB + khalf * 16 + j;
+                vo = lane_base - (unsigned)(khalf * 16) * HWin * EB + (unsigned)(c < a.C ? c : a.C - 1) * HWin * EB + off;
+                so = 0u;
             }
-            breg[j] = v;
+            if (NTERM == 3) {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_in, vo, so, 0);
+                ex[j] = v.x;
+                ey[NTERM == 3 ? j : 0] = v.y;
+            } else ex[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, so, 0);
         }
-        // A: (tap slab, channel chunk) slab in fragment order (pack_slab_offset); rows m0 .. m0+MT
-        const int Mp = pack_mp(a.M);
-        const __bf16* slab = wbase + ((long)a.tap_w[t] * nck + cc) * Mp * KCB;
-#pragma unroll
-        for (int q = 0; q < NTERM; ++q)
-#pragma unroll
-            for (int u = 0; u < A_U; ++u) {
-                const int unit = tid + 256 * u;          // 16-byte unit of the LDS image: row = unit/4, piece = unit%4
-                const int row = m0 + (unit >> 2), piece = unit & 3;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (row < Mp) v = *reinterpret_cast<const uint4*>(slab + (long)q * term_elems + pack_slab_offset(row, piece * 8));
-                areg[q][u] = v;
-            }
     };
-    auto stage = [&]() {
-        // pack term q of 16 consecutive channels k-contiguous: dword d = term(2d) | term(2d+1) << 16   (v_perm_b32)
+    const int wrow = n_l * BPITCH, wsw = (n_l >> 2) & 3;
+    auto write_b = [&](unsigned char* buf) {
 #pragma unroll
         for (int q = 0; q < NTERM; ++q) {
+            const unsigned sel = q == 1 ? 0x07060302u : 0x05040100u;
             unsigned w[8];
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
-                const unsigned e0 = q == 2 ? breg[2 * d].y : breg[2 * d].x;
-                const unsigned e1 = q == 2 ? breg[2 * d + 1].y : breg[2 * d + 1].x;
-                w[d] = __builtin_amdgcn_perm(e1, e0, q == 1 ? 0x07060302u : 0x05040100u);
+                const unsigned e0 = q == 2 ? ey[NTERM == 3 ? 2 * d : 0] : ex[2 * d];
+                const unsigned e1 = q == 2 ? ey[NTERM == 3 ? 2 * d + 1 : 0] : ex[2 * d + 1];
+                const unsigned v = __builtin_amdgcn_perm(e1, e0, sel);
+                w[d] = ok_r ? v : 0u;
             }
-            unsigned char* p = Bs + ((long)q * NT + n_l) * ROWB + khalf * 32;
-            *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
-            *reinterpret_cast<uint4*>(p + 16) = make_uint4(w[4], w[5], w[6], w[7]);
-#pragma unroll
-            for (int u = 0; u < A_U; ++u) {
-                const int unit = tid + 256 * u;
-                *reinterpret_cast<uint4*>(As + ((long)q * MT + (unit >> 2)) * ROWB + (unit & 3) * 16) = areg[q][u];
-            }
+            unsigned char* p = buf + q * BPLANE + wrow;
+            *reinterpret_cast<uint4*>(p + ((((khalf * 2) ^ wsw) & 3) << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<uint4*>(p + ((((khalf * 2 + 1) ^ wsw) & 3) << 4)) = make_uint4(w[4], w[5], w[6], w[7]);
         }
+    };
+    // B fragments: lane (l31, lh) of N-subtile j reads slot ks*2 + lh of row wn*64 + j*32 + l31
+    const int rsw = (l31 >> 2) & 3;
+    const int rbase = (wn * 64 + l31) * BPITCH;
+    auto read_b = [&](const unsigned char* buf, int ks, bf16x8 (&dst)[NTERM][2]) {
+        const int o = rbase + ((((ks * 2 + lh) ^ rsw) & 3) << 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < NTERM; ++q) dst[q][j] = *reinterpret_cast<const bf16x8*>(buf + q * BPLANE + j * 32 * BPITCH + o);
+    };
+
+    // ---- A fragments straight from the fragment-order pack (blocks past M are clamped: their rows are never stored)
+    const int Mp = pack_mp(a.M);
+    unsigned a_off[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int mblk = (m0 + wm * (MT / 2) + i * 32) >> 5;
+        mblk = mblk < (Mp >> 5) ? mblk : (Mp >> 5) - 1;
+        a_off[i] = (unsigned)mblk * 2048u + (unsigned)lane * 16u;
+    }
+    const unsigned slab_bytes = (unsigned)Mp * KCB * 2u;         // one (tap, chunk) slab of one term
+    const unsigned term_bytes = (unsigned)term_elems * 2u;
+    auto load_a = [&](int cc, int t, int ks, bf16x8 (&dst)[NTERM][TM]) {
+        const unsigned tw = (unsigned)((wpack >> (4 * t)) & 15u);
+        const unsigned so = (tw * nck + cc) * slab_bytes + ks * 1024;
+#pragma unroll
+        for (int q = 0; q < NTERM; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                dst[q][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_off[i], so + q * term_bytes, 0));
     };
 
     f32x16 acc[TM][2];
@@ -408,40 +474,55 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int l31 = lane & 31, lh = lane >> 5;
-    if (ci_beg < ci_end) prefetch(ci_beg);
-    for (int ci = ci_beg; ci < ci_end; ++ci) {
-        __syncthreads();                 // everyone is done reading the previous chunk
-        stage();
-        __syncthreads();
-        if (ci + 1 < ci_end) prefetch(ci + 1);     // global loads fly under the MFMAs below
+    auto mma_step = [&](bf16x8 (&af)[NTERM][TM], bf16x8 (&bf)[NTERM][2]) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[NTERM][TM], bf[NTERM][2];
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < NTERM; ++q) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    af[q][i] = *reinterpret_cast<const bf16x8*>(As + ((long)q * MT + wm * (MT / 2) + i * 32 + l31) * ROWB + ks * 32 + lh * 16);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    bf[q][j] = *reinterpret_cast<const bf16x8*>(Bs + ((long)q * NT + wn * 64 + j * 32 + l31) * ROWB + ks * 32 + lh * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    // smallest products first, so they are not swamped by the leading term inside the accumulator
-                    if constexpr (NTERM == 3) {
-                        acc[i][j] = la_mma<F16>(af[2][i], bf[0][j], acc[i][j]);   // lh
-                        acc[i][j] = la_mma<F16>(af[0][i], bf[2][j], acc[i][j]);   // hl
-                        acc[i][j] = la_mma<F16>(af[1][i], bf[1][j], acc[i][j]);   // mm
-                    }
-                    acc[i][j] = la_mma<F16>(af[1][i], bf[0][j], acc[i][j]);   // mh
-                    acc[i][j] = la_mma<F16>(af[0][i], bf[1][j], acc[i][j]);   // hm
-                    acc[i][j] = la_mma<F16>(af[0][i], bf[0][j], acc[i][j]);   // hh
+            for (int j = 0; j < 2; ++j) {
+                // smallest products first, so they are not swamped by the leading term inside the accumulator
+                if constexpr (NTERM == 3) {
+                    acc[i][j] = la_mma<F16>(af[2][i], bf[0][j], acc[i][j]);   // lh
+                    acc[i][j] = la_mma<F16>(af[0][i], bf[2][j], acc[i][j]);   // hl
+                    acc[i][j] = la_mma<F16>(af[1][i], bf[1][j], acc[i][j]);   // mm
                 }
+                acc[i][j] = la_mma<F16>(af[1][i], bf[0][j], acc[i][j]);   // mh
+                acc[i][j] = la_mma<F16>(af[0][i], bf[1][j], acc[i][j]);   // hm
+                acc[i][j] = la_mma<F16>(af[0][i], bf[0][j], acc[i][j]);   // hh
+            }
+    };
+
+    if (nstep > 0) {
+        // (chunk, tap) of steps s, s+1, s+2; past the end they stay on the last valid step (harmless re-loads)
+        int c1 = ck_beg, t1 = 0;
+        auto adv = [&](int& c, int& t) {
+            if (t + 1 < ntaps) ++t;
+            else if (c + 1 < ck_end) { ++c; t = 0; }
+        };
+        bf16x8 acur[2][NTERM][TM], bf0[NTERM][2], bf1[NTERM][2];
+        load_b(c1, t1);
+        load_a(c1, t1, 0, acur[0]);
+        load_a(c1, t1, 1, acur[1]);
+        adv(c1, t1);                                   // (c1, t1) = step 1
+        int c2 = c1, t2 = t1;
+        write_b(smem);
+        __syncthreads();
+        load_b(c1, t1);
+        adv(c2, t2);                                   // (c2, t2) = step 2
+#pragma unroll 1
+        for (int s = 0; s < nstep; ++s) {
+            const unsigned char* cur = smem + (s & 1) * BBUF;
+            unsigned char* nxt = smem + ((s + 1) & 1) * BBUF;
+            read_b(cur, 0, bf0);
+            read_b(cur, 1, bf1);
+            write_b(nxt);                              // step s+1 (loaded during step s-1)
+            load_b(c2, t2);                            // step s+2
+            mma_step(acur[0], bf0);
+            load_a(c1, t1, 0, acur[0]);                // re-loaded as soon as its MFMAs have issued
+            mma_step(acur[1], bf1);
+            load_a(c1, t1, 1, acur[1]);
+            c1 = c2; t1 = t2;
+            adv(c2, t2);
+            __syncthreads();
         }
     }
     if (F16) {
@@ -458,7 +539,6 @@ __global__ __launch_bounds__(256) void la_conv_bf16_kernel(LaConvArgs a) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
         }
     }
-    __syncthreads();     // LDS is reused by the epilogue's reduction scratch
     la_conv_epilogue<MT, SPLIT>(a, acc, red, ntile, m0, G, Ntot);
 }
 
@@ -491,8 +571,6 @@ extern "C" int la_debug_stamps(unsigned long long* out, int n) {
 #define HPITCH 64
 #define H_UNITS (8 * HALO_PX)          // (4-channel group, halo pixel) load units per chunk
 #define H_UPT 182                      // units per tap (9 x 182 >= 1632)
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 template <int MT, int FMT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void la_conv_bf16_halo_kernel(LaConvArgs a) {
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
@@ -727,7 +805,7 @@ static bool halo_ok(const LaConvArgs& a) {
 template <int FMT>
 static void launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, hipStream_t stream) {
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
-    const size_t lds128 = (size_t)NTERM * (128 + NT) * ROWB, lds64 = (size_t)NTERM * (64 + NT) * ROWB;
+    const size_t lds128 = (size_t)2 * NTERM * NT * BPITCH, lds64 = lds128;     // two pixel buffers (>= the epilogue's 4 * MT floats)
     if (!split && halo_ok(as)) {
         const size_t h128 = (size_t)2 * NTERM * HALO_PX * HPITCH, h64 = h128;      // two halo buffers (>= the epilogue's 2 * MT floats)
         static bool attr_done = false;
