@@ -30,9 +30,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (not
 # fp32-equivalent peak of each contraction mode: one fp32 product = 1 fp32 MFMA, or 6 / 3 bf16 MFMAs of the split scheme
 CONTRACTION = {
     'f32': dict(peak=MFMA_F32_PEAK_TFLOPS, kernel='la_conv_igemm_kernel (fp32 MFMA 32x32x2, exact fp32)', mfma_per_product=1),
-    'bf16x3': dict(peak=MFMA_BF16_PEAK_TFLOPS / 6, kernel='la_conv_bf16_kernel<NTERM=3> (fp32 split into 3 bf16 terms, 6 bf16 '
+    'bf16x3': dict(peak=MFMA_BF16_PEAK_TFLOPS / 6, kernel='la_conv_bf16_halo_kernel / la_conv_bf16_kernel <FMT_BF16X3> (fp32 split into 3 bf16 terms, 6 bf16 '
                    'MFMA 32x32x16 per product, fp32 accumulate; fp32-class error)', mfma_per_product=6),
-    'f16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_kernel<FMT_F16X2> (fp32 scaled by powers of two and split into '
+    'f16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_halo_kernel / la_conv_bf16_kernel <FMT_F16X2> (fp32 scaled by powers of two and split into '
                   '2 fp16 terms, 3 fp16 MFMA 32x32x16 per product, fp32 accumulate; fp32-class error)', mfma_per_product=3),
     'bf16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_kernel<NTERM=2> (2 bf16 terms, 3 bf16 MFMA per product; '
                    'approximate mode)', mfma_per_product=3),
@@ -49,8 +49,9 @@ def parse():
     p.add_argument('--res', type=int, default=256)
     p.add_argument('--channel-base', type=int, default=32768, help='32768 = config-f, 16384 = config-e')
     p.add_argument('--criterion-mode', default='gemm', choices=['gemm', 'collapsed'])
-    p.add_argument('--precision', default='bf16x3', choices=['f32', 'f16x2', 'bf16x3', 'bf16x2'],
-                   help='contraction arithmetic: exact fp32 MFMA, or fp32 split into 3 / 2 bf16 terms on the bf16 MFMA')
+    p.add_argument('--precision', default='f16x2', choices=['f32', 'f16x2', 'bf16x3', 'bf16x2'],
+                   help='contraction arithmetic: exact fp32 MFMA, or fp32 operands split into 2 scaled fp16 / 3 bf16 / 2 bf16 terms '
+                        'on the 16-bit MFMA (fp32 accumulate); f16x2 and bf16x3 have fp32-class error')
     p.add_argument('--w-disc', type=float, default=0.0, help='discriminator criterion weight (BASELINE.md second run: 0.01)')
     p.add_argument('--preset', default='B', choices=['B', 'E'],
                    help="B: BASELINE.json configs[1] (the metric's config). E: configs[4] per-GPU shape -- config-e 256^2, all four "

@@ -282,7 +282,10 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
     }
     if (as.splitk_ws && G <= SPLITK_MAX_G && nck >= 2) {
         const int ntiles_flat = la_cdiv((long)a.B * G, NT);
-        int ks = la_cdiv(768, (long)ntiles_flat * mtiles);
+        // fill the 512 resident workgroup slots (2 per CU) in ONE round: a second, half-empty round costs more than the
+        // longer K loop of fewer slices (and a longer K loop amortises the prologue / epilogue better)
+        // (the fp32 kernel keeps 3 workgroups per CU: 768 slots, rounded up as before)
+        int ks = bf ? (int)(512 / ((long)ntiles_flat * mtiles)) : la_cdiv(768, (long)ntiles_flat * mtiles);
         if (ks > nck) ks = nck;
         if (ks >= 2) {
             const int per = la_cdiv(nck, ks);

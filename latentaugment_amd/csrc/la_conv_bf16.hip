@@ -512,13 +512,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
         for (int s = 0; s < nstep; ++s) {
             const unsigned char* cur = smem + (s & 1) * BBUF;
             unsigned char* nxt = smem + ((s + 1) & 1) * BBUF;
+            // (the fences pin the issue order: left alone, the scheduler sinks every load to just before its first use)
             read_b(cur, 0, bf0);
             read_b(cur, 1, bf1);
             write_b(nxt);                              // step s+1 (loaded during step s-1)
             load_b(c2, t2);                            // step s+2
+            __builtin_amdgcn_sched_barrier(0);
             mma_step(acur[0], bf0);
+            __builtin_amdgcn_sched_barrier(0);
             load_a(c1, t1, 0, acur[0]);                // re-loaded as soon as its MFMAs have issued
+            __builtin_amdgcn_sched_barrier(0);
             mma_step(acur[1], bf1);
+            __builtin_amdgcn_sched_barrier(0);
             load_a(c1, t1, 1, acur[1]);
             c1 = c2; t1 = t2;
             adv(c2, t2);
@@ -754,15 +759,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
             const int tn = t + 1 < 9 ? t + 1 : 0;
             const int ccn = t + 1 < 9 ? cc : (NEXT ? cc + 1 : 0);
             const int shift_n = (int)((shpack >> (7 * (t + 1 < 9 ? t + 1 : 8))) & 127u);   // (last tap: harmless re-read)
-            read_b(cur, shift, 1, bf1);
+            // (the fences pin the issue order: left alone, the scheduler sinks every load to just before its first use)
+            read_b(cur, shift, 1, bf1);            // B of K-step 1 flies under the MFMAs of K-step 0
+            __builtin_amdgcn_sched_barrier(0);
             mma_step(acur[0], bf0);
+            __builtin_amdgcn_sched_barrier(0);
             load_a(ccn, tn, 0, acur[0]);           // re-loaded as soon as its MFMAs have issued
+            read_b(cur, shift_n, 0, bf0);          // B of the next tap's K-step 0
             if (NEXT) {
                 slice_write(nxt, sl);              // the slice loaded one tap ago
                 slice_load(cc + 1, t, sl);
             }
-            read_b(cur, shift_n, 0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
             mma_step(acur[1], bf1);
+            __builtin_amdgcn_sched_barrier(0);
             load_a(ccn, tn, 1, acur[1]);
 #if LA_STAMP
             if (cc < 4) STAMP(4 + cc * 10 + t);

@@ -54,7 +54,7 @@ int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_st
                      hipStream_t);
 int la_seam_slabs(long HW);
 int la_seam_backward(const LaSeamArgs& a, int B, int imgc, hipStream_t);
-int la_style_backward_conv(const float* ds_part, int ntiles, const float* ddn_part, int nslabs, const float* d,
+int la_style_backward_conv(float* ds_part, int ntiles, float* ddn_part, int nslabs, const float* d,
                            int d_stride, const float* s, int s_stride, const float* wsq, int cin, int cout, int B,
                            float* ds_out, int ds_stride, hipStream_t);
 int la_style_backward_rgb(const float* dweff_part, int nslabs, const float* wrgb, int C, int imgc, int B,

@@ -166,12 +166,88 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_kernel(const float* __restri
     }
 }
 
+// Small planes (<= 64x64): the pixel grid alone cannot fill the chip and one thread walking all C channels is a chain of
+// dependent-latency loads, so the channels are split over PARTS thread groups and combined through LDS in a fixed order.
+template <int IMGC>
+__global__ __launch_bounds__(256) void la_torgb_fwd_small_kernel(const float* __restrict__ x, const float* __restrict__ wrgb,
+                                                                const float* __restrict__ s, int s_stride,
+                                                                const float* __restrict__ bias, const float* __restrict__ skip,
+                                                                float* __restrict__ rgb_pre, float* __restrict__ img, int C,
+                                                                long HW, float clamp, int px_lanes) {
+    extern __shared__ float sm[];     // weff [IMGC][C]  then  comb [parts][px_lanes][IMGC] float4
+    float* weff = sm;
+    float4* comb = reinterpret_cast<float4*>(sm + ((IMGC * C + 3) & ~3));
+    const int b = blockIdx.y;
+    for (int k = threadIdx.x; k < IMGC * C; k += blockDim.x) {
+        const int i = k % C;
+        weff[k] = wrgb[k] * (s ? s[(long)b * s_stride + i] : 1.f);
+    }
+    __syncthreads();
+    const int parts = 256 / px_lanes;
+    const int pl = threadIdx.x % px_lanes, part = threadIdx.x / px_lanes;
+    const long p4 = ((long)blockIdx.x * px_lanes + pl) * 4;
+    const int per = (C + parts - 1) / parts;
+    const int i0 = part * per, i1 = i0 + per < C ? i0 + per : C;
+    const float* xb = x + (long)b * C * HW + p4;
+    float4 acc[IMGC];
+#pragma unroll
+    for (int c = 0; c < IMGC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p4 < HW) {
+#pragma unroll 8
+        for (int i = i0; i < i1; ++i) {
+            const float4 xv = *reinterpret_cast<const float4*>(xb + (long)i * HW);
+#pragma unroll
+            for (int c = 0; c < IMGC; ++c) {
+                const float wv = weff[c * C + i];
+                acc[c].x += wv * xv.x; acc[c].y += wv * xv.y; acc[c].z += wv * xv.z; acc[c].w += wv * xv.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < IMGC; ++c) comb[(part * px_lanes + pl) * IMGC + c] = acc[c];
+    __syncthreads();
+    if (part != 0 || p4 >= HW) return;
+#pragma unroll
+    for (int c = 0; c < IMGC; ++c) {
+        float4 t = comb[pl * IMGC + c];
+        for (int q = 1; q < parts; ++q) {
+            const float4 u = comb[(q * px_lanes + pl) * IMGC + c];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        const float bv = bias ? bias[c] : 0.f;
+        float4 v = make_float4(t.x + bv, t.y + bv, t.z + bv, t.w + bv);
+        const long o = ((long)b * IMGC + c) * HW + p4;
+        if (rgb_pre) *reinterpret_cast<float4*>(rgb_pre + o) = v;
+        if (clamp >= 0.f) {
+            v.x = fminf(fmaxf(v.x, -clamp), clamp); v.y = fminf(fmaxf(v.y, -clamp), clamp);
+            v.z = fminf(fmaxf(v.z, -clamp), clamp); v.w = fminf(fmaxf(v.w, -clamp), clamp);
+        }
+        if (skip) {
+            const float4 sv = *reinterpret_cast<const float4*>(skip + o);
+            v.x += sv.x; v.y += sv.y; v.z += sv.z; v.w += sv.w;
+        }
+        *reinterpret_cast<float4*>(img + o) = v;
+    }
+}
+
 int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_stride, const float* bias,
                      const float* skip, float* rgb_pre, float* img, int B, int C, int imgc, int H, int W, float clamp,
                      hipStream_t stream) {
     const long HW = (long)H * W;
     LA_CHECK_ARG(HW % 4 == 0, "torgb: H*W must be a multiple of 4");
     LA_CHECK_ARG(imgc >= 1 && imgc <= 4, "torgb: img_channels must be 1..4");
+    if (HW <= 4096) {
+        const long nq = HW / 4;
+        int px_lanes = 1;
+        while (px_lanes < 64 && px_lanes * 2 <= nq) px_lanes *= 2;
+        dim3 grid((unsigned)la_cdiv(nq, px_lanes), B);
+        const size_t lds = (size_t)((imgc * C + 3) & ~3) * sizeof(float) + (size_t)256 * imgc * sizeof(float4);
+#define LAUNCH(N) hipLaunchKernelGGL(la_torgb_fwd_small_kernel<N>, grid, dim3(256), lds, stream, x, wrgb, s, s_stride, bias, skip, rgb_pre, img, C, HW, clamp, px_lanes)
+        switch (imgc) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
+#undef LAUNCH
+        LA_CHECK_LAUNCH();
+        return LA_OK;
+    }
     dim3 grid(la_cdiv(HW / 4, 256), B);
     const size_t lds = (size_t)imgc * C * sizeof(float);
 #define LAUNCH(N) hipLaunchKernelGGL(la_torgb_fwd_kernel<N>, grid, dim3(256), lds, stream, x, wrgb, s, s_stride, bias, skip, rgb_pre, img, C, HW, clamp)
@@ -272,46 +348,76 @@ int la_seam_backward(const LaSeamArgs& a, int B, int imgc, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------------------
 // style-gradient finish for one conv layer:
 //   ds[b][i] = sum_tiles ds_part[b][i][.]  -  s[b][i] * sum_o (sum_slabs ddn_part[b][o][.]) * d[b][o]^2 * wsq[o][i]
-// one thread per i (coalesced wsq reads over i), loop over o; q[b][o] staged in LDS.
+// pass 1 (wide): every partial row (one value per pixel tile / slab, contiguous) is summed by one wave with coalesced
+//   reads and a fixed shuffle tree (deterministic); the sum replaces element 0 of the row.
+// pass 2 (small): one thread per i (coalesced wsq reads over i), loop over o; q[b][o] staged in LDS.
+__global__ __launch_bounds__(256) void la_rows_sum_inplace_kernel(float* __restrict__ a0, long rows0, int n0,
+                                                                 float* __restrict__ a1, long rows1, int n1) {
+    const int lane = threadIdx.x & 63;
+    long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float* row;
+    int n;
+    if (r < rows0) { row = a0 + r * n0; n = n0; }
+    else if (r - rows0 < rows1) { row = a1 + (r - rows0) * n1; n = n1; }
+    else return;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int k = lane;
+    for (; k + 192 < n; k += 256) { v0 += row[k]; v1 += row[k + 64]; v2 += row[k + 128]; v3 += row[k + 192]; }
+    for (; k < n; k += 64) v0 += row[k];
+    float v = (v0 + v1) + (v2 + v3);
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft, 64);
+    if (lane == 0) row[0] = v;
+}
+
 __global__ __launch_bounds__(256) void la_style_bwd_conv_kernel(const float* __restrict__ ds_part, int ntiles,
                                                                const float* __restrict__ ddn_part, int nslabs,
                                                                const float* __restrict__ d, int d_stride,
                                                                const float* __restrict__ s, int s_stride,
                                                                const float* __restrict__ wsq, int cin, int cout,
                                                                float* __restrict__ ds_out, int ds_stride) {
-    // block = 64 input channels x 4 output-channel quarters; q[b][o] staged in LDS, quarters combined through LDS
-    extern __shared__ float q[];   // [cout] + [4][64]
+    // block = 16 input channels x 16 output-channel parts (a wide grid of short loops: this kernel is pure latency);
+    // q[b][o] staged in LDS, the parts combined through LDS in a fixed order
+    extern __shared__ float q[];   // [cout] + [16][16]
     float* comb = q + cout;
     const int b = blockIdx.y;
     for (int o = threadIdx.x; o < cout; o += blockDim.x) {
-        float v = 0.f;
-        for (int k = 0; k < nslabs; ++k) v += ddn_part[((long)b * cout + o) * nslabs + k];
         const float dv = d[(long)b * d_stride + o];
-        q[o] = v * dv * dv;
+        q[o] = ddn_part[((long)b * cout + o) * nslabs] * dv * dv;
     }
     __syncthreads();
-    const int il = threadIdx.x & 63, qt = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + il;
-    float acc = 0.f;
+    const int il = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + il;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (i < cin) {
-        const int per = (cout + 3) / 4;
-        const int o1 = (qt + 1) * per < cout ? (qt + 1) * per : cout;
-        for (int o = qt * per; o < o1; ++o) acc += q[o] * wsq[(long)o * cin + i];
+        const int per = (cout + 15) / 16;
+        const int o0 = part * per, o1 = o0 + per < cout ? o0 + per : cout;
+        int o = o0;
+        for (; o + 3 < o1; o += 4) {
+            a0 += q[o] * wsq[(long)o * cin + i];
+            a1 += q[o + 1] * wsq[(long)(o + 1) * cin + i];
+            a2 += q[o + 2] * wsq[(long)(o + 2) * cin + i];
+            a3 += q[o + 3] * wsq[(long)(o + 3) * cin + i];
+        }
+        for (; o < o1; ++o) a0 += q[o] * wsq[(long)o * cin + i];
     }
-    comb[qt * 64 + il] = acc;
+    comb[part * 16 + il] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (qt == 0 && i < cin) {
-        const float tot = (comb[il] + comb[64 + il]) + (comb[128 + il] + comb[192 + il]);
-        float dsm = 0.f;
-        for (int k = 0; k < ntiles; ++k) dsm += ds_part[((long)b * cin + i) * ntiles + k];
-        ds_out[(long)b * ds_stride + i] = dsm - s[(long)b * s_stride + i] * tot;
+    if (part == 0 && i < cin) {
+        float tot = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) tot += comb[p * 16 + il];
+        ds_out[(long)b * ds_stride + i] = ds_part[((long)b * cin + i) * ntiles] - s[(long)b * s_stride + i] * tot;
     }
 }
 
-int la_style_backward_conv(const float* ds_part, int ntiles, const float* ddn_part, int nslabs, const float* d,
+int la_style_backward_conv(float* ds_part, int ntiles, float* ddn_part, int nslabs, const float* d,
                            int d_stride, const float* s, int s_stride, const float* wsq, int cin, int cout, int B,
                            float* ds_out, int ds_stride, hipStream_t stream) {
-    hipLaunchKernelGGL(la_style_bwd_conv_kernel, dim3(la_cdiv(cin, 64), B), dim3(256), (cout + 256) * sizeof(float), stream,
+    const long rows0 = (long)B * cout, rows1 = (long)B * cin;
+    hipLaunchKernelGGL(la_rows_sum_inplace_kernel, dim3((unsigned)la_cdiv(rows0 + rows1, 4)), dim3(256), 0, stream, ddn_part, rows0,
+                       nslabs, ds_part, rows1, ntiles);
+    hipLaunchKernelGGL(la_style_bwd_conv_kernel, dim3(la_cdiv(cin, 16), B), dim3(256), (cout + 256) * sizeof(float), stream,
                        ds_part, ntiles, ddn_part, nslabs, d, d_stride, s, s_stride, wsq, cin, cout, ds_out, ds_stride);
     LA_CHECK_LAUNCH();
     return LA_OK;
