@@ -83,6 +83,7 @@ size_t la_conv_split_pack_bytes(int M, int C, int ktaps);
 // a.in_q / a.acc_scale_x at it and advance a.ws / a.ws_bytes past it.  Callers that launch several phases over one input
 // call this once.  bf16: {hi | mid << 16, lo} (8 B / element);  fp16: per-sample power-of-two scale, {hi | lo << 16} (4 B).
 int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream);
+bool la_conv_bf16_uses_halo(const LaConvArgs& a);     // fp32-input halo kernel (no pre-split copy needed)
 
 // number of pixel tiles per sample for a launch (the ds_part leading dimension)
 int la_conv_tiles_per_sample(int Gy, int Gx);

@@ -32,9 +32,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef LA_STAMP
 #define LA_STAMP 0
 #endif
-#ifndef LA_HALO_SB
-#define LA_HALO_SB 0
+// issue-order fences of the halo tap loop (dev builds can override LA_FENCES: bit 0 = A, bit 1 = B, bit 2 = C)
+#ifndef LA_FENCES
+#define LA_FENCES 2
 #endif
+#define LA_FENCE_A do { if (LA_FENCES & 1) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LA_FENCE_B do { if (LA_FENCES & 2) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LA_FENCE_C do { if (LA_FENCES & 4) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define FMT_BF16X3 3
 #define FMT_BF16X2 2
 #define FMT_F16X2 16
@@ -237,20 +241,25 @@ __global__ __launch_bounds__(256) void la_plane_absmax_kernel(const float* __res
     if (threadIdx.x == 0) pm[((long)b * C + c) * ns + seg] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-__global__ __launch_bounds__(256) void la_presplit_f16_kernel(const float* __restrict__ in, long in_bstride,
-                                                             const float* __restrict__ scale, int scale_stride,
-                                                             const float* __restrict__ pm, float* __restrict__ xscale,
-                                                             unsigned* __restrict__ out, int C, long HW, int ns) {
+// per-sample power-of-two scale from the segment maxima: xscale[b] = pow2(max over the sample)
+__global__ __launch_bounds__(256) void la_xscale_kernel(const float* __restrict__ pm, float* __restrict__ xscale, int n) {
     __shared__ float red[4];
-    const int c = blockIdx.y, b = blockIdx.z;
+    const int b = blockIdx.x;
     float m = 0.f;
-    for (int k = threadIdx.x; k < C * ns; k += blockDim.x) m = fmaxf(m, pm[(long)b * C * ns + k]);
+    for (int k = threadIdx.x; k < n; k += blockDim.x) m = fmaxf(m, pm[(long)b * n + k]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    const float xs = la_pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
-    if (blockIdx.x == 0 && c == 0 && threadIdx.x == 0) xscale[b] = xs;
+    if (threadIdx.x == 0) xscale[b] = la_pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+__global__ __launch_bounds__(256) void la_presplit_f16_kernel(const float* __restrict__ in, long in_bstride,
+                                                             const float* __restrict__ scale, int scale_stride,
+                                                             const float* __restrict__ xscale,
+                                                             unsigned* __restrict__ out, int C, long HW) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float xs = xscale[b];
     const float sc = (scale ? scale[(long)b * scale_stride + c] : 1.f) * xs;
     const float* ip = in + (long)b * in_bstride + (long)c * HW;
     unsigned* op = out + ((long)b * C + c) * HW;
@@ -285,36 +294,72 @@ __global__ __launch_bounds__(256) void la_presplit_f16_kernel(const float* __res
 static inline size_t presplit_hdr_bytes(int B, int C) { return (PRESPLIT_HDR + (size_t)B * C * PM_NS * 4 + 255) & ~(size_t)255; }
 size_t la_conv_presplit_bytes(int B, int C, int Hin, int Win) { return (size_t)B * C * Hin * Win * 8 + 16 + presplit_hdr_bytes(B, C); }
 
+// fp16 path: per-sample operand scale (segment maxima -> xscale[b]) in the header of the workspace; advances a.ws past it
+static int prepare_scale(LaConvArgs& a, hipStream_t stream) {
+    if (a.precision != LA_PREC_F16X2) return LA_OK;
+    const long HW = (long)a.Hin * a.Win;
+    const size_t hb = presplit_hdr_bytes(a.B, a.C);
+    LA_CHECK_ARG(a.ws && a.ws_bytes >= hb, "conv: split precisions need a workspace (la_modconv_workspace_bytes)");
+    LA_CHECK_ARG(((size_t)a.ws & 15) == 0, "conv: workspace must be 16-byte aligned");
+    LA_CHECK_ARG(a.B <= 64, "conv: split precisions support at most 64 samples per launch");
+    char* base = static_cast<char*>(a.ws);
+    float* xscale = reinterpret_cast<float*>(base);
+    float* pm = reinterpret_cast<float*>(base + PRESPLIT_HDR);       // segment maxima [B][C][ns]
+    int ns = (int)(HW / 8192);
+    ns = ns < 1 ? 1 : (ns > PM_NS ? PM_NS : ns);
+    hipLaunchKernelGGL(la_plane_absmax_kernel, dim3(ns, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
+                       a.scale_stride, pm, a.C, HW, ns);
+    hipLaunchKernelGGL(la_xscale_kernel, dim3(a.B), dim3(256), 0, stream, pm, xscale, a.C * ns);
+    LA_CHECK_LAUNCH();
+    a.acc_scale_x = xscale;
+    a.ws = base + hb;
+    a.ws_bytes -= hb;
+    return LA_OK;
+}
+
+// can this launch use the halo kernel?  dense stride-1 3x3 taps within +-1, grid = whole 4x32 tiles, above the split-K sizes
+bool la_conv_bf16_uses_halo(const LaConvArgs& a) {
+    if (a.precision == LA_PREC_F32 || a.in_q) return false;
+    if (a.in_sy != 1 || a.in_sx != 1 || a.out_sy != 1 || a.out_sx != 1 || a.out_oy != 0 || a.out_ox != 0) return false;
+    if ((a.Gx & 31) != 0 || (a.Gy & 3) != 0 || a.Gy != a.Hout || a.Gx != a.Wout || a.ntaps != 9) return false;
+    if ((long)a.Gy * a.Gx <= 1156) return false;                         // split-K territory (la_conv.hip SPLITK_MAX_G)
+    if ((long)a.C * a.Hin * a.Win >= (1l << 29) || a.C > 4096) return false;   // 32-bit byte offsets inside one sample
+    for (int t = 0; t < a.ntaps; ++t)
+        if (a.tap_dy[t] < -1 || a.tap_dy[t] > 1 || a.tap_dx[t] < -1 || a.tap_dx[t] > 1) return false;
+    return true;
+}
+
+// Operand preparation of a split-precision launch.  Halo launches read the fp32 input directly (modulation, scaling and
+// the split happen on the way into LDS) and only need the fp16 scale; every other launch gets a pre-split copy.
 int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
     if (a.precision == LA_PREC_F32 || a.in_q) return LA_OK;
     const long HW = (long)a.Hin * a.Win;
+    if (la_conv_bf16_uses_halo(a)) return prepare_scale(a, stream);
     const size_t qb = la_conv_presplit_bytes(a.B, a.C, a.Hin, a.Win);
     LA_CHECK_ARG(a.ws && a.ws_bytes >= qb, "conv: split precisions need a workspace (la_modconv_workspace_bytes)");
     LA_CHECK_ARG(((size_t)a.ws & 15) == 0, "conv: workspace must be 16-byte aligned");
     LA_CHECK_ARG(a.B <= 64, "conv: split precisions support at most 64 samples per launch");
     char* base = static_cast<char*>(a.ws);
-    float* xscale = reinterpret_cast<float*>(base);
-    float* pm = reinterpret_cast<float*>(base + PRESPLIT_HDR);       // per-plane maxima [B][C]
-    void* q = base + presplit_hdr_bytes(a.B, a.C);
-    int gx = la_cdiv(HW, 512);
-    if (gx > 64) gx = 64;
+    const size_t ws_bytes = a.ws_bytes;
     if (a.precision == LA_PREC_F16X2) {
-        int ns = (int)(HW / 8192);
-        ns = ns < 1 ? 1 : (ns > PM_NS ? PM_NS : ns);
-        hipLaunchKernelGGL(la_plane_absmax_kernel, dim3(ns, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
-                           a.scale_stride, pm, a.C, HW, ns);
+        int rc = prepare_scale(a, stream);
+        if (rc) return rc;
+        void* q = a.ws;
         hipLaunchKernelGGL(la_presplit_f16_kernel, dim3(la_cdiv(HW, PS_SEG), a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride,
-                           a.in_scale, a.scale_stride, pm, xscale, (unsigned*)q, a.C, HW, ns);
-        a.acc_scale_x = xscale;
+                           a.in_scale, a.scale_stride, a.acc_scale_x, (unsigned*)q, a.C, HW);
+        a.in_q = q;
     } else {
+        void* q = base + presplit_hdr_bytes(a.B, a.C);
+        int gx = la_cdiv(HW, 512);
+        if (gx > 64) gx = 64;
         hipLaunchKernelGGL(la_presplit_kernel, dim3(gx, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
                            a.scale_stride, (uint2*)q, a.C, HW);
+        a.in_q = q;
     }
     LA_CHECK_LAUNCH();
-    a.in_q = q;
     const size_t off = (qb + 255) & ~(size_t)255;
-    a.ws = a.ws_bytes > off ? base + off : nullptr;
-    a.ws_bytes = a.ws_bytes > off ? a.ws_bytes - off : 0;
+    a.ws = ws_bytes > off ? base + off : nullptr;
+    a.ws_bytes = ws_bytes > off ? ws_bytes - off : 0;
     return LA_OK;
 }
 
@@ -581,11 +626,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     constexpr bool F16 = FMT == FMT_F16X2;
     constexpr int TM = MT / 64;
-    constexpr int EB = F16 ? 4 : 8;                // bytes per pre-split element
+    constexpr int EB = 4;                          // the halo kernel reads the fp32 input itself
     constexpr int HPLANE = HALO_PX * HPITCH;       // one term of one halo buffer
     constexpr int HBUF = NTERM * HPLANE;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][NTERM][HALO_PX][HPITCH]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][NTERM][HALO_PX][HPITCH] + scl[nck*32]
     float (*red)[MT] = reinterpret_cast<float (*)[MT]>(smem);
+    float* scl = reinterpret_cast<float*>(smem + 2 * HBUF);     // per-channel factor: style modulation (x fp16 sample scale)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -606,9 +652,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     const int sblk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 #endif
     STAMP(0);
-    // buffer descriptors (wave-uniform): this sample's pre-split input, and the weight pack of this format
+    // buffer descriptors (wave-uniform): this sample's fp32 input, and the weight pack of this format
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(static_cast<const char*>(a.in_q)) + (size_t)b * a.C * HWin * EB, 0, (int)((unsigned)a.C * HWin * EB), 0x00020000);
+        const_cast<float*>(a.in) + (size_t)b * a.in_bstride, 0, (int)((unsigned)a.C * HWin * EB), 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(static_cast<const char*>(a.wgt_bf16)) + (F16 ? pack_f16_offset(term_elems) : 0), 0, (int)(NTERM * term_elems * 2),
         0x00020000);
@@ -620,10 +666,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
         shpack |= (unsigned long long)((1 + a.tap_dy[t]) * HALO_W + (1 + a.tap_dx[t])) << (7 * t);
         wpack |= (unsigned long long)a.tap_w[t] << (4 * t);
     }
+    {
+        const float xs = F16 ? a.acc_scale_x[b] : 1.f;
+        for (int k = tid; k < nck * KCB; k += 256)
+            scl[k] = k < a.C ? (a.in_scale ? a.in_scale[(long)b * a.scale_stride + k] : 1.f) * xs : 0.f;
+    }
 
     // ---- halo slices.  Every load is unconditional (clamped address; out-of-image pixels are zeroed on the way to LDS,
     // channels past C meet zero weights), so the compiler can count them: no wait in the tap loop is a vmcnt(0).
-    struct Slice { unsigned x[4], y[NTERM == 3 ? 4 : 1]; int wr; bool ok; };
+    struct Slice { float x[4]; int wr, c0; bool ok; };
     auto slice_load = [&](int cc, int t, Slice& sl) {
         const int lt = (tid + 64 * t) & 255;                      // the idle lanes rotate over the waves
         int u = t * H_UPT + (lt < H_UPT ? lt : H_UPT - 1);
@@ -636,6 +687,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
         const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
         const unsigned off = (unsigned)(iyc * a.Win + ixc) * EB;
         sl.wr = valid ? hp * HPITCH + ((((c4 >> 1) ^ (hp >> 2)) & 3) << 4) + (c4 & 1) * 8 : -1;
+        sl.c0 = cc * KCB + c4 * 4;
         const bool fast = cc * KCB + KCB <= a.C;                  // uniform: only a ragged last chunk clamps channels
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -646,27 +698,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
                 vo = (unsigned)(c < a.C ? c : a.C - 1) * HWin * EB + off;
                 so = 0u;
             }
-            if (NTERM == 3) {
-                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_in, vo, so, 0);
-                sl.x[j] = v.x;
-                sl.y[NTERM == 3 ? j : 0] = v.y;
-            } else sl.x[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, so, 0);
+            sl.x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, so, 0));
         }
     };
+    // modulate (+ scale), split into NTERM 16-bit terms (each the rounding of the remainder), 8 bytes per term
     auto slice_write = [&](unsigned char* buf, const Slice& sl) {
         if (sl.wr >= 0) {
+            // (2-wide vector types so that the packed v_cvt_pk_* / v_pk_* instructions are selected)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const float4 f = *reinterpret_cast<const float4*>(scl + sl.c0);
+            f32x2 v0 = {sl.x[0] * f.x, sl.x[1] * f.y}, v1 = {sl.x[2] * f.z, sl.x[3] * f.w};
 #pragma unroll
             for (int q = 0; q < NTERM; ++q) {
-                const unsigned sel = q == 1 ? 0x07060302u : 0x05040100u;
-                unsigned w0, w1;
-                if (q == 2) {
-                    w0 = __builtin_amdgcn_perm(sl.y[NTERM == 3 ? 1 : 0], sl.y[0], sel);
-                    w1 = __builtin_amdgcn_perm(sl.y[NTERM == 3 ? 3 : 0], sl.y[NTERM == 3 ? 2 : 0], sel);
+                uint2 w;
+                if constexpr (F16) {
+                    const f16x2 h0 = __builtin_convertvector(v0, f16x2), h1 = __builtin_convertvector(v1, f16x2);
+                    w = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+                    if (q + 1 < NTERM) { v0 -= __builtin_convertvector(h0, f32x2); v1 -= __builtin_convertvector(h1, f32x2); }
                 } else {
-                    w0 = __builtin_amdgcn_perm(sl.x[1], sl.x[0], sel);
-                    w1 = __builtin_amdgcn_perm(sl.x[3], sl.x[2], sel);
+                    const bf16x2_t h0 = __builtin_convertvector(v0, bf16x2_t), h1 = __builtin_convertvector(v1, bf16x2_t);
+                    w = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+                    if (q + 1 < NTERM) { v0 -= __builtin_convertvector(h0, f32x2); v1 -= __builtin_convertvector(h1, f32x2); }
                 }
-                *reinterpret_cast<uint2*>(buf + q * HPLANE + sl.wr) = sl.ok ? make_uint2(w0, w1) : make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(buf + q * HPLANE + sl.wr) = sl.ok ? w : make_uint2(0u, 0u);
             }
         }
     };
@@ -761,18 +817,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
             const int shift_n = (int)((shpack >> (7 * (t + 1 < 9 ? t + 1 : 8))) & 127u);   // (last tap: harmless re-read)
             // (the fences pin the issue order: left alone, the scheduler sinks every load to just before its first use)
             read_b(cur, shift, 1, bf1);            // B of K-step 1 flies under the MFMAs of K-step 0
-            __builtin_amdgcn_sched_barrier(0);
+            LA_FENCE_A;
             mma_step(acur[0], bf0);
-            __builtin_amdgcn_sched_barrier(0);
+            LA_FENCE_B;
             load_a(ccn, tn, 0, acur[0]);           // re-loaded as soon as its MFMAs have issued
             read_b(cur, shift_n, 0, bf0);          // B of the next tap's K-step 0
             if (NEXT) {
                 slice_write(nxt, sl);              // the slice loaded one tap ago
                 slice_load(cc + 1, t, sl);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            LA_FENCE_C;
             mma_step(acur[1], bf1);
-            __builtin_amdgcn_sched_barrier(0);
+            LA_FENCE_B;
             load_a(ccn, tn, 1, acur[1]);
 #if LA_STAMP
             if (cc < 4) STAMP(4 + cc * 10 + t);
@@ -802,26 +858,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     STAMP(45);
 }
 
-// can this launch use the halo kernel?  dense stride-1 taps within +-1, grid = whole 4x32 tiles, not a split-K candidate
-static bool halo_ok(const LaConvArgs& a) {
-    if (a.in_sy != 1 || a.in_sx != 1 || a.out_sy != 1 || a.out_sx != 1 || a.out_oy != 0 || a.out_ox != 0) return false;
-    if ((a.Gx & 31) != 0 || (a.Gy & 3) != 0 || a.Gy != a.Hout || a.Gx != a.Wout || a.ntaps != 9) return false;
-    if ((long)a.C * a.Hin * a.Win >= (1l << 27)) return false;      // 32-bit byte offsets inside one sample
-    for (int t = 0; t < a.ntaps; ++t)
-        if (a.tap_dy[t] < -1 || a.tap_dy[t] > 1 || a.tap_dx[t] < -1 || a.tap_dx[t] > 1) return false;
-    return true;
-}
-
 template <int FMT>
 static void launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, hipStream_t stream) {
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     const size_t lds128 = (size_t)2 * NTERM * NT * BPITCH, lds64 = lds128;     // two pixel buffers (>= the epilogue's 4 * MT floats)
-    if (!split && halo_ok(as)) {
-        const size_t h128 = (size_t)2 * NTERM * HALO_PX * HPITCH, h64 = h128;      // two halo buffers (>= the epilogue's 2 * MT floats)
+    if (!split && la_conv_bf16_uses_halo(as)) {
+        // two halo buffers (>= the epilogue's 4 * MT floats) + the per-channel factor table
+        const size_t h128 = (size_t)2 * NTERM * HALO_PX * HPITCH + (size_t)la_cdiv(as.C, KCB) * KCB * sizeof(float), h64 = h128;
         static bool attr_done = false;
         if (!attr_done) {      // > 64 KB of dynamic LDS needs the opt-in (idempotent)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h128);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<64, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h64);
+            const int cap = 2 * 3 * HALO_PX * HPITCH + 4096 * (int)sizeof(float);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<64, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
             attr_done = true;
         }
         if (MTsel == 128) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, FMT>), grid, dim3(256), h128, stream, as);

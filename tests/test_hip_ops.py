@@ -205,6 +205,7 @@ def test_modconv_vs_oracle(dev, case):
     dict(B=2, cin=16, cout=16, res=8, up=False, noise_strength=0.0),
     dict(B=2, cin=24, cout=132, res=32, up=False, noise_strength=0.1),     # ragged channels
     dict(B=1, cin=64, cout=128, res=64, up=False, noise_strength=0.0),
+    dict(B=2, cin=40, cout=200, res=64, up=False, noise_strength=0.1),     # halo kernel with a ragged channel chunk and M tile
     dict(B=2, cin=64, cout=32, res=32, up=True, noise_strength=0.0),
     dict(B=1, cin=128, cout=64, res=64, up=True, noise_strength=0.1),
     dict(B=2, cin=512, cout=512, res=4, up=False, noise_strength=0.0),
