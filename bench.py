@@ -216,12 +216,16 @@ def main():
                     'traffic': None, 'launches': n.value, 'avg_launch_ms': ms.value / max(n.value, 1),
                     'kernel_time_frac_of_wall': ms.value * 1e-3 / elapsed,
                     'algorithmic_gbs': by.value / (ms.value * 1e-3) / 1e9, 'hbm_peak_gbs': HBM_PEAK_GBS}
-            pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-            if os.path.isfile(pmc):
+            # HBM bytes per launch from the committed PMC passes of this exact workload (scripts/make_profiles.sh)
+            for pmc in (os.path.join(ROOT, 'profiles', f'r01_d_pmc_traffic_{args.precision}.json'),
+                        os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')):
+                if not os.path.isfile(pmc):
+                    continue
                 pj = json.load(open(pmc))
                 if pj.get('precision') == args.precision and args.w_disc == 0 and args.preset == 'B':
                     roof['traffic'] = pj.get('bytes_per_launch')
                     roof['traffic_note'] = pj.get('note')
+                    break
             roof['algorithmic_bytes_per_launch'] = by.value / max(n.value, 1)
     assert out['A'].shape == (args.batch, 1, args.res, args.res)
     if world > 1:
