@@ -52,13 +52,13 @@ struct LaConvArgs {
     long xin_bstride;
     float* ds_part;          // [B][M][tiles_per_sample]
     int tiles_per_sample;
-    // optional caller-provided scratch (la_conv_workspace_bytes): [pre-split bf16 input | split-K slice partials]
+    // optional caller-provided scratch (la_conv_workspace_bytes): [fp16 scale header | pre-split input | split-K slice partials]
     void* ws;
     size_t ws_bytes;
     // filled in by la_conv_launch
     float* splitk_ws;
     int ksplit;
-    const void* in_q;              // split-bf16 path: input already split by la_conv_presplit (8 B / element), or NULL
+    const void* in_q;              // split paths: input already split by la_conv_prepare_input (flat / split-K kernels), or NULL
     // split-bf16 path (precision != LA_PREC_F32): weights pre-split by la_pack_conv_weights_bf16
     int precision;
     const void* wgt_bf16;          // split pack (la_conv_split_pack_bytes): 3 bf16 terms, 2 fp16 terms, fp16 weight scale

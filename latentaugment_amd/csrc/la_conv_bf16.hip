@@ -1,24 +1,23 @@
-// Implicit-GEMM convolution on the bf16 MFMA path with fp32 operands split into bf16 terms ("split-bf16").
+// Implicit-GEMM convolution on the 16-bit MFMA path with fp32 operands split into 16-bit terms.
 //
-// fp32 MFMA runs at 1/16 of the bf16 MFMA rate on gfx950 (MI355X_MICROARCH.md, Matrix cores), so an fp32 contraction is
-// re-expressed as a few bf16 x bf16 products with fp32 accumulation:
-//     x = x_h + x_m + x_l  (each term the bf16 rounding of what the previous terms left),   same for w
-//     NTERM = 3:  x.w ~= hh + (hm + mh) + (mm + hl + lh)     6 MFMAs, error ~1e-7 relative (fp32-class; measured in
-//                                                            tests/test_hip_ops.py against an fp64 reference)
-//     NTERM = 2:  x.w ~= hh + (hm + mh)                       3 MFMAs, error ~4e-6 relative
-// bf16 x bf16 products are exact in fp32, and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the only approximation is
-// the dropped low-order cross terms.  The leading product and the correction products use separate accumulators that are
-// added once in the epilogue (small terms are not swamped inside the K loop).
-// (Current version: one accumulator, correction products issued before the leading one within each K step; measured
-//  error stays at the fp32-MFMA level, see tests.)
+// fp32 MFMA runs at 1/16 of the 16-bit MFMA rate on gfx950 (MI355X_MICROARCH.md, Matrix cores), so an fp32 contraction is
+// re-expressed as a few 16-bit x 16-bit products with fp32 accumulation (the products are exact in fp32, the MFMA
+// accumulates in fp32, so the only approximation is the dropped low-order cross terms):
+//     FMT_BF16X3:  x = h + m + l (each term the bf16 rounding of what the previous terms left), same for w;
+//                  x.w ~= hh + (hm + mh) + (mm + hl + lh)     6 MFMAs, error ~1e-7 relative (fp32-class)
+//     FMT_BF16X2:  x.w ~= hh + (hm + mh)                       3 MFMAs, error ~4e-6 relative (approximate mode)
+//     FMT_F16X2:   x and w are first brought into fp16 range by exact power-of-two scales (one per weight tensor, one per
+//                  sample of the modulated input, scaled max in [2^14, 2^15)), then x = h + l in fp16 (22 significand
+//                  bits);  x.w ~= hh + hl + lh               3 MFMAs, error ~2e-7 relative (fp32-class); the accumulators
+//                  are multiplied by the inverse scales before the epilogue (exact)
+// One accumulator per output; within a K step the correction products are issued before the leading one.  Measured errors:
+// tests/test_hip_ops.py against the oracle.
 //
 // Tiling: as la_conv.hip (256 threads = 2x2 waves, tile MT x 128 pixels, wave 64x64 = 2x2 MFMA tiles), K chunk =
-// (one tap, 32 input channels) = two K=16 MFMA steps.  Weights are pre-split at pack time into
-// wgt_bf16[term][slab][ceil(C/32)][M][32] (k contiguous = the A fragment order).  Activations are modulated and split ONCE
-// per launch input by la_conv_presplit (8 bytes per element: {hi | mid<<16, lo}) -- the contraction re-reads every
-// element 9 taps x (M/MT) times, so splitting inside the gather would repeat the VALU work 9-36x.  The gather packs the
-// terms k-contiguous with v_perm_b32 and writes them to LDS ([pixel][32] bf16, 80-byte row stride: conflict-free for
-// ds_read_b128 fragments and ds_write_b128 staging).
+// (one tap, 32 input channels) = two K=16 MFMA steps.  Weights are split at pack time into a FRAGMENT-ORDER pack
+// (pack_slab_offset) that the waves read straight from global memory.  Pixels: the halo kernel reads the fp32 input and
+// splits on the way into LDS; the flat kernel (whose gather re-reads every element once per tap) reads a pre-split copy
+// made once per launch input (la_presplit_*: 8 bytes per element {h | m<<16, l} bf16, 4 bytes {h | l<<16} fp16).
 #include "la_conv_device.h"
 #include <type_traits>
 
@@ -42,7 +41,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define FMT_BF16X3 3
 #define FMT_BF16X2 2
 #define FMT_F16X2 16
-#define PRESPLIT_HDR 512       // bytes in front of a pre-split copy: [0,256) xscale[b] floats, [256,512) |x| max bit patterns
+#define PRESPLIT_HDR 512       // head of the workspace: [0,256) xscale[b] floats; the segment maxima follow the header
 
 template <bool F16>
 __device__ __forceinline__ f32x16 la_mma(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -51,7 +50,6 @@ __device__ __forceinline__ f32x16 la_mma(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 
 #define KCB 32                 // channels per chunk
-#define ROWB 80                // LDS bytes per (row, 32 bf16) incl. 16 B pad
 
 // ------------------------------------------------------------------------------------------------------------
 // weight packing: W[o][i][t] (fp32) -> out[term][t][cc][m/32][k/16][lane][8] with (m,k) = (o,i) forward or (i,o) backward.
@@ -364,6 +362,17 @@ int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+#if LA_STAMP
+// dev builds only: s_memtime stamps of wave 0 of the first 4096 workgroups (la_debug_stamps reads them back)
+#define LA_NSTAMP 48
+__device__ unsigned long long la_stamps[4096 * LA_NSTAMP];
+#define STAMP(k) do { if (lane == 0 && wid == 0 && sblk < 4096) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); la_stamps[sblk * LA_NSTAMP + (k)] = t_; } } while (0)
+extern "C" int la_debug_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(la_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#else
+#define STAMP(k) do {} while (0)
+#endif
 // Flat variant: 128 consecutive grid positions per tile, any stride / tap table / ragged grid, optional split-K.
 //   * B (pixels): thread (pixel, 16-channel half) gathers the tap-shifted inputs of one (chunk, tap) step with 16
 //     unconditional buffer loads (clamped addresses; out-of-image pixels are zeroed on the way to LDS), one step ahead,
@@ -377,7 +386,10 @@ template <int MT, bool SPLIT, int FMT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void la_conv_bf16_kernel(LaConvArgs a) {
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     constexpr bool F16 = FMT == FMT_F16X2;
-    constexpr int TM = MT / 64;
+    constexpr int WM_ = MT == 128 ? 4 : 2;         // wave grid WM_ x WN_ over the MT x 128 tile: every wave owns 32 rows
+    constexpr int WN_ = 4 / WM_;                   // (128-row tiles: 4 x 1, no weight fragment is loaded by two waves)
+    constexpr int TM = 1;
+    constexpr int NJ = 4 / WN_;                    // 32-pixel MFMA tiles per wave
     constexpr int EB = F16 ? 4 : 8;                // bytes per pre-split element
     constexpr int BPLANE = NT * BPITCH;            // one term of one pixel buffer
     constexpr int BBUF = NTERM * BPLANE;
@@ -386,7 +398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN_, wn = wid % WN_;
     // XCD-aware tile order (direct mode): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
     // run of pixel tiles -- vertically adjacent tiles (which share the +-1 row halos of the 3x3 taps) then hit the same L2.
     int ntile = blockIdx.x;
@@ -480,13 +492,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
             *reinterpret_cast<uint4*>(p + ((((khalf * 2 + 1) ^ wsw) & 3) << 4)) = make_uint4(w[4], w[5], w[6], w[7]);
         }
     };
-    // B fragments: lane (l31, lh) of N-subtile j reads slot ks*2 + lh of row wn*64 + j*32 + l31
+    // B fragments: lane (l31, lh) of N-subtile j reads slot ks*2 + lh of row (wn*NJ + j)*32 + l31
     const int rsw = (l31 >> 2) & 3;
-    const int rbase = (wn * 64 + l31) * BPITCH;
-    auto read_b = [&](const unsigned char* buf, int ks, bf16x8 (&dst)[NTERM][2]) {
+    const int rbase = (wn * NJ * 32 + l31) * BPITCH;
+    auto read_b = [&](const unsigned char* buf, int ks, bf16x8 (&dst)[NTERM][NJ]) {
         const int o = rbase + ((((ks * 2 + lh) ^ rsw) & 3) << 4);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int q = 0; q < NTERM; ++q) dst[q][j] = *reinterpret_cast<const bf16x8*>(buf + q * BPLANE + j * 32 * BPITCH + o);
     };
@@ -496,7 +508,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     unsigned a_off[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        int mblk = (m0 + wm * (MT / 2) + i * 32) >> 5;
+        int mblk = (m0 + wm * (MT / WM_) + i * 32) >> 5;
         mblk = mblk < (Mp >> 5) ? mblk : (Mp >> 5) - 1;
         a_off[i] = (unsigned)mblk * 2048u + (unsigned)lane * 16u;
     }
@@ -512,18 +524,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
                 dst[q][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_off[i], so + q * term_bytes, 0));
     };
 
-    f32x16 acc[TM][2];
+    f32x16 acc[TM][NJ];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    auto mma_step = [&](bf16x8 (&af)[NTERM][TM], bf16x8 (&bf)[NTERM][2]) {
+    auto mma_step = [&](bf16x8 (&af)[NTERM][TM], bf16x8 (&bf)[NTERM][NJ]) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 // smallest products first, so they are not swamped by the leading term inside the accumulator
                 if constexpr (NTERM == 3) {
                     acc[i][j] = la_mma<F16>(af[2][i], bf[0][j], acc[i][j]);   // lh
@@ -536,6 +548,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
             }
     };
 
+#if LA_STAMP
+    const int sblk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#endif
+    STAMP(0);
     if (nstep > 0) {
         // (chunk, tap) of steps s, s+1, s+2; past the end they stay on the last valid step (harmless re-loads)
         int c1 = ck_beg, t1 = 0;
@@ -543,7 +559,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
             if (t + 1 < ntaps) ++t;
             else if (c + 1 < ck_end) { ++c; t = 0; }
         };
-        bf16x8 acur[2][NTERM][TM], bf0[NTERM][2], bf1[NTERM][2];
+        bf16x8 acur[2][NTERM][TM], bf0[NTERM][NJ], bf1[NTERM][NJ];
         load_b(c1, t1);
         load_a(c1, t1, 0, acur[0]);
         load_a(c1, t1, 1, acur[1]);
@@ -551,6 +567,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
         int c2 = c1, t2 = t1;
         write_b(smem);
         __syncthreads();
+        STAMP(1);
         load_b(c1, t1);
         adv(c2, t2);                                   // (c2, t2) = step 2
 #pragma unroll 1
@@ -573,15 +590,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
             c1 = c2; t1 = t2;
             adv(c2, t2);
             __syncthreads();
+#if LA_STAMP
+            if (s < 40) STAMP(2 + s);
+#endif
         }
     }
+    STAMP(44);
     if (F16) {
         // undo the power-of-two operand scales (exact)
         const float iw = 1.f / a.acc_scale_w[0];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             int bb = blockIdx.z;
-            if (SPLIT) { const int nidx = ntile * NT + wn * 64 + j * 32 + l31; bb = nidx < Ntot ? nidx / G : 0; }
+            if (SPLIT) { const int nidx = ntile * NT + (wn * NJ + j) * 32 + l31; bb = nidx < Ntot ? nidx / G : 0; }
             const float inv = iw / a.acc_scale_x[bb];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -589,7 +610,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
         }
     }
-    la_conv_epilogue<MT, SPLIT>(a, acc, red, ntile, m0, G, Ntot);
+    la_conv_epilogue<MT, SPLIT, false, WM_>(a, acc, red, ntile, m0, G, Ntot);
+    STAMP(45);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -605,17 +627,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
 //     loads a fragment with one coalesced 1 KB buffer load; each fragment register is re-loaded for the next tap right
 //     after the MFMAs that read it have issued.
 // LDS: 2 x 204 px x 64 B x NTERM = 51 / 76.5 KB; registers <= 168 (NTERM = 2: three waves per SIMD) / <= 256.
-#if LA_STAMP
-// dev builds only: s_memtime stamps of wave 0 of the first 4096 workgroups (la_debug_stamps reads them back)
-#define LA_NSTAMP 48
-__device__ unsigned long long la_stamps[4096 * LA_NSTAMP];
-#define STAMP(k) do { if (lane == 0 && wid == 0 && sblk < 4096) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); la_stamps[sblk * LA_NSTAMP + (k)] = t_; } } while (0)
-extern "C" int la_debug_stamps(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(la_stamps), (size_t)n * sizeof(unsigned long long));
-}
-#else
-#define STAMP(k) do {} while (0)
-#endif
 #define HALO_W 34
 #define HALO_PX (6 * HALO_W)
 #define HPITCH 64
@@ -625,7 +636,10 @@ template <int MT, int FMT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void la_conv_bf16_halo_kernel(LaConvArgs a) {
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     constexpr bool F16 = FMT == FMT_F16X2;
-    constexpr int TM = MT / 64;
+    constexpr int WM_ = MT == 128 ? 4 : 2;         // wave grid WM_ x WN_ over the MT x 128 tile: every wave owns 32 rows
+    constexpr int WN_ = 4 / WM_;                   // (128-row tiles: 4 x 1, no weight fragment is loaded by two waves)
+    constexpr int TM = 1;
+    constexpr int NJ = 4 / WN_;                    // 32-pixel MFMA tiles (= tile rows) per wave
     constexpr int EB = 4;                          // the halo kernel reads the fp32 input itself
     constexpr int HPLANE = HALO_PX * HPITCH;       // one term of one halo buffer
     constexpr int HBUF = NTERM * HPLANE;
@@ -635,7 +649,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN_, wn = wid % WN_;
     int ntile = blockIdx.x;
     if ((gridDim.x & 7) == 0) ntile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous tile runs
     const int m0 = blockIdx.y * MT;
@@ -732,7 +746,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     unsigned a_off[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        int mblk = (m0 + wm * (MT / 2) + i * 32) >> 5;
+        int mblk = (m0 + wm * (MT / WM_) + i * 32) >> 5;
         mblk = mblk < (Mp >> 5) ? mblk : (Mp >> 5) - 1;
         a_off[i] = (unsigned)mblk * 2048u + (unsigned)lane * 16u;
     }
@@ -747,29 +761,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
             for (int i = 0; i < TM; ++i)
                 dst[q][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_off[i], so + q * term_bytes, 0));
     };
-    // B fragments: lane (l31, lh) of N-subtile j reads slot ks*2 + lh of halo pixel (wn*2 + j) * 34 + shift + l31
-    auto read_b = [&](const unsigned char* buf, int shift, int ks, bf16x8 (&dst)[NTERM][2]) {
+    // B fragments: lane (l31, lh) of N-subtile j reads slot ks*2 + lh of halo pixel (wn*NJ + j) * 34 + shift + l31
+    auto read_b = [&](const unsigned char* buf, int shift, int ks, bf16x8 (&dst)[NTERM][NJ]) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int p = (wn * 2 + j) * HALO_W + shift + l31;
+        for (int j = 0; j < NJ; ++j) {
+            const int p = (wn * NJ + j) * HALO_W + shift + l31;
             const int o = p * HPITCH + ((((ks * 2 + lh) ^ (p >> 2)) & 3) << 4);
 #pragma unroll
             for (int q = 0; q < NTERM; ++q) dst[q][j] = *reinterpret_cast<const bf16x8*>(buf + q * HPLANE + o);
         }
     };
 
-    f32x16 acc[TM][2];
+    f32x16 acc[TM][NJ];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    auto mma_step = [&](bf16x8 (&af)[NTERM][TM], bf16x8 (&bf)[NTERM][2]) {
+    auto mma_step = [&](bf16x8 (&af)[NTERM][TM], bf16x8 (&bf)[NTERM][NJ]) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 // smallest products first, so they are not swamped by the leading term inside the accumulator
                 if constexpr (NTERM == 3) {
                     acc[i][j] = la_mma<F16>(af[2][i], bf[0][j], acc[i][j]);   // lh
@@ -799,7 +813,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     __syncthreads();
     STAMP(3);
 
-    bf16x8 bf0[NTERM][2], bf1[NTERM][2];
+    bf16x8 bf0[NTERM][NJ], bf1[NTERM][NJ];
     auto chunk = [&](int cc, auto has_next) {
         constexpr bool NEXT = decltype(has_next)::value;
         const unsigned char* cur = smem + (cc & 1) * HBUF;
@@ -849,12 +863,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
     }
     STAMP(44);
-    la_conv_epilogue<MT, false, true>(a, acc, red, ntile, m0, G, G);
+    la_conv_epilogue<MT, false, true, WM_>(a, acc, red, ntile, m0, G, G);
     STAMP(45);
 }
 

@@ -1,6 +1,8 @@
 // Device-side pieces shared by the contraction kernels (fp32 MFMA and split-bf16 MFMA): the fused epilogue.
-// Both kernel families leave the same accumulator fragment: acc[i][j][r] of a 32x32 MFMA tile,
-//   m = m0 + wm*(MT/2) + i*32 + (r&3) + 8*(r>>2) + 4*(lane>>5) ;  pixel = ntile*128 + wn*64 + j*32 + (lane&31).
+// Both kernel families leave the same kind of accumulator fragment: acc[i][j][r] of a 32x32 MFMA tile.  The 4 waves of a
+// workgroup form a WM_ x (4/WM_) grid over the MT x 128 tile (2x2: fp32 kernel and the 64-row 16-bit tiles; 4x1: the
+// 128-row 16-bit tiles, where every wave owns 32 rows x all 128 pixels so that no weight fragment is loaded twice):
+//   m = m0 + wm*(MT/WM_) + i*32 + (r&3) + 8*(r>>2) + 4*(lane>>5) ;  pixel = ntile*128 + (wn*NJ + j)*32 + (lane&31).
 #pragma once
 #include "la_conv.h"
 
@@ -14,19 +16,21 @@ __device__ __forceinline__ float la_conv_epi_fwd(const LaConvArgs& a, float v, f
 
 // TILE2D: the 128 pixels of a tile are 4 rows x 32 columns of the output grid (halo kernel) instead of 128 consecutive
 // grid positions; wave N-subtile (wn, j) is then row wn*2 + j of the tile.
-template <int MT, bool SPLIT, bool TILE2D = false>
-__device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&acc)[MT / 64][2], float (*red)[MT],   // red: [4][MT] LDS floats
+template <int MT, bool SPLIT, bool TILE2D = false, int WM_ = 2>
+__device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&acc)[MT / (32 * WM_)][WM_], float (*red)[MT],   // red: [4][MT] LDS floats
                                                  int ntile, int m0, int G, int Ntot) {
-    constexpr int TM = MT / 64;
+    constexpr int TM = MT / (32 * WM_);       // 32-row MFMA tiles per wave
+    constexpr int WN_ = 4 / WM_;              // waves along the pixels
+    constexpr int NJ = WM_;                   // 32-pixel MFMA tiles per wave (128 / 32 / WN_)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN_, wn = wid % WN_;
     const int l31 = lane & 31, lh = lane >> 5;
     if (SPLIT) {
         // raw slice accumulators -> ws[slice][b][m][g]
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int nidx = ntile * NT + wn * 64 + j * 32 + l31;
+        for (int j = 0; j < NJ; ++j) {
+            const int nidx = ntile * NT + (wn * NJ + j) * 32 + l31;
             if (nidx >= Ntot) continue;
             const int b = nidx / G, g = nidx - b * G;
             float* wsp = a.splitk_ws + (((long)blockIdx.z * a.B + b) * a.M) * G + g;
@@ -34,7 +38,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * (MT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int m = m0 + wm * (MT / WM_) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (m < a.M) wsp[(long)m * G] = acc[i][j][r];
                 }
         }
@@ -47,22 +51,22 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
     // 64 stores of a lane are not serialised behind 32 dependent round trips to L2/HBM.
     if (m0 + MT <= a.M && (TILE2D || (ntile + 1) * NT <= G)) {
         float* prm = &red[2][0];                         // [2][MT] row parameters (red[0..1] stay the ds_part scratch)
-        long np[2];
+        long np[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             int gy, gx;
             if (TILE2D) {
                 const int tpr = a.Gx >> 5;
                 const int tyb = ntile / tpr, txb = ntile - tyb * tpr;
-                gy = tyb * 4 + wn * 2 + j; gx = txb * 32 + l31;
+                gy = tyb * 4 + wn * NJ + j; gx = txb * 32 + l31;
             } else {
-                const int g = ntile * NT + wn * 64 + j * 32 + l31;
+                const int g = ntile * NT + (wn * NJ + j) * 32 + l31;
                 gy = g / a.Gx; gx = g - gy * a.Gx;
             }
             np[j] = (long)(gy * a.out_sy + a.out_oy) * a.Wout + (gx * a.out_sx + a.out_ox);
         }
         const long HWo = (long)a.Hout * a.Wout;
-        const int mw = wm * (MT / 2) + 4 * lh;            // first row of this lane inside the tile
+        const int mw = wm * (MT / WM_) + 4 * lh;          // first row of this lane inside the tile
         float* o0 = a.out + ((long)b * a.M + m0 + mw) * HWo;
         if (a.epi == LA_EPI_BWD) {
             const float* os_b = a.out_scale ? a.out_scale + (long)b * a.oscale_stride : nullptr;
@@ -71,12 +75,12 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                float xv[16][2];
+                float xv[16][NJ];
                 if (x0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) xv[r][j] = x0[(long)(i * 32 + (r & 3) + 8 * (r >> 2)) * HWo + np[j]];
+                        for (int j = 0; j < NJ; ++j) xv[r][j] = x0[(long)(i * 32 + (r & 3) + 8 * (r >> 2)) * HWo + np[j]];
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -84,7 +88,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                     const float sc = prm[mw + mr];
                     float part = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         const float v = acc[i][j][r];
                         o0[(long)mr * HWo + np[j]] = v * sc;
                         if (x0) part += v * xv[r][j];
@@ -98,12 +102,14 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
             }
             if (a.ds_part) {
                 __syncthreads();
-                if (tid < MT) a.ds_part[((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile] = red[0][tid] + red[1][tid];
+                if (tid < MT) a.ds_part[((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile] = red[0][tid] + (WN_ > 1 ? red[1][tid] : 0.f);
             }
             return;
         }
         const bool fwd = a.epi == LA_EPI_FWD;
-        float nz[2] = {0.f, 0.f};
+        float nz[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) nz[j] = 0.f;
         if (fwd) {
             const float* dm_b = a.demod ? a.demod + (long)b * a.demod_stride : nullptr;
             if (tid < MT) {
@@ -112,7 +118,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
             }
             if (a.noise) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) nz[j] = a.noise[(long)b * a.noise_bstride + np[j]] * a.noise_strength;
+                for (int j = 0; j < NJ; ++j) nz[j] = a.noise[(long)b * a.noise_bstride + np[j]] * a.noise_strength;
             }
             __syncthreads();
         }
@@ -123,19 +129,19 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
         const float* ad = (o2 && a.addend) ? a.addend + ((long)b * a.M + m0 + mw) * HWo : nullptr;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            float av[16][2];
+            float av[16][NJ];
             if (ad) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) av[r][j] = ad[(long)(i * 32 + (r & 3) + 8 * (r >> 2)) * HWo + np[j]];
+                    for (int j = 0; j < NJ; ++j) av[r][j] = ad[(long)(i * 32 + (r & 3) + 8 * (r >> 2)) * HWo + np[j]];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mr = i * 32 + (r & 3) + 8 * (r >> 2);
                 const float dmv = fwd ? prm[mw + mr] : 1.f, bv = fwd ? prm[MT + mw + mr] : 0.f;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     float v = acc[i][j][r];
                     if (fwd) {
                         v = v * dmv + nz[j] + bv;
@@ -152,18 +158,18 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
     }
 
     // ---- generic path (ragged tiles): every access guarded
-    bool pix_ok[2];
-    long npos[2];
+    bool pix_ok[NJ];
+    long npos[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         int gy, gx;
         if (TILE2D) {
             const int tpr = a.Gx >> 5;                  // tiles per row of tiles
             const int tyb = ntile / tpr, txb = ntile - tyb * tpr;
-            gy = tyb * 4 + wn * 2 + j; gx = txb * 32 + l31;
+            gy = tyb * 4 + wn * NJ + j; gx = txb * 32 + l31;
             pix_ok[j] = true;                           // the halo kernel only runs on grids that tile exactly
         } else {
-            const int g = ntile * NT + wn * 64 + j * 32 + l31;
+            const int g = ntile * NT + (wn * NJ + j) * 32 + l31;
             pix_ok[j] = g < G;
             gy = pix_ok[j] ? g / a.Gx : 0;
             gx = pix_ok[j] ? g - gy * a.Gx : 0;
@@ -181,13 +187,13 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ml = wm * (MT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int ml = wm * (MT / WM_) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int m = m0 + ml;
                 const bool mok = m < a.M;
                 const float sc = (os_b && mok) ? os_b[m] : 1.f;
                 float part = 0.f;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     const float v = acc[i][j][r];
                     if (mok && pix_ok[j]) {
                         out_b[(long)m * HWout + npos[j]] = v * sc;
@@ -205,24 +211,26 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
         if (a.ds_part) {
             __syncthreads();
             if (tid < MT && m0 + tid < a.M)
-                a.ds_part[((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile] = red[0][tid] + red[1][tid];
+                a.ds_part[((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile] = red[0][tid] + (WN_ > 1 ? red[1][tid] : 0.f);
         }
         return;
     }
 
     const bool fwd = a.epi == LA_EPI_FWD;
     const float* dm_b = (fwd && a.demod) ? a.demod + (long)b * a.demod_stride : nullptr;
-    float nz[2] = {0.f, 0.f};
+    float nz[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) nz[j] = 0.f;
     if (fwd && a.noise) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
             if (pix_ok[j]) nz[j] = a.noise[(long)b * a.noise_bstride + npos[j]] * a.noise_strength;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * (MT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int m = m0 + wm * (MT / WM_) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (m >= a.M) continue;
             float dmv = 1.f, bv = 0.f;
             if (fwd) {
@@ -230,7 +238,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                 if (a.bias) bv = a.bias[m];
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 if (!pix_ok[j]) continue;
                 float v = acc[i][j][r];
                 if (fwd) v = la_conv_epi_fwd(a, v, dmv, nz[j], bv);
