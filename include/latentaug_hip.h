@@ -277,6 +277,25 @@ int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const float* con
                       float* w_aug_out, float* losses_out, la_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Quality metrics on the augmented outputs: the numeric core of the reference's FID and Improved
+ * Precision/Recall downstream of the detector features (the detectors are NVIDIA-hosted pickles, metric_utils.py:46-60).
+ *   la_feature_moments_f64  FeatureStats.append, metrics/metric_utils.py:104-118: raw_mean[D] += sum_k x[k];
+ *                           raw_cov[D][D] += x^T x with float64 accumulators; x float32 [n][D].
+ *   la_cdist_f16            compute_distances, metrics/precision_recall.py:19-32 (torch.cdist of float16 features):
+ *                           dist float32 [nr][nc].  rows/cols: float16 [n][D] row-major, D % 16 == 0, 16-byte aligned.
+ *   la_pr_kth_f16           precision_recall.py:75-79: kth[i] = (nhood_size+1)-th smallest distance of row i.
+ *   la_pr_member_f16        precision_recall.py:80-84: member[i] = any_j dist(i, j) <= radius[j].
+ * ws: la_pr_workspace_floats(nr, nc) floats.  The [nr][nc] matrix is not materialised by the last two.
+ * ------------------------------------------------------------------------------------------------------------- */
+int la_feature_moments_f64(const float* x, long n, int D, double* raw_mean, double* raw_cov, la_stream_t stream);
+size_t la_pr_workspace_floats(long nr, long nc);
+int la_cdist_f16(const void* rows, long nr, const void* cols, long nc, int D, float* dist, float* ws, la_stream_t stream);
+int la_pr_kth_f16(const void* rows, long nr, const void* cols, long nc, int D, int nhood_size, float* kth, float* ws,
+                  la_stream_t stream);
+int la_pr_member_f16(const void* rows, long nr, const void* cols, long nc, int D, const float* radius, unsigned char* member,
+                     float* ws, la_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Opt-in profiler for the contraction launches (HIP events on the launch stream).  No reference counterpart: the
  * reference's only timing hook is wall-clock stats_time (augments/latent_aug.py:276).
  * la_prof_end: summed device ms, launch count, algorithmic FLOPs (2*MACs) and algorithmic bytes (input + output +

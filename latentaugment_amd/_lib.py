@@ -79,6 +79,11 @@ SIGNATURES = {
     'la_latent_opt_run': (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
     'la_fc_f32': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _F, _P]),
     'la_mapping_forward_f32': (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _F, _I, _P, _P, _P]),
+    'la_feature_moments_f64': (_I, [_P, _L, _I, _P, _P, _P]),
+    'la_pr_workspace_floats': (_Z, [_L, _L]),
+    'la_cdist_f16': (_I, [_P, _L, _P, _L, _I, _P, _P, _P]),
+    'la_pr_kth_f16': (_I, [_P, _L, _P, _L, _I, _I, _P, _P, _P]),
+    'la_pr_member_f16': (_I, [_P, _L, _P, _L, _I, _P, _P, _P, _P]),
     'la_disc_num_params': (_I, [_I]),
     'la_disc_workspace_bytes': (_Z, [_I, _I, _P, _I]),
     'la_disc_create': (_I, [_I, _I, _P, _F, _P, _I, _P, _I, _I, _P, _Z, _P, _P]),

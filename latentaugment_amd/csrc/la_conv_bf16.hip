@@ -575,21 +575,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
             const unsigned char* cur = smem + (s & 1) * BBUF;
             unsigned char* nxt = smem + ((s + 1) & 1) * BBUF;
             // (the fences pin the issue order: left alone, the scheduler sinks every load to just before its first use)
+#if LA_ABLATE == 13
+            if (s == 0) { read_b(cur, 0, bf0); read_b(cur, 1, bf1); }
+#else
             read_b(cur, 0, bf0);
             read_b(cur, 1, bf1);
+#endif
+#if LA_ABLATE != 12
             write_b(nxt);                              // step s+1 (loaded during step s-1)
+#endif
+#if LA_ABLATE != 11
             load_b(c2, t2);                            // step s+2
+#endif
             __builtin_amdgcn_sched_barrier(0);
             mma_step(acur[0], bf0);
             __builtin_amdgcn_sched_barrier(0);
+#if LA_ABLATE != 14
             load_a(c1, t1, 0, acur[0]);                // re-loaded as soon as its MFMAs have issued
+#endif
             __builtin_amdgcn_sched_barrier(0);
             mma_step(acur[1], bf1);
             __builtin_amdgcn_sched_barrier(0);
+#if LA_ABLATE != 14
             load_a(c1, t1, 1, acur[1]);
+#endif
             c1 = c2; t1 = t2;
             adv(c2, t2);
+#if LA_ABLATE != 15
             __syncthreads();
+#endif
 #if LA_STAMP
             if (s < 40) STAMP(2 + s);
 #endif
