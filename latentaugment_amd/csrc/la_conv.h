@@ -58,6 +58,8 @@ struct LaConvArgs {
     // filled in by la_conv_launch
     float* splitk_ws;
     int ksplit;
+    const float* in_pmax;          // optional [B][C][in_pmax_nseg]: partial max |in| of every plane, left by the kernel that produced `in`
+    int in_pmax_nseg;              //   (the fp16 operand scale then needs no absmax pass)
     const void* in_q;              // split paths: input already split by la_conv_prepare_input (flat / split-K kernels), or NULL
     // split-bf16 path (precision != LA_PREC_F32): weights pre-split by la_pack_conv_weights_bf16
     int precision;

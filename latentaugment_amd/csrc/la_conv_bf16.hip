@@ -252,6 +252,22 @@ __global__ __launch_bounds__(256) void la_xscale_kernel(const float* __restrict_
     if (threadIdx.x == 0) xscale[b] = la_pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
+__global__ __launch_bounds__(256) void la_xscale_pmax_kernel(const float* __restrict__ pmax, int nseg, const float* __restrict__ scale,
+                                                            int scale_stride, float* __restrict__ xscale, int C) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* pb = pmax + (long)b * C * nseg;
+    const float* sb = scale ? scale + (long)b * scale_stride : nullptr;
+    const int n = C * nseg;
+    float m = 0.f;
+    for (int k = threadIdx.x; k < n; k += 256) m = fmaxf(m, pb[k] * fabsf(sb ? sb[k / nseg] : 1.f));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) xscale[b] = la_pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
 __global__ __launch_bounds__(256) void la_presplit_f16_kernel(const float* __restrict__ in, long in_bstride,
                                                              const float* __restrict__ scale, int scale_stride,
                                                              const float* __restrict__ xscale,
@@ -305,9 +321,14 @@ static int prepare_scale(LaConvArgs& a, hipStream_t stream) {
     float* pm = reinterpret_cast<float*>(base + PRESPLIT_HDR);       // segment maxima [B][C][ns]
     int ns = (int)(HW / 8192);
     ns = ns < 1 ? 1 : (ns > PM_NS ? PM_NS : ns);
-    hipLaunchKernelGGL(la_plane_absmax_kernel, dim3(ns, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
-                       a.scale_stride, pm, a.C, HW, ns);
-    hipLaunchKernelGGL(la_xscale_kernel, dim3(a.B), dim3(256), 0, stream, pm, xscale, a.C * ns);
+    if (a.in_pmax) {      // the producer of `in` already reduced every plane: max over the sample of |style| * plane max
+        hipLaunchKernelGGL(la_xscale_pmax_kernel, dim3(a.B), dim3(256), 0, stream, a.in_pmax, a.in_pmax_nseg > 0 ? a.in_pmax_nseg : 1, a.in_scale,
+                           a.scale_stride, xscale, a.C);
+    } else {
+        hipLaunchKernelGGL(la_plane_absmax_kernel, dim3(ns, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
+                           a.scale_stride, pm, a.C, HW, ns);
+        hipLaunchKernelGGL(la_xscale_kernel, dim3(a.B), dim3(256), 0, stream, pm, xscale, a.C * ns);
+    }
     LA_CHECK_LAUNCH();
     a.acc_scale_x = xscale;
     a.ws = base + hb;

@@ -4,6 +4,22 @@
 #include "la_common.h"
 #include "la_style.h"
 
+// Internal variants with plane maxima passed between producer and consumer (fp16 operand scale without an absmax pass):
+//   in_pmax  [B][C][in_nseg]: partial max |input| per plane, written by the kernel that produced the input
+//   y_pmax   [B][cout][la_fir4x4_segments(res, res)]: partial max |y| per plane, written by the FIR epilogue of the up-sampling layer
+int la_modconv3x3_fwd_ex(const float* x, long x_bstride, const float* in_pmax, int in_nseg, const float* wf, const void* wq, int precision, const float* s,
+                         int s_stride, const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
+                         const float* bias, int act, float alpha, float gain, float clamp, float* y, void* ws, size_t ws_bytes, int B,
+                         int cin, int cout, int res, hipStream_t stream);
+int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
+                             const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
+                             const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
+                             float* scratch, float* y, float* y_pmax, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
+                             hipStream_t stream);
+int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, const float* wb, const void* wq, int precision, const float* s, int s_stride,
+                         const float* xin, long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
+                         int res, hipStream_t stream);
+
 extern "C" {
 int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps, hipStream_t);
 int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride, const float* d,

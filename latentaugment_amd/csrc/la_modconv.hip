@@ -21,13 +21,13 @@ extern "C" int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, fl
     return la_pack_conv_weights(w, wf, wb, wsq, cout, cin, ktaps, stream);
 }
 
-extern "C" int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
-                                     const float* d, int d_stride, const float* noise, long noise_bstride,
-                                     float noise_strength, const float* bias, int act, float alpha, float gain,
-                                     float clamp, float* y, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, hipStream_t stream) {
+int la_modconv3x3_fwd_ex(const float* x, long x_bstride, const float* in_pmax, int in_nseg, const float* wf, const void* wq, int precision, const float* s,
+                         int s_stride, const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
+                         const float* bias, int act, float alpha, float gain, float clamp, float* y, void* ws, size_t ws_bytes, int B,
+                         int cin, int cout, int res, hipStream_t stream) {
     LA_CHECK_ARG(x && wf && y, "modconv_fwd: null pointer");
     LaConvArgs a; base_args(a);
-    a.in = x; a.in_bstride = x_bstride; a.wgt = wf; a.out = y;
+    a.in = x; a.in_bstride = x_bstride; a.wgt = wf; a.out = y; a.in_pmax = in_pmax; a.in_pmax_nseg = in_nseg;
     a.in_scale = s; a.scale_stride = s_stride;
     a.ws = ws; a.ws_bytes = ws_bytes;
     a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cout, cin, 9);
@@ -41,11 +41,19 @@ extern "C" int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float
     return la_conv_launch(a, stream);
 }
 
-extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
-                                         const float* d, int d_stride, const float* noise, long noise_bstride,
-                                         float noise_strength, const float* bias, int act, float alpha, float gain,
-                                         float clamp, const float* fir_host, float* scratch, float* y, void* ws, size_t ws_bytes, int B, int cin,
-                                         int cout, int res, hipStream_t stream) {
+extern "C" int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride, const float* d,
+                                     int d_stride, const float* noise, long noise_bstride, float noise_strength, const float* bias,
+                                     int act, float alpha, float gain, float clamp, float* y, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
+                                     hipStream_t stream) {
+    return la_modconv3x3_fwd_ex(x, x_bstride, nullptr, 0, wf, wq, precision, s, s_stride, d, d_stride, noise, noise_bstride, noise_strength, bias, act,
+                                alpha, gain, clamp, y, ws, ws_bytes, B, cin, cout, res, stream);
+}
+
+int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
+                             const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
+                             const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
+                             float* scratch, float* y, float* y_pmax, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
+                             hipStream_t stream) {
     LA_CHECK_ARG(x && wf && y && scratch && fir_host, "modconv_up2_fwd: null pointer");
     LA_CHECK_ARG(res >= 2 && res % 2 == 0, "modconv_up2_fwd: output resolution must be even");
     // transposed stride-2 conv as 4 output phases: row Y = 2*qy + py receives taps ky with (Y - ky) even
@@ -77,15 +85,24 @@ extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const f
         }
     // FIR with pad (1,1,1,1) and gain up^2 = 4 (conv2d_resample.py:119-126), then the layer epilogue
     return la_upfirdn2d_modconv_epilogue(scratch, y, B, cout, res + 1, res + 1, fir_host, 4, 4, 1, 1, 1, 1, 4.f, d, d_stride,
-                                         noise, noise_bstride, noise_strength, bias, act, alpha, gain, clamp, stream);
+                                         noise, noise_bstride, noise_strength, bias, act, alpha, gain, clamp, stream, y_pmax);
 }
 
-extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
-                                     long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
-                                     hipStream_t stream) {
+extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
+                                         const float* d, int d_stride, const float* noise, long noise_bstride,
+                                         float noise_strength, const float* bias, int act, float alpha, float gain,
+                                         float clamp, const float* fir_host, float* scratch, float* y, void* ws, size_t ws_bytes, int B, int cin,
+                                         int cout, int res, hipStream_t stream) {
+    return la_modconv3x3_up2_fwd_ex(x, x_bstride, wf, wq, precision, s, s_stride, d, d_stride, noise, noise_bstride, noise_strength, bias, act,
+                                    alpha, gain, clamp, fir_host, scratch, y, nullptr, ws, ws_bytes, B, cin, cout, res, stream);
+}
+
+int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, const float* wb, const void* wq, int precision, const float* s, int s_stride,
+                         const float* xin, long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
+                         int res, hipStream_t stream) {
     LA_CHECK_ARG(gz && wb && gx, "modconv_bwd: null pointer");
     LaConvArgs a; base_args(a);
-    a.in = gz; a.in_bstride = (long)cout * res * res; a.wgt = wb; a.out = gx;
+    a.in = gz; a.in_bstride = (long)cout * res * res; a.wgt = wb; a.out = gx; a.in_pmax = in_pmax; a.in_pmax_nseg = in_nseg;
     a.ws = ws; a.ws_bytes = ws_bytes;
     a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cin, cout, 9);
     a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = a.Hout = a.Wout = a.Gy = a.Gx = res;
@@ -98,6 +115,12 @@ extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const voi
     return la_conv_launch(a, stream);
 }
 
+extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
+                                     long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
+                                     hipStream_t stream) {
+    return la_modconv3x3_bwd_ex(gz, nullptr, 0, wb, wq, precision, s, s_stride, xin, xin_bstride, gx, ds_part, ws, ws_bytes, B, cin, cout, res, stream);
+}
+
 extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
                                          long xin_bstride, const float* fir_host, float* scratch, float* gx,
                                          float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
@@ -105,10 +128,20 @@ extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const
     LA_CHECK_ARG(gz && wb && gx && scratch && fir_host, "modconv_up2_bwd: null pointer");
     const int hin = res / 2;
     // adjoint of [pad (1,1,1,1) -> FIR]: pad fw-1-pad = 2 per side, flipped filter, same gain (upfirdn2d.py:255-266)
-    int rc = la_upfirdn2d_ex(gz, scratch, B, cout, res, res, fir_host, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, 1, 4.f, nullptr, stream);
+    // (fp16 mode: the FIR kernel also leaves the plane maxima of the scratch at the head of ws, so the contraction below
+    //  needs no absmax pass)
+    float* pmax = nullptr;
+    const int nseg = la_fir4x4_segments(res + 1, res + 1);
+    const size_t pm_bytes = ((size_t)B * cout * nseg * sizeof(float) + 255) & ~(size_t)255;
+    if (precision == LA_PREC_F16X2 && ws && ws_bytes > pm_bytes) {
+        pmax = static_cast<float*>(ws);
+        ws = static_cast<char*>(ws) + pm_bytes;
+        ws_bytes -= pm_bytes;
+    }
+    int rc = la_upfirdn2d_ex(gz, scratch, B, cout, res, res, fir_host, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, 1, 4.f, nullptr, stream, pmax);
     if (rc) return rc;
     LaConvArgs a; base_args(a);
-    a.in = scratch; a.in_bstride = (long)cout * (res + 1) * (res + 1); a.wgt = wb; a.out = gx;
+    a.in = scratch; a.in_bstride = (long)cout * (res + 1) * (res + 1); a.wgt = wb; a.out = gx; a.in_pmax = pmax; a.in_pmax_nseg = nseg;
     a.ws = ws; a.ws_bytes = ws_bytes;
     a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cin, cout, 9);
     a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = res + 1; a.Hout = a.Wout = a.Gy = a.Gx = hin;
@@ -144,6 +177,8 @@ extern "C" size_t la_modconv_workspace_bytes(int B, int cin, int cout, int res, 
         if (nf > need) need = nf;
         if (nb > need) need = nb;
     }
+    // head of the workspace in la_modconv3x3_up2_bwd (fp16 mode): plane maxima of the FIR-adjoint scratch
+    need += ((size_t)B * (cin > cout ? cin : cout) * la_fir4x4_segments(res + 1, res + 1) * sizeof(float) + 255) & ~(size_t)255;
     return need;
 }
 

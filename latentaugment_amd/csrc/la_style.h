@@ -42,6 +42,7 @@ struct LaSeamArgs {
     const float* wrgb;       // [imgc][C]
     const float* s_rgb; int s_stride;   // styles of the ToRGB layer (already * weight_gain)
     float* dweff_part;       // [B][imgc][C][slabs]
+    float* pmax_out;         // optional [B][C][slabs]: partial max |gz| per plane (one per workgroup)
 };
 
 int la_pack_conv_weights(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps, hipStream_t,

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void la_seam_bwd_kernel(LaSeamArgs a) {
     float weff[IMGC > 0 ? IMGC : 1];
 #pragma unroll
     for (int k = 0; k < IMGC; ++k) weff[k] = a.wrgb[k * a.C + c] * a.s_rgb[(long)b * a.s_stride + c];
-    float ddn = 0.f;
+    float ddn = 0.f, gmax = 0.f;
     float dwe[IMGC > 0 ? IMGC : 1];
 #pragma unroll
     for (int k = 0; k < IMGC; ++k) dwe[k] = 0.f;
@@ -317,6 +317,16 @@ __global__ __launch_bounds__(256) void la_seam_bwd_kernel(LaSeamArgs a) {
         ONE(x) ONE(y) ONE(z) ONE(w)
 #undef ONE
         *reinterpret_cast<float4*>(a.gz + plane + p) = gz;
+        gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(gz.x), fabsf(gz.y)), fmaxf(fabsf(gz.z), fabsf(gz.w))));
+    }
+    if (a.pmax_out) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gmax;
+        __syncthreads();
+        if (threadIdx.x == 0) a.pmax_out[((long)b * a.C + c) * gridDim.x + slab] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
     }
     const float ddn_t = la_block_sum_256(ddn, red);
     if (threadIdx.x == 0 && a.ddn_part) a.ddn_part[((long)b * a.C + c) * gridDim.x + slab] = ddn_t;

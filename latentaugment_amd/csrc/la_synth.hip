@@ -50,6 +50,7 @@ struct la_synth {
     float *zT, *G0, *G1, *ds_part, *ddn_part, *dweff_part, *aff_part;
     void* cws;
     size_t cws_bytes;
+    float* pmax;             // [maxB][max channels]: plane maxima handed from a producing kernel to the next contraction (fp16 mode)
     int lastB;
     int precision;
     float* final_img;   // where the last forward put the full-resolution image
@@ -115,6 +116,17 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
     h->aff_part = c.take((size_t)la_affine_bwd_chunks(h->st) * mb * h->wdim);
     h->cws = c.take((skf + 3) / 4);
     h->cws_bytes = skf;
+    {
+        // plane-maxima hand-off buffer: [B][C][segments] of the largest producer (FIR epilogue of an up layer, seam kernel)
+        size_t pmx = 0;
+        for (int k = 0; k < h->nconv; ++k) {
+            const ConvLayer& L = h->conv[k];
+            const size_t a = (size_t)L.cout * (L.up ? la_fir4x4_segments(L.res, L.res) : 1), b2 = (size_t)L.cout * la_seam_slabs((long)L.res * L.res);
+            if (a > pmx) pmx = a;
+            if (b2 > pmx) pmx = b2;
+        }
+        h->pmax = c.take(mb * pmx);
+    }
     *need = c.off;
     return LA_OK;
 }
@@ -265,6 +277,9 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
     int ci = 0;
     const float* x = h->cst;
     long x_bstride = 0;
+    const bool f16 = h->precision == LA_PREC_F16X2;
+    const float* x_pmax = nullptr;      // plane maxima of x when its producer (the FIR epilogue of an up-sampling layer) left them
+    int x_nseg = 0;
     for (int k = 0; k < h->nblocks; ++k) {
         const int res = 4 << k;
         const int nl = (k == 0) ? 1 : 2;
@@ -276,14 +291,19 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
                 else if (noise_mode == 2) { L.noise_used = noises[ci]; L.noise_bstride = (long)res * res; LA_CHECK_ARG(L.noise_used, "synth_forward: missing noise tensor"); }
             }
             const float sq2 = sqrtf(2.f);
-            if (!L.up)
-                rc = la_modconv3x3_fwd_f32(x, x_bstride, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
-                                           L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f, sq2,
-                                           h->clamp, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream);
-            else
-                rc = la_modconv3x3_up2_fwd_f32(x, x_bstride, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
-                                               L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f,
-                                               sq2, h->clamp, h->fir, h->zT, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream);
+            if (!L.up) {
+                rc = la_modconv3x3_fwd_ex(x, x_bstride, x_pmax, x_nseg, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
+                                          L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f, sq2,
+                                          h->clamp, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream);
+                x_pmax = nullptr;
+            } else {
+                rc = la_modconv3x3_up2_fwd_ex(x, x_bstride, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
+                                              L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f,
+                                              sq2, h->clamp, h->fir, h->zT, L.y, f16 ? h->pmax : nullptr, h->cws, h->cws_bytes, B, L.cin,
+                                              L.cout, res, stream);
+                x_pmax = f16 ? h->pmax : nullptr;
+                x_nseg = la_fir4x4_segments(res, res);
+            }
             if (rc) return rc;
             x = L.y; x_bstride = (long)L.cout * res * res;
         }
@@ -328,6 +348,8 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
         s.ddn_part = h->ddn_part;
         s.g_img = gi; s.rgb_pre = T.rgb_pre; s.rgb_clamp = h->clamp; s.wrgb = T.weight;
         s.s_rgb = h->s_all + T.s_off; s.s_stride = h->S; s.dweff_part = h->dweff_part;
+        const bool f16 = h->precision == LA_PREC_F16X2;
+        if (f16) s.pmax_out = h->pmax;      // the seam kernel leaves the plane maxima of gz for the contraction that follows
         if ((rc = la_seam_backward(s, B, h->imgc, stream))) return rc;
         const int slabs = la_seam_slabs(HW);
         if ((rc = la_style_backward_rgb(h->dweff_part, slabs, T.weight, T.cin, h->imgc, B, h->ds_all + T.s_off, h->S, stream)))
@@ -337,8 +359,8 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
             const float* xin = (k == 0) ? h->cst : h->conv[ci - 1].y;
             const long xin_bs = (k == 0) ? 0 : (long)L1.cin * HW;
             const int tiles = la_modconv_ds_tiles(res);
-            if ((rc = la_modconv3x3_bwd_f32(h->G0, L1.wb, L1.wqb, h->precision, h->s_all + L1.s_off, h->S, xin, xin_bs, h->G1, h->ds_part, h->cws, h->cws_bytes, B, L1.cin,
-                                            L1.cout, res, stream)))
+            if ((rc = la_modconv3x3_bwd_ex(h->G0, f16 ? h->pmax : nullptr, slabs, L1.wb, L1.wqb, h->precision, h->s_all + L1.s_off, h->S, xin, xin_bs, h->G1,
+                                           h->ds_part, h->cws, h->cws_bytes, B, L1.cin, L1.cout, res, stream)))
                 return rc;
             if ((rc = la_style_backward_conv(h->ds_part, tiles, h->ddn_part, slabs, h->d_all + L1.d_off, h->Dt,
                                              h->s_all + L1.s_off, h->S, L1.wsq, L1.cin, L1.cout, B,

@@ -5,7 +5,10 @@
 // generic op, optional same-shape addend (skip connection add fused into the store)
 int la_upfirdn2d_ex(const float* in, float* out, int B, int C, int Hin, int Win, const float* f_host, int fh, int fw,
                     int upx, int upy, int dnx, int dny, int padx0, int padx1, int pady0, int pady1, int flip_filter,
-                    float gain, const float* addend, hipStream_t stream);
+                    float gain, const float* addend, hipStream_t stream, float* pmax = nullptr);
+// pmax (optional, [B*C][la_fir4x4_segments(Hout, Wout)]): partial max |out| of every plane, one per workgroup -- lets the
+// contraction that consumes `out` skip its own absmax pass (fp16 operand scale).
+int la_fir4x4_segments(int Hout, int Wout);
 
 // FIR (up=down=1) followed by the modulated-conv epilogue: *demod[b][c] + noise*strength + bias[c] -> act -> clamp.
 // Used after the transposed stride-2 conv of an up-sampling SynthesisLayer (conv2d_resample.py:126).
@@ -13,4 +16,4 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
                                   int fh, int fw, int padx0, int padx1, int pady0, int pady1, float fir_gain,
                                   const float* demod, int demod_stride, const float* noise, long noise_bstride,
                                   float noise_strength, const float* bias, int act, float alpha, float gain,
-                                  float clamp, hipStream_t stream);
+                                  float clamp, hipStream_t stream, float* pmax = nullptr);

@@ -19,6 +19,7 @@ struct FirArgs {
     const float* bias;
     int act; float alpha, gain, clamp;
     const float* addend;         // optional same-shape tensor added to the result (skip connection), epi 0 only
+    float* pmax;                 // optional [P][la_fir4x4_segments(Hout, Wout)]: partial max |out| per plane, 4x4 stride-1 kernel only
 };
 
 __global__ __launch_bounds__(256) void la_upfirdn2d_kernel(FirArgs a) {
@@ -62,10 +63,60 @@ __global__ __launch_bounds__(256) void la_upfirdn2d_kernel(FirArgs a) {
 // Lanes = 64 consecutive columns -> every load / store is a coalesced 256-B row segment; the +-3 halo re-reads hit L1/L2.
 #define FIR_ROWS 8
 template <int EPI>
+__device__ __forceinline__ float la_fir4x4_plane(const FirArgs& a, const float (&f)[16], const bool (&xok)[4], int p, int x, int y0, int ix0,
+                                                int iy0, long HWin, long HWout) {
+    const float* ip = a.in + (long)p * HWin;
+    float acc[FIR_ROWS];
+#pragma unroll
+    for (int r = 0; r < FIR_ROWS; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int wr = 0; wr < FIR_ROWS + 3; ++wr) {
+        const int iy = iy0 + wr;
+        float v[4];
+        const bool yok = iy >= 0 && iy < a.Hin;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (yok && xok[j]) ? ip[(long)iy * a.Win + ix0 + j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < FIR_ROWS; ++r) {
+            const int ta = wr - r;          // filter row used by output row r
+            if (ta >= 0 && ta < 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r] += v[j] * f[ta * 4 + j];
+            }
+        }
+    }
+    float dm = 1.f, bv = 0.f;
+    if (EPI == 1) {
+        const int b = p / a.C, c = p - b * a.C;
+        if (a.demod) dm = a.demod[(long)b * a.demod_stride + c];
+        if (a.bias) bv = a.bias[c];
+    }
+    float mx = 0.f;
+#pragma unroll
+    for (int r = 0; r < FIR_ROWS; ++r) {
+        const int y = y0 + r;
+        if (y >= a.Hout) break;
+        float v = acc[r];
+        const long pos = (long)y * a.Wout + x;
+        if (EPI == 1) {
+            v = v * dm + bv;
+            if (a.noise) v += a.noise[(long)(p / a.C) * a.noise_bstride + pos] * a.noise_strength;
+            v = la_act_fwd(v, a.act, a.alpha, a.gain, a.clamp);
+        } else if (a.addend) {
+            v += a.addend[(long)p * HWout + pos];
+        }
+        a.out[(long)p * HWout + pos] = v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+    return mx;
+}
+
+template <int EPI>
 __global__ __launch_bounds__(256) void la_fir4x4_s1_kernel(FirArgs a) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * FIR_ROWS;
-    if (x >= a.Wout || y0 >= a.Hout) return;
+    const bool live = x < a.Wout && y0 < a.Hout;
+    if (!live && !a.pmax) return;                       // (with plane maxima, dead lanes wait for the wave reduction)
     const long HWin = (long)a.Hin * a.Win, HWout = (long)a.Hout * a.Wout;
     float f[16];
 #pragma unroll
@@ -75,46 +126,17 @@ __global__ __launch_bounds__(256) void la_fir4x4_s1_kernel(FirArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) xok[j] = (ix0 + j) >= 0 && (ix0 + j) < a.Win;
     for (int p = blockIdx.z; p < a.P; p += gridDim.z) {
-        const float* ip = a.in + (long)p * HWin;
-        float acc[FIR_ROWS];
+        float mx = 0.f;
+        if (live) mx = la_fir4x4_plane<EPI>(a, f, xok, p, x, y0, ix0, iy0, HWin, HWout);
+        if (a.pmax) {      // one partial maximum per (plane, workgroup): plain store, reduced by the consumer (no atomics)
+            __shared__ float wmax[4];
 #pragma unroll
-        for (int r = 0; r < FIR_ROWS; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int wr = 0; wr < FIR_ROWS + 3; ++wr) {
-            const int iy = iy0 + wr;
-            float v[4];
-            const bool yok = iy >= 0 && iy < a.Hin;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (yok && xok[j]) ? ip[(long)iy * a.Win + ix0 + j] : 0.f;
-#pragma unroll
-            for (int r = 0; r < FIR_ROWS; ++r) {
-                const int ta = wr - r;          // filter row used by output row r
-                if (ta >= 0 && ta < 4) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[r] += v[j] * f[ta * 4 + j];
-                }
-            }
-        }
-        float dm = 1.f, bv = 0.f;
-        if (EPI == 1) {
-            const int b = p / a.C, c = p - b * a.C;
-            if (a.demod) dm = a.demod[(long)b * a.demod_stride + c];
-            if (a.bias) bv = a.bias[c];
-        }
-#pragma unroll
-        for (int r = 0; r < FIR_ROWS; ++r) {
-            const int y = y0 + r;
-            if (y >= a.Hout) break;
-            float v = acc[r];
-            const long pos = (long)y * a.Wout + x;
-            if (EPI == 1) {
-                v = v * dm + bv;
-                if (a.noise) v += a.noise[(long)(p / a.C) * a.noise_bstride + pos] * a.noise_strength;
-                v = la_act_fwd(v, a.act, a.alpha, a.gain, a.clamp);
-            } else if (a.addend) {
-                v += a.addend[(long)p * HWout + pos];
-            }
-            a.out[(long)p * HWout + pos] = v;
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+            __syncthreads();
+            if (threadIdx.x == 0)
+                a.pmax[(long)p * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
         }
     }
 }
@@ -130,7 +152,7 @@ static int fir_fill(FirArgs& a, const float* in, float* out, int B, int C, int H
     LA_CHECK_ARG(upW >= fw && upH >= fh, "upfirdn2d: upsampled image smaller than the filter");
     *Wout = (upW - fw + dnx) / dnx;   // upfirdn2d.cpp:35-36
     *Hout = (upH - fh + dny) / dny;
-    a.in = in; a.out = out; a.P = B * C; a.C = C;
+    a.in = in; a.out = out; a.P = B * C; a.C = C; a.pmax = nullptr;
     a.Hin = Hin; a.Win = Win; a.Hout = *Hout; a.Wout = *Wout;
     a.upx = upx; a.upy = upy; a.dnx = dnx; a.dny = dny; a.padx0 = padx0; a.pady0 = pady0;
     a.fw = fw; a.fh = fh;
@@ -143,6 +165,8 @@ static int fir_fill(FirArgs& a, const float* in, float* out, int B, int C, int H
     a.act = LA_ACT_LINEAR; a.alpha = 0.f; a.gain = 1.f; a.clamp = -1.f;
     return LA_OK;
 }
+
+int la_fir4x4_segments(int Hout, int Wout) { return la_cdiv(Wout, 64) * la_cdiv(Hout, 4 * FIR_ROWS); }
 
 static int fir_launch(const FirArgs& a, hipStream_t stream) {
     if (a.upx == 1 && a.upy == 1 && a.dnx == 1 && a.dny == 1 && a.fw == 4 && a.fh == 4) {
@@ -162,12 +186,14 @@ static int fir_launch(const FirArgs& a, hipStream_t stream) {
 
 int la_upfirdn2d_ex(const float* in, float* out, int B, int C, int Hin, int Win, const float* f_host, int fh, int fw,
                     int upx, int upy, int dnx, int dny, int padx0, int padx1, int pady0, int pady1, int flip_filter,
-                    float gain, const float* addend, hipStream_t stream) {
+                    float gain, const float* addend, hipStream_t stream, float* pmax) {
     FirArgs a; int ho, wo;
     int rc = fir_fill(a, in, out, B, C, Hin, Win, f_host, fh, fw, upx, upy, dnx, dny, padx0, padx1, pady0, pady1,
                       flip_filter, gain, &ho, &wo);
     if (rc) return rc;
     a.addend = addend;
+    if (pmax && upx == 1 && upy == 1 && dnx == 1 && dny == 1 && fw == 4 && fh == 4) a.pmax = pmax;
+    else LA_CHECK_ARG(!pmax, "upfirdn2d: plane maxima are produced by the 4x4 stride-1 kernel only");
     return fir_launch(a, stream);
 }
 
@@ -175,13 +201,15 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
                                   int fh, int fw, int padx0, int padx1, int pady0, int pady1, float fir_gain,
                                   const float* demod, int demod_stride, const float* noise, long noise_bstride,
                                   float noise_strength, const float* bias, int act, float alpha, float gain,
-                                  float clamp, hipStream_t stream) {
+                                  float clamp, hipStream_t stream, float* pmax) {
     FirArgs a; int ho, wo;
     int rc = fir_fill(a, in, out, B, C, Hin, Win, f_host, fh, fw, 1, 1, 1, 1, padx0, padx1, pady0, pady1, 0, fir_gain,
                       &ho, &wo);
     if (rc) return rc;
     a.epi = 1; a.demod = demod; a.demod_stride = demod_stride; a.noise = noise; a.noise_bstride = noise_bstride;
     a.noise_strength = noise_strength; a.bias = bias; a.act = act; a.alpha = alpha; a.gain = gain; a.clamp = clamp;
+    if (fw == 4 && fh == 4) a.pmax = pmax;
+    else LA_CHECK_ARG(!pmax, "upfirdn2d: plane maxima are produced by the 4x4 stride-1 kernel only");
     return fir_launch(a, stream);
 }
 
