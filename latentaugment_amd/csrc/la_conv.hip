@@ -20,10 +20,11 @@ long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx, int precision) {
     if (G > SPLITK_MAX_G || nck < 2) return 0;
     const int mtiles = la_cdiv(M, M >= 128 ? 128 : 64);
     const int ntiles_flat = la_cdiv((long)B * G, NT);
+    // upper bound over the slice counts la_conv_launch may choose (fp32: ceil(768 / tiles); 16-bit: cost model, <= 16)
     int ks = la_cdiv(768, (long)ntiles_flat * mtiles);
+    if (precision != LA_PREC_F32 && ks < 16) ks = 16;
     if (ks > nck) ks = nck;
     if (ks < 2) return 0;
-    ks = la_cdiv(nck, la_cdiv(nck, ks));
     return (long)ks * B * M * G;
 }
 
@@ -282,10 +283,22 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
     }
     if (as.splitk_ws && G <= SPLITK_MAX_G && nck >= 2) {
         const int ntiles_flat = la_cdiv((long)a.B * G, NT);
-        // fill the 512 resident workgroup slots (2 per CU) in ONE round: a second, half-empty round costs more than the
-        // longer K loop of fewer slices (and a longer K loop amortises the prologue / epilogue better)
+        // K slices: the 16-bit kernels keep 2 workgroups per CU = 512 resident slots.  A launch costs
+        // rounds(ks) * (1/ks + c) of one full K loop (c ~ prologue + epilogue + its share of the finish kernel), so pick the
+        // slice count that minimises it -- e.g. 256 tiles -> 2 slices in one round, 276 tiles -> 3 slices in two rounds.
         // (the fp32 kernel keeps 3 workgroups per CU: 768 slots, rounded up as before)
-        int ks = bf ? (int)(512 / ((long)ntiles_flat * mtiles)) : la_cdiv(768, (long)ntiles_flat * mtiles);
+        int ks;
+        if (bf) {
+            const long base = (long)ntiles_flat * mtiles;
+            float best = 1e30f;
+            ks = 1;
+            for (int k = 1; k <= nck && k <= 16; ++k) {
+                const float cost = (float)la_cdiv(base * k, 512) * (1.f / k + 0.08f);
+                if (cost < best - 1e-6f) { best = cost; ks = k; }
+            }
+        } else {
+            ks = la_cdiv(768, (long)ntiles_flat * mtiles);
+        }
         if (ks > nck) ks = nck;
         if (ks >= 2) {
             const int per = la_cdiv(nck, ks);
