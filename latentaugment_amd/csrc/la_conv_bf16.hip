@@ -169,40 +169,8 @@ int la_pack_conv_weights_bf16(const float* w, void* out, int cout, int cin, int 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// pre-split: q[b][c][p] = split3(x[b][c][p] * scale[b][c])  ->  uint2 {hi | mid << 16, lo}
-__global__ __launch_bounds__(256) void la_presplit_kernel(const float* __restrict__ in, long in_bstride,
-                                                         const float* __restrict__ scale, int scale_stride,
-                                                         uint2* __restrict__ out, int C, long HW) {
-    const int c = blockIdx.y, b = blockIdx.z;
-    const float sc = scale ? scale[(long)b * scale_stride + c] : 1.f;
-    const float* ip = in + (long)b * in_bstride + (long)c * HW;
-    uint2* op = out + ((long)b * C + c) * HW;
-    const bool aligned16 = ((((long)b * C + c) * HW) & 1) == 0;    // odd planes (e.g. 257^2) start on an 8-byte boundary
-    for (long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2; p < HW; p += (long)gridDim.x * blockDim.x * 2) {
-        float v0 = ip[p] * sc, v1 = (p + 1 < HW) ? ip[p + 1] * sc : 0.f;
-        unsigned short t0[3], t1[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
-            t0[q] = __builtin_bit_cast(unsigned short, h0);
-            t1[q] = __builtin_bit_cast(unsigned short, h1);
-            v0 -= (float)h0; v1 -= (float)h1;
-        }
-        const uint2 e0 = make_uint2((unsigned)t0[0] | ((unsigned)t0[1] << 16), (unsigned)t0[2]);
-        const uint2 e1 = make_uint2((unsigned)t1[0] | ((unsigned)t1[1] << 16), (unsigned)t1[2]);
-        if (p + 1 < HW) {
-            if (aligned16) *reinterpret_cast<uint4*>(op + p) = make_uint4(e0.x, e0.y, e1.x, e1.y);
-            else { op[p] = e0; op[p + 1] = e1; }
-        } else {
-            op[p] = e0;
-        }
-    }
-}
-
-// fp16 path, pass 1: max |x * scale| of every (b, c) plane in PM_NS segments, one workgroup per segment (no atomics);
-// pass 2: each workgroup reduces its sample's segment maxima, derives the power-of-two scale and splits.
+// fp16 operand scale, pass 1: max |x * scale| of every (b, c) plane in PM_NS segments, one workgroup per segment (no atomics)
 #define PM_NS 8
-#define PS_SEG 8192                // elements per workgroup of the fp16 pre-split pass
 __global__ __launch_bounds__(256) void la_plane_absmax_kernel(const float* __restrict__ in, long in_bstride,
                                                              const float* __restrict__ scale, int scale_stride,
                                                              float* __restrict__ pm, int C, long HW, int ns) {
@@ -268,45 +236,69 @@ __global__ __launch_bounds__(256) void la_xscale_pmax_kernel(const float* __rest
     if (threadIdx.x == 0) xscale[b] = la_pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
-__global__ __launch_bounds__(256) void la_presplit_f16_kernel(const float* __restrict__ in, long in_bstride,
-                                                             const float* __restrict__ scale, int scale_stride,
-                                                             const float* __restrict__ xscale,
-                                                             unsigned* __restrict__ out, int C, long HW) {
-    const int c = blockIdx.y, b = blockIdx.z;
-    const float xs = xscale[b];
-    const float sc = (scale ? scale[(long)b * scale_stride + c] : 1.f) * xs;
-    const float* ip = in + (long)b * in_bstride + (long)c * HW;
-    unsigned* op = out + ((long)b * C + c) * HW;
-    auto split = [](float v) -> unsigned {
-        const _Float16 h = (_Float16)v;
-        const _Float16 l = (_Float16)(v - (float)h);
-        return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-    };
-    // each workgroup owns PS_SEG consecutive elements of the plane
-    const long p0 = (long)blockIdx.x * PS_SEG, p1 = p0 + PS_SEG < HW ? p0 + PS_SEG : HW;
-    if ((((size_t)ip | (size_t)op | (size_t)(HW * 4)) & 15) == 0) {          // aligned plane: 16-byte loads and stores
-        const float4* ip4 = reinterpret_cast<const float4*>(ip);
-        uint4* op4 = reinterpret_cast<uint4*>(op);
-        long q = p0 / 4 + threadIdx.x;
-        const long q1 = p1 / 4;
-        for (; q + 768 < q1; q += 1024) {
-            const float4 v0 = ip4[q], v1 = ip4[q + 256], v2 = ip4[q + 512], v3 = ip4[q + 768];
-            op4[q] = make_uint4(split(v0.x * sc), split(v0.y * sc), split(v0.z * sc), split(v0.w * sc));
-            op4[q + 256] = make_uint4(split(v1.x * sc), split(v1.y * sc), split(v1.z * sc), split(v1.w * sc));
-            op4[q + 512] = make_uint4(split(v2.x * sc), split(v2.y * sc), split(v2.z * sc), split(v2.w * sc));
-            op4[q + 768] = make_uint4(split(v3.x * sc), split(v3.y * sc), split(v3.z * sc), split(v3.w * sc));
+// Pre-split copy for the flat kernel, CHANNEL-INTERLEAVED: q[b][chunk][pixel][32 channels] (4 B per element fp16 {h | l<<16},
+// 8 B bf16 {h | m<<16, l}; channels past C are zeros).  The flat kernel's gather thread (pixel, 16-channel half) then reads its
+// operand as 64 / 128 contiguous bytes (4 / 8 dwordx4) instead of 16 strided dwords, and a stride-2 gather wastes no sectors.
+// One workgroup = 32 channels x 64 pixels, transposed through LDS.
+template <bool F16>
+__global__ __launch_bounds__(256) void la_presplit_t_kernel(const float* __restrict__ in, long in_bstride,
+                                                           const float* __restrict__ scale, int scale_stride,
+                                                           const float* __restrict__ xscale, unsigned* __restrict__ out, int C, long HW) {
+    constexpr int EW = F16 ? 1 : 2;                           // dwords per element
+    __shared__ unsigned tile[EW][64][33];
+    const int cc = blockIdx.y, b = blockIdx.z, nck = gridDim.y;
+    const long p0 = (long)blockIdx.x * 64;
+    const float xs = F16 ? xscale[b] : 1.f;
+    {
+        const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
+        const long p = p0 + px;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int cl = cg * 8 + i, c = cc * KCB + cl;
+            float v = 0.f;
+            if (c < C && p < HW) v = in[(long)b * in_bstride + (long)c * HW + p] * ((scale ? scale[(long)b * scale_stride + c] : 1.f) * xs);
+            if (F16) {
+                const _Float16 h = (_Float16)v;
+                const _Float16 l = (_Float16)(v - (float)h);
+                tile[0][px][cl] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+            } else {
+                unsigned short t[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const __bf16 h = (__bf16)v;
+                    t[q] = __builtin_bit_cast(unsigned short, h);
+                    v -= (float)h;
+                }
+                tile[0][px][cl] = (unsigned)t[0] | ((unsigned)t[1] << 16);
+                tile[EW - 1][px][cl] = (unsigned)t[2];
+            }
         }
-        for (; q < q1; q += 256) {
-            const float4 v = ip4[q];
-            op4[q] = make_uint4(split(v.x * sc), split(v.y * sc), split(v.z * sc), split(v.w * sc));
+    }
+    __syncthreads();
+    {
+        const int px = threadIdx.x >> 2, qt = threadIdx.x & 3;         // 8 channels of one pixel per thread
+        const long p = p0 + px;
+        if (p < HW) {
+            unsigned* op = out + (((long)b * nck + cc) * HW + p) * (KCB * EW) + qt * 8 * EW;
+            if (F16) {
+                uint4 w0 = make_uint4(tile[0][px][qt * 8 + 0], tile[0][px][qt * 8 + 1], tile[0][px][qt * 8 + 2], tile[0][px][qt * 8 + 3]);
+                uint4 w1 = make_uint4(tile[0][px][qt * 8 + 4], tile[0][px][qt * 8 + 5], tile[0][px][qt * 8 + 6], tile[0][px][qt * 8 + 7]);
+                reinterpret_cast<uint4*>(op)[0] = w0;
+                reinterpret_cast<uint4*>(op)[1] = w1;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    reinterpret_cast<uint4*>(op)[k] = make_uint4(tile[0][px][qt * 8 + 2 * k], tile[EW - 1][px][qt * 8 + 2 * k],
+                                                                 tile[0][px][qt * 8 + 2 * k + 1], tile[EW - 1][px][qt * 8 + 2 * k + 1]);
+            }
         }
-    } else {
-        for (long p = p0 + threadIdx.x; p < p1; p += 256) op[p] = split(ip[p] * sc);
     }
 }
 
 static inline size_t presplit_hdr_bytes(int B, int C) { return (PRESPLIT_HDR + (size_t)B * C * PM_NS * 4 + 255) & ~(size_t)255; }
-size_t la_conv_presplit_bytes(int B, int C, int Hin, int Win) { return (size_t)B * C * Hin * Win * 8 + 16 + presplit_hdr_bytes(B, C); }
+size_t la_conv_presplit_bytes(int B, int C, int Hin, int Win) {      // channel-interleaved copy, C padded to whole chunks, 8 B / element
+    return (size_t)B * la_cdiv(C, KCB) * KCB * Hin * Win * 8 + 16 + presplit_hdr_bytes(B, C);
+}
 
 // fp16 path: per-sample operand scale (segment maxima -> xscale[b]) in the header of the workspace; advances a.ws past it
 static int prepare_scale(LaConvArgs& a, hipStream_t stream) {
@@ -360,19 +352,18 @@ int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
     LA_CHECK_ARG(a.B <= 64, "conv: split precisions support at most 64 samples per launch");
     char* base = static_cast<char*>(a.ws);
     const size_t ws_bytes = a.ws_bytes;
+    const dim3 pgrid((unsigned)la_cdiv(HW, 64), (unsigned)la_cdiv(a.C, KCB), (unsigned)a.B);
     if (a.precision == LA_PREC_F16X2) {
         int rc = prepare_scale(a, stream);
         if (rc) return rc;
         void* q = a.ws;
-        hipLaunchKernelGGL(la_presplit_f16_kernel, dim3(la_cdiv(HW, PS_SEG), a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride,
-                           a.in_scale, a.scale_stride, a.acc_scale_x, (unsigned*)q, a.C, HW);
+        hipLaunchKernelGGL(la_presplit_t_kernel<true>, pgrid, dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale, a.scale_stride,
+                           a.acc_scale_x, (unsigned*)q, a.C, HW);
         a.in_q = q;
     } else {
         void* q = base + presplit_hdr_bytes(a.B, a.C);
-        int gx = la_cdiv(HW, 512);
-        if (gx > 64) gx = 64;
-        hipLaunchKernelGGL(la_presplit_kernel, dim3(gx, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
-                           a.scale_stride, (uint2*)q, a.C, HW);
+        hipLaunchKernelGGL(la_presplit_t_kernel<false>, pgrid, dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale, a.scale_stride,
+                           (const float*)nullptr, (unsigned*)q, a.C, HW);
         a.in_q = q;
     }
     LA_CHECK_LAUNCH();
@@ -452,14 +443,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     const int nstep = ck_end > ck_beg ? (ck_end - ck_beg) * ntaps : 0;
     const long term_elems = a.wgt_bf16_term_elems;
     // buffer descriptors (wave-uniform).  Direct mode: this sample's pre-split input; split-K: the whole batch.
-    const unsigned samp_bytes = (unsigned)a.C * HWin * EB;
+    // pre-split layout: [b][chunk][pixel][32 channels] -> a gather thread reads 16 contiguous channels of its pixel
+    const unsigned samp_bytes = (unsigned)nck * KCB * HWin * EB;
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(static_cast<const char*>(a.in_q)) + (SPLIT ? (size_t)0 : (size_t)blockIdx.z * samp_bytes), 0,
         (int)(SPLIT ? samp_bytes * (unsigned)a.B : samp_bytes), 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(static_cast<const char*>(a.wgt_bf16)) + (F16 ? pack_f16_offset(term_elems) : 0), 0, (int)(NTERM * term_elems * 2),
         0x00020000);
-    const unsigned lane_base = (SPLIT ? (unsigned)b_l * samp_bytes : 0u) + (unsigned)(khalf * 16) * HWin * EB;
+    const unsigned lane_base = (SPLIT ? (unsigned)b_l * samp_bytes : 0u) + (unsigned)(khalf * 16) * EB;
 
     // tap table -> packed scalars (offsets are within +-7), so the step loop needs no indexed kernarg reads
     unsigned long long dypack = 0ull, dxpack = 0ull, wpack = 0ull;
@@ -470,29 +462,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
         wpack |= (unsigned long long)(a.tap_w[t] & 15) << (4 * t);
     }
 
-    // ---- B gather of one step: 16 channels of this thread's pixel
+    // ---- B gather of one step: 16 channels of this thread's pixel = 64 / 128 contiguous bytes
     unsigned ex[16], ey[NTERM == 3 ? 16 : 1];
     bool ok_r = false;
     auto load_b = [&](int cc, int t) {
         const int iy = iy0 + (int)((dypack >> (4 * t)) & 15u) - 8, ix = ix0 + (int)((dxpack >> (4 * t)) & 15u) - 8;
         ok_r = nvalid && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
         const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
-        const unsigned off = (unsigned)(iyc * a.Win + ixc) * EB;
-        const bool fast = cc * KCB + KCB <= a.C;                  // uniform: only a ragged last chunk clamps channels
+        const unsigned vo = lane_base + (unsigned)(iyc * a.Win + ixc) * (KCB * EB);
+        const unsigned so = (unsigned)cc * HWin * (KCB * EB);
+        if (NTERM == 3) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            unsigned vo, so;
-            if (fast) { vo = lane_base + off; so = (unsigned)(cc * KCB + j) * HWin * EB; }
-            else {
-                const int c = cc * KCB + khalf * 16 + j;
-                vo = lane_base - (unsigned)(khalf * 16) * HWin * EB + (unsigned)(c < a.C ? c : a.C - 1) * HWin * EB + off;
-                so = 0u;
+            for (int k = 0; k < 8; ++k) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, so + 16 * k, 0);
+                ex[2 * k] = v.x; ey[NTERM == 3 ? 2 * k : 0] = v.y; ex[2 * k + 1] = v.z; ey[NTERM == 3 ? 2 * k + 1 : 0] = v.w;
             }
-            if (NTERM == 3) {
-                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_in, vo, so, 0);
-                ex[j] = v.x;
-                ey[NTERM == 3 ? j : 0] = v.y;
-            } else ex[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, vo, so, 0);
+        } else if (F16) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, so + 16 * k, 0);
+                ex[4 * k] = v.x; ex[4 * k + 1] = v.y; ex[4 * k + 2] = v.z; ex[4 * k + 3] = v.w;
+            }
+        } else {      // 2 bf16 terms: the {h | m} words of the 8-byte elements
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, so + 16 * k, 0);
+                ex[2 * k] = v.x; ex[2 * k + 1] = v.z;
+            }
         }
     };
     const int wrow = n_l * BPITCH, wsw = (n_l >> 2) & 3;

@@ -148,7 +148,9 @@ def _modconv_case(dev, B, cin, cout, res, up, noise_strength, seed, splitk=True,
     skn = int(lib.la_modconv_workspace_bytes(B, cin, cout, res, 1 if up else 0))
     if not splitk:      # only room for the pre-split input: forces the direct (non split-K) kernels
         rin_ = res // 2 if up else res
-        skn = (8 * B * max(cin * rin_ * rin_, cout * (res + 1) * (res + 1)) + 16 + 1024 + 32 * B * max(cin, cout) + 255) // 256 * 256 if prec else 0
+        pad32 = lambda c: (c + 31) // 32 * 32      # the pre-split copy is channel-interleaved in whole 32-channel chunks
+        skn = (8 * B * max(pad32(cin) * rin_ * rin_, pad32(cout) * (res + 1) * (res + 1)) + 16 + 1024 + 32 * B * max(cin, cout)
+               + 4 * B * max(cin, cout) * 64 + 1024 + 255) // 256 * 256 if prec else 0
     skw = torch.empty([max(skn, 1)], dtype=torch.uint8, device=dev) if skn else None
     if up:
         _lib.check(lib.la_modconv3x3_up2_fwd_f32(_lib.ptr(xd), cin * rin * rin, _lib.ptr(wf), _lib.ptr(wqf), prec, _lib.ptr(sd), cin, _lib.ptr(d),
