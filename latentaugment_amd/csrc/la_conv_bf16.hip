@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
             if (t + 1 < ntaps) ++t;
             else if (c + 1 < ck_end) { ++c; t = 0; }
         };
-        bf16x8 acur[2][NTERM][TM], bf0[NTERM][NJ], bf1[NTERM][NJ];
+        bf16x8 acur[2][NTERM][TM], anxt[2][NTERM][TM], bf0[NTERM][NJ], bf1[NTERM][NJ];
         load_b(c1, t1);
         load_a(c1, t1, 0, acur[0]);
         load_a(c1, t1, 1, acur[1]);
@@ -604,18 +604,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
 #if LA_ABLATE != 11
             load_b(c2, t2);                            // step s+2
 #endif
+#if LA_ABLATE != 14
+            load_a(c1, t1, 0, anxt[0]);                // weights of step s+1: a full step ahead (they may come from beyond L2)
+            load_a(c1, t1, 1, anxt[1]);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             mma_step(acur[0], bf0);
-            __builtin_amdgcn_sched_barrier(0);
-#if LA_ABLATE != 14
-            load_a(c1, t1, 0, acur[0]);                // re-loaded as soon as its MFMAs have issued
-#endif
-            __builtin_amdgcn_sched_barrier(0);
             mma_step(acur[1], bf1);
-            __builtin_amdgcn_sched_barrier(0);
-#if LA_ABLATE != 14
-            load_a(c1, t1, 1, acur[1]);
-#endif
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int q = 0; q < NTERM; ++q)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acur[ks][q][i] = anxt[ks][q][i];
             c1 = c2; t1 = t2;
             adv(c2, t2);
 #if LA_ABLATE != 15
