@@ -13,6 +13,8 @@
 #define LA_EPI_FWD 1
 #define LA_EPI_BWD 2
 #define LA_CONV_MAX_TAPS 9
+#define LA_CONV_MAX_PHASES 4
+#define LA_CONV_PHASE_TAPS 4
 
 // contraction arithmetic: exact fp32 MFMA, or fp32 operands split into 3 / 2 bf16 terms on the bf16 MFMA (la_conv_bf16.hip)
 #define LA_PREC_F32 0
@@ -68,6 +70,11 @@ struct LaConvArgs {
     // LA_PREC_F16X2: acc is divided by xscale[b] * wscale (exact powers of two) before the epilogue; set by la_conv_prepare_input
     const float* acc_scale_x;      // [B]
     const float* acc_scale_w;      // [1]
+    // Merged output phases (transposed stride-2 conv, 16-bit direct kernel only): nphase > 0 runs all phases in ONE launch,
+    // blockIdx.z = phase * B + sample, each phase with its own grid / output offset / tap table (<= 4 taps).  One launch of
+    // ~4x the workgroups instead of four launches that each end in a nearly empty last round.
+    int nphase;
+    struct Phase { int Gy, Gx, out_oy, out_ox, ntaps; int tap_dy[LA_CONV_PHASE_TAPS], tap_dx[LA_CONV_PHASE_TAPS], tap_w[LA_CONV_PHASE_TAPS]; } ph[LA_CONV_MAX_PHASES];
 };
 
 long la_conv_bf16_pack_elems(int M, int C, int ktaps);   // elements per term

@@ -250,15 +250,34 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
         LA_CHECK_ARG(a.tiles_per_sample == la_conv_tiles_per_sample(a.Gy, a.Gx), "conv: tiles_per_sample mismatch");
         LA_CHECK_ARG(a.out_sy == 1 && a.out_sx == 1 && a.out_oy == 0 && a.out_ox == 0, "conv: bwd epilogue needs dense output");
     }
-    const int tiles = la_conv_tiles_per_sample(a.Gy, a.Gx);
+    int tiles = la_conv_tiles_per_sample(a.Gy, a.Gx);
+    const int nphase = a.nphase;
+    LA_CHECK_ARG(nphase >= 0 && nphase <= LA_CONV_MAX_PHASES, "conv: bad phase count");
+    if (nphase > 0) {
+        LA_CHECK_ARG(a.precision != LA_PREC_F32 && a.epi == LA_EPI_RAW && a.in_q, "conv: merged phases need a pre-split 16-bit launch without epilogue");
+        tiles = 0;
+        for (int p = 0; p < nphase; ++p) {
+            const LaConvArgs::Phase& P = a.ph[p];
+            LA_CHECK_ARG(P.Gy > 0 && P.Gx > 0 && P.ntaps >= 1 && P.ntaps <= LA_CONV_PHASE_TAPS, "conv: bad phase");
+            LA_CHECK_ARG((P.Gy - 1) * a.out_sy + P.out_oy < a.Hout && (P.Gx - 1) * a.out_sx + P.out_ox < a.Wout && P.out_oy >= 0 && P.out_ox >= 0,
+                         "conv: phase grid exceeds output tensor");
+            LA_CHECK_ARG((long)P.Gy * P.Gx > SPLITK_MAX_G, "conv: merged phases are for grids above the split-K sizes");
+            const int t = la_conv_tiles_per_sample(P.Gy, P.Gx);
+            if (t > tiles) tiles = t;
+        }
+    }
     int pslot = -1;
     if (g_prof.enabled) {
         if (g_prof.count < LA_PROF_MAX) {
             pslot = g_prof.count++;
             // algorithmic work of this launch: 2*MACs; bytes = input read once + output written once (+ weights once)
-            g_prof.flops += 2.0 * a.B * (double)a.Gy * a.Gx * a.M * (double)a.C * a.ntaps;
-            g_prof.bytes += 4.0 * ((double)a.B * a.C * a.Hin * a.Win * (a.in_bstride ? 1.0 : 1.0 / a.B) +
-                                   (double)a.B * a.M * a.Gy * a.Gx + (double)a.ntaps * a.C * a.M);
+            double gt = (double)a.Gy * a.Gx * a.ntaps, gout = (double)a.Gy * a.Gx, ntw = a.ntaps;
+            if (nphase > 0) {
+                gt = gout = ntw = 0.0;
+                for (int p = 0; p < nphase; ++p) { gt += (double)a.ph[p].Gy * a.ph[p].Gx * a.ph[p].ntaps; gout += (double)a.ph[p].Gy * a.ph[p].Gx; ntw += a.ph[p].ntaps; }
+            }
+            g_prof.flops += 2.0 * a.B * gt * a.M * (double)a.C;
+            g_prof.bytes += 4.0 * ((double)a.B * a.C * a.Hin * a.Win * (a.in_bstride ? 1.0 : 1.0 / a.B) + (double)a.B * a.M * gout + ntw * a.C * a.M);
             LA_HIP(hipEventRecord(g_prof.ev0[pslot], stream));
         } else {
             g_prof.overflow = 1;
@@ -281,7 +300,7 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
         as.splitk_ws = reinterpret_cast<float*>(as.ws);
         splitk_floats = (long)(as.ws_bytes / sizeof(float));
     }
-    if (as.splitk_ws && G <= SPLITK_MAX_G && nck >= 2) {
+    if (nphase == 0 && as.splitk_ws && G <= SPLITK_MAX_G && nck >= 2) {
         const int ntiles_flat = la_cdiv((long)a.B * G, NT);
         // K slices: the 16-bit kernels keep 2 workgroups per CU = 512 resident slots.  A launch costs
         // rounds(ks) * (1/ks + c) of one full K loop (c ~ prologue + epilogue + its share of the finish kernel), so pick the
@@ -314,7 +333,7 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
         }
     }
     if (as.ksplit == 1) {
-        dim3 grid(tiles, mtiles, a.B);
+        dim3 grid(tiles, mtiles, a.B * (nphase > 0 ? nphase : 1));
         if (bf) la_conv_bf16_dispatch(as, MTsel, grid, false, stream);
         else if (MTsel == 128) hipLaunchKernelGGL((la_conv_igemm_kernel<128, false>), grid, dim3(256), 0, stream, as);
         else hipLaunchKernelGGL((la_conv_igemm_kernel<64, false>), grid, dim3(256), 0, stream, as);

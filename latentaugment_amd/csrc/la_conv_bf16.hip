@@ -395,7 +395,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define BPITCH 64
 template <int MT, bool SPLIT, int FMT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void la_conv_bf16_kernel(LaConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void la_conv_bf16_kernel(LaConvArgs a_in) {
+    // merged output phases: blockIdx.z = phase * B + sample; the phase's grid, output offset and taps replace the launch-wide ones
+    LaConvArgs a = a_in;
+    int bz = blockIdx.z;
+    if (!SPLIT && a_in.nphase > 0) {
+        const int ph = bz / a_in.B;
+        bz -= ph * a_in.B;
+        a.Gy = a_in.ph[ph].Gy; a.Gx = a_in.ph[ph].Gx; a.out_oy = a_in.ph[ph].out_oy; a.out_ox = a_in.ph[ph].out_ox; a.ntaps = a_in.ph[ph].ntaps;
+#pragma unroll
+        for (int t = 0; t < LA_CONV_PHASE_TAPS; ++t) { a.tap_dy[t] = a_in.ph[ph].tap_dy[t]; a.tap_dx[t] = a_in.ph[ph].tap_dx[t]; a.tap_w[t] = a_in.ph[ph].tap_w[t]; }
+    }
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     constexpr bool F16 = FMT == FMT_F16X2;
     constexpr int WM_ = MT == 128 ? 4 : 2;         // wave grid WM_ x WN_ over the MT x 128 tile: every wave owns 32 rows
@@ -418,6 +428,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     const int m0 = blockIdx.y * MT;
     const int G = a.Gy * a.Gx;
     const int Ntot = SPLIT ? a.B * G : G;
+    if (!SPLIT && (long)ntile * NT >= G) return;          // merged phases: the launch is sized for the largest phase
     const int l31 = lane & 31, lh = lane >> 5;
 
     // ---- loader role: thread = (pixel n_l, 16-channel half khalf)
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     const int khalf = tid >> 7;
     const int nidx_l = ntile * NT + n_l;
     const bool nvalid = nidx_l < Ntot;
-    const int b_l = SPLIT ? (nvalid ? nidx_l / G : 0) : (int)blockIdx.z;
+    const int b_l = SPLIT ? (nvalid ? nidx_l / G : 0) : bz;
     const int g_l = SPLIT ? nidx_l - b_l * G : nidx_l;
     const int gy_l = nvalid ? g_l / a.Gx : 0;
     const int gx_l = nvalid ? g_l - gy_l * a.Gx : 0;
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     // pre-split layout: [b][chunk][pixel][32 channels] -> a gather thread reads 16 contiguous channels of its pixel
     const unsigned samp_bytes = (unsigned)nck * KCB * HWin * EB;
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(static_cast<const char*>(a.in_q)) + (SPLIT ? (size_t)0 : (size_t)blockIdx.z * samp_bytes), 0,
+        const_cast<char*>(static_cast<const char*>(a.in_q)) + (SPLIT ? (size_t)0 : (size_t)bz * samp_bytes), 0,
         (int)(SPLIT ? samp_bytes * (unsigned)a.B : samp_bytes), 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(static_cast<const char*>(a.wgt_bf16)) + (F16 ? pack_f16_offset(term_elems) : 0), 0, (int)(NTERM * term_elems * 2),
@@ -633,7 +644,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
         const float iw = 1.f / a.acc_scale_w[0];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            int bb = blockIdx.z;
+            int bb = bz;
             if (SPLIT) { const int nidx = ntile * NT + (wn * NJ + j) * 32 + l31; bb = nidx < Ntot ? nidx / G : 0; }
             const float inv = iw / a.acc_scale_x[bb];
 #pragma unroll
@@ -642,7 +653,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
         }
     }
-    la_conv_epilogue<MT, SPLIT, false, WM_>(a, acc, red, ntile, m0, G, Ntot);
+    la_conv_epilogue<MT, SPLIT, false, WM_>(a, acc, red, ntile, m0, G, Ntot, SPLIT ? -1 : bz);
     STAMP(45);
 }
 

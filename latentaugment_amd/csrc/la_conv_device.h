@@ -18,7 +18,7 @@ __device__ __forceinline__ float la_conv_epi_fwd(const LaConvArgs& a, float v, f
 // grid positions; wave N-subtile (wn, j) is then row wn*2 + j of the tile.
 template <int MT, bool SPLIT, bool TILE2D = false, int WM_ = 2>
 __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&acc)[MT / (32 * WM_)][WM_], float (*red)[MT],   // red: [4][MT] LDS floats
-                                                 int ntile, int m0, int G, int Ntot) {
+                                                 int ntile, int m0, int G, int Ntot, int b_sel = -1) {
     constexpr int TM = MT / (32 * WM_);       // 32-row MFMA tiles per wave
     constexpr int WN_ = 4 / WM_;              // waves along the pixels
     constexpr int NJ = WM_;                   // 32-pixel MFMA tiles per wave (128 / 32 / WN_)
@@ -45,7 +45,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
         return;
     }
 
-    const int b = blockIdx.z;
+    const int b = b_sel >= 0 ? b_sel : (int)blockIdx.z;      // (merged-phase launches pass the sample explicitly)
     // ---- fast path: the whole MT x 128 tile is inside the output (block-uniform).  Straight-line code: per-row parameters
     // come from LDS (staged with one coalesced load), every global load is unconditional and issued in one batch, so the
     // 64 stores of a lane are not serialised behind 32 dependent round trips to L2/HBM.

@@ -70,6 +70,9 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
         int rc = la_conv_prepare_input(a, stream);
         if (rc) return rc;
     }
+    // 16-bit kernels above the split-K sizes: the four phases in ONE launch (each phase launch would end in a nearly empty round)
+    const bool merged = precision != LA_PREC_F32 && (long)hin * hin > 1156;
+    int np = 0;
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             a.out_oy = py; a.out_ox = px;
@@ -80,9 +83,21 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
                     a.tap_dy[nt] = -(ky / 2); a.tap_dx[nt] = -(kx / 2); a.tap_w[nt] = ky * 3 + kx; ++nt;
                 }
             a.ntaps = nt;
+            if (merged) {
+                LaConvArgs::Phase& P = a.ph[np++];
+                P.Gy = a.Gy; P.Gx = a.Gx; P.out_oy = py; P.out_ox = px; P.ntaps = nt;
+                for (int t = 0; t < nt; ++t) { P.tap_dy[t] = a.tap_dy[t]; P.tap_dx[t] = a.tap_dx[t]; P.tap_w[t] = a.tap_w[t]; }
+                continue;
+            }
             int rc = la_conv_launch(a, stream);
             if (rc) return rc;
         }
+    if (merged) {
+        a.nphase = np;
+        a.out_oy = a.out_ox = 0; a.Gy = a.Gx = hin + 1; a.ntaps = 4;      // launch-wide fields = the largest phase (checks only)
+        int rc = la_conv_launch(a, stream);
+        if (rc) return rc;
+    }
     // FIR with pad (1,1,1,1) and gain up^2 = 4 (conv2d_resample.py:119-126), then the layer epilogue
     return la_upfirdn2d_modconv_epilogue(scratch, y, B, cout, res + 1, res + 1, fir_host, 4, 4, 1, 1, 1, 1, 4.f, d, d_stride,
                                          noise, noise_bstride, noise_strength, bias, act, alpha, gain, clamp, stream, y_pmax);
