@@ -6,8 +6,8 @@ int la_bank_dot(const float* Y, long m, long K, const float* X, int n, long ldx,
                 hipStream_t stream);
 int la_bank_colsum(const float* Y, long m, long K, float* colsum, hipStream_t stream);
 // scratch sizes of the bank kernels (floats): yx 5*m*n, yy 5*m, xx 33*n
-#define LA_YX_FLOATS(m, n) (5L * (m) * (n))
-#define LA_YY_FLOATS(m) (5L * (m))
+#define LA_YX_FLOATS(m, n) (17L * (m) * (n))      // result + up to 16 K-slice partials (la_criteria.hip KSPLIT)
+#define LA_YY_FLOATS(m) (17L * (m))
 #define LA_XX_FLOATS(n) (33L * (n))
 // out[0] (+)= scale * sum_{m,n} (|Y_m|^2 + |X_n|^2 - 2<Y_m,X_n>); workspaces: yx_ws LA_YX_FLOATS, yy_ws LA_YY_FLOATS, xx_ws LA_XX_FLOATS
 int la_l2_mean_from_bank(const float* Y, long m, long K, const float* X, int n, long ldx, long xmod, float* yx_ws,

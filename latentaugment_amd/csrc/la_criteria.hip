@@ -11,15 +11,14 @@
 // feeds RB FMAs), each thread keeps RB x NCH accumulators, K slices are summed by la_bank_dot_finish_kernel in a fixed
 // order (deterministic).  X element (n, k) = X[n*ldx + k % xmod].  VEC = 4 needs K % 4 == 0 and 16-byte aligned rows.
 #define RB 8
-#define KSPLIT 4
+#define KSPLIT 16     // workspace slices; a launch uses 4 (short rows) or all 16 (rows > 16384 elements, e.g. the pixel bank)
 template <int VEC>
 __global__ __launch_bounds__(256) void la_bank_dot_kernel(const float* __restrict__ Y, long m, long K, const float* __restrict__ X,
                                                          int n, int n0, long ldx, long xmod, float* __restrict__ part_yx,
-                                                         float* __restrict__ part_yy) {
-    __shared__ float red[4];
+                                                         float* __restrict__ part_yy, int ksplit) {
     const long r0 = (long)blockIdx.x * RB;
     const int ks = blockIdx.y;
-    const long kper = ((K + KSPLIT - 1) / KSPLIT + VEC * 256 - 1) / (VEC * 256) * (VEC * 256);
+    const long kper = ((K + ksplit - 1) / ksplit + VEC * 256 - 1) / (VEC * 256) * (VEC * 256);
     const long kbeg = ks * kper, kend = (kbeg + kper < K) ? kbeg + kper : K;
     float acc[RB][NCH], sq[RB];
 #pragma unroll
@@ -53,31 +52,48 @@ __global__ __launch_bounds__(256) void la_bank_dot_kernel(const float* __restric
             }
         }
     }
+    // block sums of the RB*NCH + RB accumulators: shuffle tree inside each wave, then one pass through LDS (fixed order)
+    __shared__ float wsum[4][RB * NCH + RB];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
     for (int r = 0; r < RB; ++r) {
-        if (r0 + r >= m) break;
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
-            const float t = la_block_sum_256(acc[r][q], red);
-            if (threadIdx.x == 0 && n0 + q < n) part_yx[((long)ks * m + r0 + r) * n + n0 + q] = t;
+            float v = acc[r][q];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) wsum[wv][r * NCH + q] = v;
         }
-        if (n0 == 0 && part_yy) {
-            const float t = la_block_sum_256(sq[r], red);
-            if (threadIdx.x == 0) part_yy[(long)ks * m + r0 + r] = t;
+        float v = sq[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) wsum[wv][RB * NCH + r] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < RB * NCH + RB) {
+        const int i = threadIdx.x;
+        const float t = (wsum[0][i] + wsum[1][i]) + (wsum[2][i] + wsum[3][i]);
+        if (i < RB * NCH) {
+            const int r = i / NCH, q = i - r * NCH;
+            if (r0 + r < m && n0 + q < n) part_yx[((long)ks * m + r0 + r) * n + n0 + q] = t;
+        } else {
+            const int r = i - RB * NCH;
+            if (r0 + r < m && n0 == 0 && part_yy) part_yy[(long)ks * m + r0 + r] = t;
         }
     }
 }
 
 __global__ void la_bank_dot_finish_kernel(const float* __restrict__ part_yx, const float* __restrict__ part_yy,
-                                          float* __restrict__ yx, float* __restrict__ yy, long m, int n) {
+                                          float* __restrict__ yx, float* __restrict__ yy, long m, int n, int ksplit) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m * n) {
         float v = 0.f;
-        for (int k = 0; k < KSPLIT; ++k) v += part_yx[(long)k * m * n + i];
+        for (int k = 0; k < ksplit; ++k) v += part_yx[(long)k * m * n + i];
         yx[i] = v;
     }
     if (yy && i < m) {
         float v = 0.f;
-        for (int k = 0; k < KSPLIT; ++k) v += part_yy[(long)k * m + i];
+        for (int k = 0; k < ksplit; ++k) v += part_yy[(long)k * m + i];
         yy[i] = v;
     }
 }
@@ -157,12 +173,14 @@ int la_bank_dot(const float* Y, long m, long K, const float* X, int n, long ldx,
     float* pyx = yx + m * n;
     float* pyy = yy ? yy + m : nullptr;
     const bool vec = (K % 4 == 0) && (ldx % 4 == 0) && (xmod % 4 == 0) && (((size_t)Y | (size_t)X) & 15) == 0;
-    dim3 grid(la_cdiv(m, RB), KSPLIT);
+    // long rows with few bank rows (pixel bank: 256 x 32761) need more K slices to cover the chip
+    const int ksplit = (K > 16384 && la_cdiv(m, RB) * 4 < 512) ? KSPLIT : 4;
+    dim3 grid(la_cdiv(m, RB), ksplit);
     for (int n0 = 0; n0 < n; n0 += NCH) {
-        if (vec) hipLaunchKernelGGL(la_bank_dot_kernel<4>, grid, dim3(256), 0, stream, Y, m, K, X, n, n0, ldx, xmod, pyx, pyy);
-        else hipLaunchKernelGGL(la_bank_dot_kernel<1>, grid, dim3(256), 0, stream, Y, m, K, X, n, n0, ldx, xmod, pyx, pyy);
+        if (vec) hipLaunchKernelGGL(la_bank_dot_kernel<4>, grid, dim3(256), 0, stream, Y, m, K, X, n, n0, ldx, xmod, pyx, pyy, ksplit);
+        else hipLaunchKernelGGL(la_bank_dot_kernel<1>, grid, dim3(256), 0, stream, Y, m, K, X, n, n0, ldx, xmod, pyx, pyy, ksplit);
     }
-    hipLaunchKernelGGL(la_bank_dot_finish_kernel, dim3(la_cdiv(m * n > m ? m * n : m, 256)), dim3(256), 0, stream, pyx, pyy, yx, yy, m, n);
+    hipLaunchKernelGGL(la_bank_dot_finish_kernel, dim3(la_cdiv(m * n > m ? m * n : m, 256)), dim3(256), 0, stream, pyx, pyy, yx, yy, m, n, ksplit);
     LA_CHECK_LAUNCH();
     return LA_OK;
 }
