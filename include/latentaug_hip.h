@@ -303,6 +303,10 @@ int la_pr_member_f16(const void* rows, long nr, const void* cols, long nc, int D
  * ------------------------------------------------------------------------------------------------------------- */
 int la_prof_begin(void);
 int la_prof_end(double* total_ms, long* launches, double* flops, double* bytes);
+/* la_prof_set_stride(k): bracket a hashed 1-in-k sample of the launches instead of all of them (an event pair costs ~3 us on
+ * the stream); la_prof_end then reports the sampled launches' ms / count / FLOPs / bytes, la_prof_total_launches() all of them. */
+int la_prof_set_stride(int stride);
+long la_prof_total_launches(void);
 
 #ifdef __cplusplus
 }

@@ -204,7 +204,16 @@ static struct {
     hipEvent_t ev0[LA_PROF_MAX], ev1[LA_PROF_MAX];
     int created;
     double flops, bytes;
+    int stride;              // 1 = bracket every launch; k > 1 = a hashed 1-in-k sample (the event pairs themselves cost ~3 us each)
+    unsigned seq;            // all contraction launches seen since la_prof_begin
 } g_prof;
+
+extern "C" int la_prof_set_stride(int stride) {
+    LA_CHECK_ARG(stride >= 1 && stride <= 64, "prof: stride must be 1..64");
+    g_prof.stride = stride;
+    return LA_OK;
+}
+extern "C" long la_prof_total_launches(void) { return (long)g_prof.seq; }
 
 extern "C" int la_prof_begin(void) {
     if (g_prof.created < LA_PROF_MAX) {
@@ -214,7 +223,8 @@ extern "C" int la_prof_begin(void) {
             g_prof.created = i + 1;
         }
     }
-    g_prof.count = 0; g_prof.overflow = 0; g_prof.flops = 0; g_prof.bytes = 0; g_prof.enabled = 1;
+    g_prof.count = 0; g_prof.overflow = 0; g_prof.flops = 0; g_prof.bytes = 0; g_prof.seq = 0; g_prof.enabled = 1;
+    if (g_prof.stride < 1) g_prof.stride = 1;
     return LA_OK;
 }
 
@@ -267,7 +277,9 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
         }
     }
     int pslot = -1;
-    if (g_prof.enabled) {
+    // (sampling is by a hash of the launch sequence number, so that no periodic launch pattern can alias with it)
+    if (g_prof.enabled && (g_prof.stride <= 1 || ((g_prof.seq++ * 2654435761u) >> 13) % (unsigned)g_prof.stride == 0)) {
+        if (g_prof.stride <= 1) ++g_prof.seq;
         if (g_prof.count < LA_PROF_MAX) {
             pslot = g_prof.count++;
             // algorithmic work of this launch: 2*MACs; bytes = input read once + output written once (+ weights once)
