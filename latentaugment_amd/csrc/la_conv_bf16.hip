@@ -26,7 +26,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // FMT template parameter of the kernels below
 #ifndef LA_ABLATE
-#define LA_ABLATE 0      // dev builds only: knock out one pipeline stage of the halo kernel to time the rest
+#define LA_ABLATE 0      // dev builds only (11..15): knock out one stage of the flat kernel step loop to time the rest
 #endif
 #ifndef LA_STAMP
 #define LA_STAMP 0
