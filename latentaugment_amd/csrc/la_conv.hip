@@ -154,13 +154,19 @@ __global__ __launch_bounds__(256) void la_conv_igemm_kernel(LaConvArgs a) {
     la_conv_epilogue<MT, SPLIT>(a, acc, red, ntile, m0, G, Ntot);
 }
 
-// Split-K finisher: one wave per (b, m) plane of the output grid; sums the K slices in a fixed order and applies the
-// same epilogue as the direct kernel (deterministic).
+// Split-K finisher: sums the K slices in a fixed order and applies the same epilogue as the direct kernel (deterministic).
+// One wave per (b, m) plane for grids below 256 positions, a whole workgroup per plane above (the kernel is pure latency:
+// a wave walking a 32x32 plane makes 16 dependent round trips).
+template <int PPB>      // planes per workgroup: 4 (one wave each) or 1
 __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a) {
+    __shared__ float wpart[4];
+    constexpr int T = 256 / PPB;                    // threads per plane
     const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tp = threadIdx.x % T;
+    const int m = blockIdx.x * PPB + threadIdx.x / T;
     const int b = blockIdx.y;
-    if (m >= a.M) return;
+    const bool live = m < a.M;
+    if (!live && PPB > 1) return;
     const int G = a.Gy * a.Gx;
     const long HWout = (long)a.Hout * a.Wout;
     const long slice = (long)a.B * a.M * G;
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
     const float sc = (a.epi == LA_EPI_BWD && a.out_scale) ? a.out_scale[(long)b * a.oscale_stride + m] : 1.f;
     const float* xin_p = (a.epi == LA_EPI_BWD && a.xin) ? a.xin + (long)b * a.xin_bstride + (long)m * HWout : nullptr;
     float part = 0.f;
-    for (int g = lane; g < G; g += 64) {
+    for (int g = tp; g < G; g += T) {
         float v = 0.f;
         for (int k = 0; k < a.ksplit; ++k) v += wsp[(long)k * slice + g];
         const int gy = g / a.Gx, gx = g - gy * a.Gx;
@@ -191,7 +197,12 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
     }
     if (a.epi == LA_EPI_BWD && a.ds_part) {
         part = la_wave_sum(part);
-        if (lane < a.tiles_per_sample) a.ds_part[((long)b * a.M + m) * a.tiles_per_sample + lane] = lane == 0 ? part : 0.f;
+        if (PPB == 1) {
+            if (lane == 0) wpart[threadIdx.x >> 6] = part;
+            __syncthreads();
+            part = (wpart[0] + wpart[1]) + (wpart[2] + wpart[3]);
+        }
+        if (tp < a.tiles_per_sample) a.ds_part[((long)b * a.M + m) * a.tiles_per_sample + tp] = tp == 0 ? part : 0.f;
     }
 }
 
@@ -340,7 +351,8 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
                 if (bf) la_conv_bf16_dispatch(as, MTsel, grid, true, stream);
                 else if (MTsel == 128) hipLaunchKernelGGL((la_conv_igemm_kernel<128, true>), grid, dim3(256), 0, stream, as);
                 else hipLaunchKernelGGL((la_conv_igemm_kernel<64, true>), grid, dim3(256), 0, stream, as);
-                hipLaunchKernelGGL(la_conv_splitk_finish_kernel, dim3(la_cdiv(a.M, 4), a.B), dim3(256), 0, stream, as);
+                if (G >= 256) hipLaunchKernelGGL(la_conv_splitk_finish_kernel<1>, dim3(a.M, a.B), dim3(256), 0, stream, as);
+                else hipLaunchKernelGGL(la_conv_splitk_finish_kernel<4>, dim3(la_cdiv(a.M, 4), a.B), dim3(256), 0, stream, as);
             }
         }
     }
