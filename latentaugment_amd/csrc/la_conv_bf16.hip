@@ -723,11 +723,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
         shpack |= (unsigned long long)((1 + a.tap_dy[t]) * HALO_W + (1 + a.tap_dx[t])) << (7 * t);
         wpack |= (unsigned long long)a.tap_w[t] << (4 * t);
     }
-    {
-        const float xs = F16 ? a.acc_scale_x[b] : 1.f;
-        for (int k = tid; k < nck * KCB; k += 256)
-            scl[k] = k < a.C ? (a.in_scale ? a.in_scale[(long)b * a.scale_stride + k] : 1.f) * xs : 0.f;
-    }
 
     // ---- halo slices.  Every load is unconditional (clamped address; out-of-image pixels are zeroed on the way to LDS,
     // channels past C meet zero weights), so the compiler can count them: no wait in the tap loop is a vmcnt(0).
@@ -847,8 +842,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
         for (int t = 0; t < 9; ++t) slice_load(0, t, pre[t]);
         load_a(0, 0, 0, acur[0]);
         load_a(0, 0, 1, acur[1]);
-#pragma unroll
+        {      // per-channel factors: filled after the halo / weight loads were issued, so that the latencies overlap
+            const float xs = F16 ? a.acc_scale_x[b] : 1.f;
+            for (int k = tid; k < nck * KCB; k += 256)
+                scl[k] = k < a.C ? (a.in_scale ? a.in_scale[(long)b * a.scale_stride + k] : 1.f) * xs : 0.f;
+        }
         STAMP(1);
+        __syncthreads();                           // scl is complete before any slice is scaled with it
 #pragma unroll
         for (int t = 0; t < 9; ++t) slice_write(smem, pre[t]);
     }
