@@ -210,6 +210,7 @@ def test_modconv_vs_oracle(dev, case):
     dict(B=2, cin=40, cout=200, res=64, up=False, noise_strength=0.1),     # halo kernel with a ragged channel chunk and M tile
     dict(B=2, cin=64, cout=32, res=32, up=True, noise_strength=0.0),
     dict(B=1, cin=128, cout=64, res=64, up=True, noise_strength=0.1),
+    dict(B=2, cin=48, cout=32, res=128, up=True, noise_strength=0.1),      # 64x64 input: the four phases run as ONE merged launch
     dict(B=2, cin=512, cout=512, res=4, up=False, noise_strength=0.0),
 ])
 def test_modconv_split_bf16_vs_oracle(dev, case):
