@@ -211,6 +211,7 @@ def test_modconv_vs_oracle(dev, case):
     dict(B=2, cin=64, cout=32, res=32, up=True, noise_strength=0.0),
     dict(B=1, cin=128, cout=64, res=64, up=True, noise_strength=0.1),
     dict(B=2, cin=48, cout=32, res=128, up=True, noise_strength=0.1),      # 64x64 input: the four phases run as ONE merged launch
+    dict(B=1, cin=128, cout=40, res=128, up=True, noise_strength=0.0),     # 128-row backward tile over a 129^2 gradient scratch, ragged channel chunk
     dict(B=2, cin=512, cout=512, res=4, up=False, noise_strength=0.0),
 ])
 def test_modconv_split_bf16_vs_oracle(dev, case):
