@@ -313,7 +313,8 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
     const bool bf = a.precision != LA_PREC_F32;
     LA_CHECK_ARG(!bf || (a.wgt_bf16 && a.wgt_bf16_term_elems > 0), "conv: split-bf16 precision needs packed bf16 weights");
     const int nck = la_cdiv(a.C, bf ? 32 : KC);
-    const int MTsel = a.M >= 128 ? 128 : 64;
+    // 32-row tiles only exist for the halo kernel (the 32-channel layers of the 1024^2 generators)
+    const int MTsel = a.M >= 128 ? 128 : ((a.M <= 32 && bf && !a.in_q && la_conv_bf16_uses_halo(a)) ? 32 : 64);
     const int mtiles = la_cdiv(a.M, MTsel);
     // scratch: pre-split input first (split precisions only), split-K partials after it
     if (bf) { int rc = la_conv_prepare_input(as, stream); if (rc) return rc; }

@@ -679,8 +679,9 @@ template <int MT, int FMT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void la_conv_bf16_halo_kernel(LaConvArgs a) {
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     constexpr bool F16 = FMT == FMT_F16X2;
-    constexpr int WM_ = MT == 128 ? 4 : 2;         // wave grid WM_ x WN_ over the MT x 128 tile: every wave owns 32 rows
-    constexpr int WN_ = 4 / WM_;                   // (128-row tiles: 4 x 1, no weight fragment is loaded by two waves)
+    constexpr int WM_ = MT / 32;                   // wave grid WM_ x WN_ over the MT x 128 tile: every wave owns 32 rows
+    constexpr int WN_ = 4 / WM_;                   // (128-row tiles: 4 x 1, no weight fragment is loaded by two waves; 32-row tiles
+                                                   //  for the 32-channel layers of the 1024^2 generators: 1 x 4)
     constexpr int TM = 1;
     constexpr int NJ = 4 / WN_;                    // 32-pixel MFMA tiles (= tile rows) per wave
     constexpr int EB = 4;                          // the halo kernel reads the fp32 input itself
@@ -927,10 +928,12 @@ static void launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, 
             const int cap = 2 * 3 * HALO_PX * HPITCH + 4096 * (int)sizeof(float);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<64, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<32, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
             attr_done = true;
         }
         if (MTsel == 128) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, FMT>), grid, dim3(256), h128, stream, as);
-        else hipLaunchKernelGGL((la_conv_bf16_halo_kernel<64, FMT>), grid, dim3(256), h64, stream, as);
+        else if (MTsel == 64) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<64, FMT>), grid, dim3(256), h64, stream, as);
+        else hipLaunchKernelGGL((la_conv_bf16_halo_kernel<32, FMT>), grid, dim3(256), h64, stream, as);
         return;
     }
     if (MTsel == 128) {

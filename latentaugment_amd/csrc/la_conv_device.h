@@ -17,7 +17,7 @@ __device__ __forceinline__ float la_conv_epi_fwd(const LaConvArgs& a, float v, f
 // TILE2D: the 128 pixels of a tile are 4 rows x 32 columns of the output grid (halo kernel) instead of 128 consecutive
 // grid positions; wave N-subtile (wn, j) is then row wn*2 + j of the tile.
 template <int MT, bool SPLIT, bool TILE2D = false, int WM_ = 2>
-__device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&acc)[MT / (32 * WM_)][WM_], float (*red)[MT],   // red: [4][MT] LDS floats
+__device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&acc)[MT / (32 * WM_)][WM_], float (*red)[MT],   // red: [WN_ > 2 ? 6 : 4][MT] LDS floats
                                                  int ntile, int m0, int G, int Ntot, int b_sel = -1) {
     constexpr int TM = MT / (32 * WM_);       // 32-row MFMA tiles per wave
     constexpr int WN_ = 4 / WM_;              // waves along the pixels
@@ -50,7 +50,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
     // come from LDS (staged with one coalesced load), every global load is unconditional and issued in one batch, so the
     // 64 stores of a lane are not serialised behind 32 dependent round trips to L2/HBM.
     if (m0 + MT <= a.M && (TILE2D || (ntile + 1) * NT <= G)) {
-        float* prm = &red[2][0];                         // [2][MT] row parameters (red[0..1] stay the ds_part scratch)
+        float* prm = &red[WN_ > 2 ? 4 : 2][0];           // [2][MT] row parameters (red[0 .. WN_) stay the ds_part scratch)
         long np[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -102,7 +102,12 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
             }
             if (a.ds_part) {
                 __syncthreads();
-                if (tid < MT) a.ds_part[((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile] = red[0][tid] + (WN_ > 1 ? red[1][tid] : 0.f);
+                if (tid < MT) {
+                    float t = red[0][tid];
+#pragma unroll
+                    for (int w = 1; w < WN_; ++w) t += red[w][tid];
+                    a.ds_part[((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile] = t;
+                }
             }
             return;
         }
@@ -211,7 +216,12 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
         if (a.ds_part) {
             __syncthreads();
             if (tid < MT && m0 + tid < a.M)
-                a.ds_part[((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile] = red[0][tid] + (WN_ > 1 ? red[1][tid] : 0.f);
+                {
+                    float t = red[0][tid];
+#pragma unroll
+                    for (int w = 1; w < WN_; ++w) t += red[w][tid];
+                    a.ds_part[((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile] = t;
+                }
         }
         return;
     }

@@ -208,6 +208,8 @@ def test_modconv_vs_oracle(dev, case):
     dict(B=2, cin=24, cout=132, res=32, up=False, noise_strength=0.1),     # ragged channels
     dict(B=1, cin=64, cout=128, res=64, up=False, noise_strength=0.0),
     dict(B=2, cin=40, cout=200, res=64, up=False, noise_strength=0.1),     # halo kernel with a ragged channel chunk and M tile
+    dict(B=2, cin=32, cout=32, res=64, up=False, noise_strength=0.1),      # 32-row halo tiles (1 x 4 wave grid)
+    dict(B=1, cin=24, cout=20, res=64, up=False, noise_strength=0.0),      # ... ragged in both M and C
     dict(B=2, cin=64, cout=32, res=32, up=True, noise_strength=0.0),
     dict(B=1, cin=128, cout=64, res=64, up=True, noise_strength=0.1),
     dict(B=2, cin=48, cout=32, res=128, up=True, noise_strength=0.1),      # 64x64 input: the four phases run as ONE merged launch
