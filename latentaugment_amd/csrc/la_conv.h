@@ -80,7 +80,7 @@ struct LaConvArgs {
 long la_conv_bf16_pack_elems(int M, int C, int ktaps);   // elements per term
 int la_pack_conv_weights_bf16(const float* w, void* out, int cout, int cin, int ktaps, int transpose, int nterm,
                               hipStream_t stream, float scale = 1.f, int m_pad = 0);
-void la_conv_bf16_dispatch(const LaConvArgs& as, int MTsel, dim3 grid, bool split, hipStream_t stream);
+int la_conv_bf16_dispatch(const LaConvArgs& as, int MTsel, dim3 grid, bool split, hipStream_t stream);
 
 // scratch floats that let every <= 32x32 launch of a (B, M) problem use split-K: slices * B * M * G, G <= 1024
 long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx, int precision);

@@ -349,7 +349,7 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
             if ((long)ks * a.B * a.M * G <= splitk_floats && ks >= 2) {
                 as.ksplit = ks;
                 dim3 grid(ntiles_flat, mtiles, ks);
-                if (bf) la_conv_bf16_dispatch(as, MTsel, grid, true, stream);
+                if (bf) { int rc = la_conv_bf16_dispatch(as, MTsel, grid, true, stream); if (rc) return rc; }
                 else if (MTsel == 128) hipLaunchKernelGGL((la_conv_igemm_kernel<128, true>), grid, dim3(256), 0, stream, as);
                 else hipLaunchKernelGGL((la_conv_igemm_kernel<64, true>), grid, dim3(256), 0, stream, as);
                 if (G >= 256) hipLaunchKernelGGL(la_conv_splitk_finish_kernel<1>, dim3(a.M, a.B), dim3(256), 0, stream, as);
@@ -359,7 +359,7 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
     }
     if (as.ksplit == 1) {
         dim3 grid(tiles, mtiles, a.B * (nphase > 0 ? nphase : 1));
-        if (bf) la_conv_bf16_dispatch(as, MTsel, grid, false, stream);
+        if (bf) { int rc = la_conv_bf16_dispatch(as, MTsel, grid, false, stream); if (rc) return rc; }
         else if (MTsel == 128) hipLaunchKernelGGL((la_conv_igemm_kernel<128, false>), grid, dim3(256), 0, stream, as);
         else hipLaunchKernelGGL((la_conv_igemm_kernel<64, false>), grid, dim3(256), 0, stream, as);
     }

@@ -19,6 +19,7 @@
 // splits on the way into LDS; the flat kernel (whose gather re-reads every element once per tap) reads a pre-split copy
 // made once per launch input (la_presplit_*: 8 bytes per element {h | m<<16, l} bf16, 4 bytes {h | l<<16} fp16).
 #include "la_conv_device.h"
+#include <atomic>
 #include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -917,24 +918,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
 }
 
 template <int FMT>
-static void launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, hipStream_t stream) {
+static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, hipStream_t stream) {
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     const size_t lds128 = (size_t)2 * NTERM * NT * BPITCH, lds64 = lds128;     // two pixel buffers (>= the epilogue's 4 * MT floats)
     if (!split && la_conv_bf16_uses_halo(as)) {
         // two halo buffers (>= the epilogue's 4 * MT floats) + the per-channel factor table
         const size_t h128 = (size_t)2 * NTERM * HALO_PX * HPITCH + (size_t)la_cdiv(as.C, KCB) * KCB * sizeof(float), h64 = h128;
-        static bool attr_done = false;
-        if (!attr_done) {      // > 64 KB of dynamic LDS needs the opt-in (idempotent)
+        // > 64 KB of dynamic LDS needs the opt-in, and the attribute is per DEVICE: track it per device (atomic flags: the
+        // entry points may be entered from several host threads, one per device)
+        static std::atomic<bool> attr_done[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!attr_done[dev].load(std::memory_order_acquire)) {
             const int cap = 2 * 3 * HALO_PX * HPITCH + 4096 * (int)sizeof(float);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<64, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<32, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-            attr_done = true;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<64, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<32, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            if (e != hipSuccess) { la_set_error(hipGetErrorString(e)); return LA_ERR_HIP; }
+            attr_done[dev].store(true, std::memory_order_release);
         }
         if (MTsel == 128) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, FMT>), grid, dim3(256), h128, stream, as);
         else if (MTsel == 64) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<64, FMT>), grid, dim3(256), h64, stream, as);
         else hipLaunchKernelGGL((la_conv_bf16_halo_kernel<32, FMT>), grid, dim3(256), h64, stream, as);
-        return;
+        return LA_OK;
     }
     if (MTsel == 128) {
         if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT>), grid, dim3(256), lds128, stream, as);
@@ -943,13 +949,14 @@ static void launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, 
         if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<64, true, FMT>), grid, dim3(256), lds64, stream, as);
         else hipLaunchKernelGGL((la_conv_bf16_kernel<64, false, FMT>), grid, dim3(256), lds64, stream, as);
     }
+    return LA_OK;
 }
 
-void la_conv_bf16_dispatch(const LaConvArgs& args, int MTsel, dim3 grid, bool split, hipStream_t stream) {
+int la_conv_bf16_dispatch(const LaConvArgs& args, int MTsel, dim3 grid, bool split, hipStream_t stream) {
     LaConvArgs as = args;
     if (as.precision == LA_PREC_F16X2)      // the fp16 weight scale lives behind the terms of the pack
         as.acc_scale_w = reinterpret_cast<const float*>(static_cast<const char*>(as.wgt_bf16) + pack_wscale_offset(as.wgt_bf16_term_elems));
-    if (as.precision == LA_PREC_BF16X3) launch_bf16<FMT_BF16X3>(as, MTsel, grid, split, stream);
-    else if (as.precision == LA_PREC_F16X2) launch_bf16<FMT_F16X2>(as, MTsel, grid, split, stream);
-    else launch_bf16<FMT_BF16X2>(as, MTsel, grid, split, stream);
+    if (as.precision == LA_PREC_BF16X3) return launch_bf16<FMT_BF16X3>(as, MTsel, grid, split, stream);
+    if (as.precision == LA_PREC_F16X2) return launch_bf16<FMT_F16X2>(as, MTsel, grid, split, stream);
+    return launch_bf16<FMT_BF16X2>(as, MTsel, grid, split, stream);
 }

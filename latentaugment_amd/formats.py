@@ -67,7 +67,7 @@ class LatentCodeDataset(_ZipPickles):
     def _load_w(self, idx):
         fname = self._fnames[idx]
         with self.open_file(fname) as f:
-            w = pickle.load(f)                     # plain ndarray pickles written by the inversion step
+            w = _restricted_load(f)                # plain ndarray pickles written by the inversion step
         return np.asarray(w).astype('float32'), fname
 
     def __getitem__(self, idx):
@@ -76,7 +76,7 @@ class LatentCodeDataset(_ZipPickles):
     def lookup(self, fname):
         """Latent of one file name, as LatentAugment.sample_from_inversion reads it (latent_aug.py:314-318)."""
         with self.open_file(fname) as f:
-            return np.asarray(pickle.load(f)).astype('float32')
+            return np.asarray(_restricted_load(f)).astype('float32')
 
 
 class ImgDataset(_ZipPickles):
@@ -93,7 +93,7 @@ class ImgDataset(_ZipPickles):
     def _load_raw_image(self, idx):
         fname = self._fnames[idx]
         with self.open_file(fname) as f:
-            p = pickle.load(f)
+            p = _restricted_load(f)
         s = p[self._modalities[0]]
         out = np.zeros((len(self._modalities), s.shape[0], s.shape[1]), dtype='float32')
         for i, m in enumerate(self._modalities):
@@ -223,24 +223,34 @@ _SAFE_GLOBALS = {
     ('dnnlib.util', 'EasyDict'): _EasyDictStub, ('dnnlib', 'EasyDict'): _EasyDictStub,
     ('torch_utils.persistence', '_reconstruct_persistent_obj'): _reconstruct_persistent_obj,
 }
-_SAFE_MODULE_PREFIXES = ('numpy', 'torch._utils', 'torch.storage', 'torch.nn.parameter', 'torch.serialization',
-                         'torch._tensor', 'torch')
 _SAFE_TORCH_NAMES = {'_rebuild_tensor_v2', '_rebuild_tensor', '_rebuild_parameter', '_rebuild_parameter_with_state',
-                     '_load_from_bytes', 'FloatStorage', 'HalfStorage', 'DoubleStorage', 'LongStorage', 'IntStorage',
+                     'FloatStorage', 'HalfStorage', 'DoubleStorage', 'LongStorage', 'IntStorage',
                      'BoolStorage', 'ByteStorage', 'UntypedStorage', 'Size', 'device', 'dtype', 'float32', 'float16',
                      'float64', 'int64', 'int32', 'uint8', 'bool', 'Tensor', 'Parameter', '_rebuild_from_type_v2',
                      'StorageType', 'TypedStorage'}
+# numpy reconstruction helpers, by exact (module suffix, name): nothing else of numpy is reachable from a pickle
+_SAFE_NUMPY = {('numpy', 'ndarray'), ('numpy', 'dtype'),
+               ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+               ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'),
+               ('numpy.core.numeric', '_frombuffer'), ('numpy._core.numeric', '_frombuffer')}
+
+
+def _load_tensor_from_bytes(b):
+    """Stand-in for torch.storage._load_from_bytes (which is a full `torch.load(..., weights_only=False)`, i.e. an
+    unrestricted unpickle of attacker-controlled bytes): persistence pickles carry their tensors through it, so the entry
+    must exist -- but only tensors may come out of it."""
+    return torch.load(io.BytesIO(b), weights_only=True, map_location='cpu')
 
 
 class _RestrictedUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if (module, name) in _SAFE_GLOBALS:
             return _SAFE_GLOBALS[(module, name)]
-        if module.startswith('numpy'):
+        if (module, name) == ('torch.storage', '_load_from_bytes'):
+            return _load_tensor_from_bytes
+        if (module, name) in _SAFE_NUMPY:
             import importlib
-            if name in ('ndarray', 'dtype', '_reconstruct', 'scalar', '_frombuffer') or module.endswith('multiarray') or \
-                    module.endswith('numeric') or module.endswith('_multiarray_umath'):
-                return getattr(importlib.import_module(module), name)
+            return getattr(importlib.import_module(module), name)
         if module.startswith('torch') and name in _SAFE_TORCH_NAMES:
             import importlib
             return getattr(importlib.import_module(module), name)

@@ -62,6 +62,19 @@ def gather_shards(local, per, batch, group=None):
     return out[:batch].to(dev)
 
 
+def broadcast_controls(crop_pos, group=None, device=None):
+    """Rank 0's per-forward host draws -- (crop x, crop y, 48-bit seed of the final-synthesis noise) -- to every rank of the
+    group.  Control plane only (three integers through the host); the data path keeps its single all_gather."""
+    import torch.distributed as dist
+    ctl = [None]
+    if dist.get_rank(group) == 0:
+        ctl[0] = (int(crop_pos[0]), int(crop_pos[1]), random.getrandbits(48))
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    on_host = dist.get_backend(group) == 'gloo' or device is None
+    dist.broadcast_object_list(ctl, src=src, group=group, device=torch.device('cpu') if on_host else device)
+    return ctl[0]
+
+
 class InMemoryLatentCodes:
     """Minimal stand-in for util_dataset.LatentCodeDataset: fname -> inverted latent [num_ws, w_dim] (or [w_dim])."""
 
@@ -234,7 +247,13 @@ class LatentAug:
                 ax, ay = self.crop_window(get_params(self.res, self.crop_size, self.preprocess)['crop_pos'])
                 t = t[:, :, ay:ay + self.crop_size, ax:ax + self.crop_size].repeat(1, 3, 1, 1) * scale + shift   # plumbing
                 return self.feat.forward(t.contiguous()).cpu().numpy()
-            st = formats.compute_stats(ds, 'features_jit', os.path.join(root, 'cache_dir'), cache_tag=f'{mode}-{self.crop_size}',
+            # The reference names the cache '<mode>-<crop>-features_jit-...': its contents also depend on the input range, the
+            # preprocess and the feature-net weights, so those are folded into the tag -- a cache written by the reference (raw
+            # 0..255 inputs, NVIDIA's weights) or under other settings is never picked up silently.
+            tag = f'{mode}-{self.crop_size}'
+            if not (raw and (scale, shift) == (1.0, 0.0) and getattr(opt, 'lpips_cache_compat', False)):
+                tag += f"-{'raw' if raw else 'unit'}-s{scale:g}-b{shift:g}-w{self.feat.weights_digest}"
+            st = formats.compute_stats(ds, 'features_jit', os.path.join(root, 'cache_dir'), cache_tag=tag,
                                        step=opt.step_img, feature_fn=feature_fn)
             out.append(st.get_all_torch())
         return out
@@ -299,9 +318,22 @@ class LatentAug:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             B = w.shape[0]
-            lo, hi, per = shard_bounds(B, dist.get_world_size(self.group), dist.get_rank(self.group))
+            rank = dist.get_rank(self.group)
+            lo, hi, per = shard_bounds(B, dist.get_world_size(self.group), rank)
+            # The reference draws ONE crop position per forward for the whole batch (:216) and one noise stream for the final
+            # synthesis: rank 0's draws are the batch's (control plane: one tiny host-side broadcast of 3 integers; the data
+            # path still has exactly one collective).  Sample i's final noise is a function of (seed, i) only, so the gathered
+            # batch does not depend on how it was sharded.
+            cx, cy, noise_seed = broadcast_controls(self.crop_params['crop_pos'], self.group, self.device)
+            self._last_controls = (cx, cy, noise_seed)
+            self.crop_params = {'crop_pos': (cx, cy)}
             if hi > lo:
-                fn = [t[lo:hi].contiguous() for t in final_noises] if final_noises is not None else None
+                if final_noises is not None:
+                    fn = [t[lo:hi].contiguous() if t is not None else None for t in final_noises]
+                elif self._cfg.final_noise_mode == 2:
+                    fn = self.engine.make_noises(hi - lo, sample_seeds=[noise_seed + i for i in range(lo, hi)])
+                else:
+                    fn = None
                 img, w_aug, _ = self.run_local(w[lo:hi], fn)
             else:
                 img = torch.empty([0, self.engine.img_channels, self.res, self.res], device=self.device)

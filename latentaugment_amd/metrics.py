@@ -67,8 +67,9 @@ class FeatureStats:
             self.all_features.append(x.cpu().numpy())
         if self.capture_mean_cov:
             lib = _lib.load()
-            _lib.check(lib.la_feature_moments_f64(_lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(self._mean), _lib.ptr(self._cov),
-                                                  _lib.stream_ptr()), 'feature_moments')
+            with torch.cuda.device(x.device):
+                _lib.check(lib.la_feature_moments_f64(_lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(self._mean), _lib.ptr(self._cov),
+                                                      _lib.stream_ptr()), 'feature_moments')
 
     def append(self, x):
         x = np.asarray(x, dtype=np.float32)
@@ -107,8 +108,9 @@ class FeatureStats:
 
     @staticmethod
     def load(pkl_file, device='cuda:0'):
+        from .formats import _restricted_load          # cache files are data (dict of numpy / python values): never a full unpickle
         with open(pkl_file, 'rb') as f:
-            s = pickle.load(f)
+            s = _restricted_load(f)
         obj = FeatureStats(capture_all=s['capture_all'], capture_mean_cov=s.get('capture_mean_cov', False),
                            max_items=s['max_items'], device=device)
         obj.num_items, obj.num_features, obj.all_features = s['num_items'], s['num_features'], s['all_features']
@@ -143,8 +145,9 @@ def compute_distances(row_features, col_features, num_gpus=1, rank=0, col_batch_
     r, c = _f16_padded(row_features, dev), _f16_padded(col_features, dev)
     dist = torch.empty([r.shape[0], c.shape[0]], dtype=torch.float32, device=dev)
     ws = torch.empty([lib.la_pr_workspace_floats(r.shape[0], c.shape[0])], dtype=torch.float32, device=dev)
-    _lib.check(lib.la_cdist_f16(_lib.ptr(r), r.shape[0], _lib.ptr(c), c.shape[0], r.shape[1], _lib.ptr(dist), _lib.ptr(ws),
-                                _lib.stream_ptr()), 'cdist')
+    with torch.cuda.device(dev):          # the stream must be `dev`'s, not the current device's
+        _lib.check(lib.la_cdist_f16(_lib.ptr(r), r.shape[0], _lib.ptr(c), c.shape[0], r.shape[1], _lib.ptr(dist), _lib.ptr(ws),
+                                    _lib.stream_ptr()), 'cdist')
     return dist.cpu()
 
 
@@ -161,12 +164,14 @@ def compute_pr_from_features(real_features, gen_features, nhood_size=3, row_batc
         nm, npb, D = manifold.shape[0], probes.shape[0], manifold.shape[1]
         ws = torch.empty([lib.la_pr_workspace_floats(max(nm, npb), nm)], dtype=torch.float32, device=dev)
         kth = torch.empty([nm], dtype=torch.float32, device=dev)
-        _lib.check(lib.la_pr_kth_f16(_lib.ptr(manifold), nm, _lib.ptr(manifold), nm, D, nhood_size, _lib.ptr(kth), _lib.ptr(ws),
-                                     _lib.stream_ptr()), 'pr_kth')
+        with torch.cuda.device(dev):
+            _lib.check(lib.la_pr_kth_f16(_lib.ptr(manifold), nm, _lib.ptr(manifold), nm, D, nhood_size, _lib.ptr(kth), _lib.ptr(ws),
+                                         _lib.stream_ptr()), 'pr_kth')
         kth = kth.to(torch.float16).to(torch.float32)          # the reference keeps the radii in float16 (precision_recall.py:78)
         member = torch.empty([npb], dtype=torch.uint8, device=dev)
-        _lib.check(lib.la_pr_member_f16(_lib.ptr(probes), npb, _lib.ptr(manifold), nm, D, _lib.ptr(kth), _lib.ptr(member),
-                                        _lib.ptr(ws), _lib.stream_ptr()), 'pr_member')
+        with torch.cuda.device(dev):
+            _lib.check(lib.la_pr_member_f16(_lib.ptr(probes), npb, _lib.ptr(manifold), nm, D, _lib.ptr(kth), _lib.ptr(member),
+                                            _lib.ptr(ws), _lib.stream_ptr()), 'pr_member')
         results[name] = float(member.to(torch.float32).mean())
         details[name + '_kth'] = kth.cpu().numpy()
         details[name + '_pred'] = member.cpu().numpy().astype(bool)

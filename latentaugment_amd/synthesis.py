@@ -121,17 +121,35 @@ class SynthesisEngine:
     def handle(self):
         return self._h
 
-    def make_noises(self, batch, generator=None):
-        """Unit-variance noise tensors for noise_mode='random' (one [B,res,res] per SynthesisLayer)."""
-        return [torch.randn([batch, r, r], device=self.device, generator=generator) for r in self.layer_resolutions]
+    def make_noises(self, batch, generator=None, sample_seeds=None):
+        """Unit-variance noise tensors for noise_mode='random': one [B,res,res] per SynthesisLayer, None where the layer's
+        noise_strength is 0 (the term vanishes, nothing is drawn).  `sample_seeds` (one int per sample) makes sample i's noise
+        a function of its seed alone, so that a rank holding a shard of the batch draws what a single process would."""
+        out = []
+        for li, (r, ns) in enumerate(zip(self.layer_resolutions, self.noise_strengths)):
+            if ns == 0.0:
+                out.append(None)
+            elif sample_seeds is None:
+                out.append(torch.randn([batch, r, r], device=self.device, generator=generator))
+            else:
+                assert len(sample_seeds) == batch
+                t = torch.empty([batch, r, r], device=self.device)
+                for i, sd in enumerate(sample_seeds):
+                    g = torch.Generator(device=self.device).manual_seed((int(sd) * 64 + li) & 0x7FFFFFFFFFFFFFFF)
+                    t[i] = torch.randn([r, r], device=self.device, generator=g)
+                out.append(t)
+        return out
 
     def noise_pointer_array(self, noises):
         if noises is None:
             return None
         assert len(noises) == self.num_layers
-        for t, r in zip(noises, self.layer_resolutions):
+        for t, r, ns in zip(noises, self.layer_resolutions, self.noise_strengths):
+            if t is None:
+                assert ns == 0.0, 'a layer with noise_strength != 0 needs its noise tensor'
+                continue
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape[-2:] == (r, r)
-        return (C.c_void_p * len(noises))(*[t.data_ptr() for t in noises])
+        return (C.c_void_p * len(noises))(*[t.data_ptr() if t is not None else None for t in noises])
 
     def forward(self, ws, noise_mode='const', noises=None, out=None):
         """ws [B,num_ws,w_dim] (or [B,1,w_dim] / [B,w_dim]: W space) -> img [B,C,R,R]."""
@@ -370,6 +388,14 @@ class FeatureEngine:
             else:
                 raise ValueError(op[0])
         self._keep = params
+        # short content hash of the weights (host side, once): identifies which feature net a cached bank was built with
+        import hashlib
+        hsh = hashlib.sha1()
+        for op in ops:
+            hsh.update(op[0].encode())
+            for t in op[1:]:
+                hsh.update(t.detach().to('cpu', torch.float32).contiguous().numpy().tobytes())
+        self.weights_digest = hsh.hexdigest()[:10]
         self.in_ch, self.in_res, self.max_batch = in_ch, in_res, int(max_batch)
         arr = (_lib.FeatOp * len(desc))(*desc)
         nbytes = lib.la_feat_workspace_bytes(len(desc), arr, in_ch, in_res, self.max_batch)

@@ -75,6 +75,13 @@ def make_banks(num_ws, res=256, img_channels=2, w_dim=512, M_w=1024, M_x=256, se
     return W, X
 
 
+def make_feature_banks(M_x, F, img_channels=2, seed=5):
+    """fea_<mode> = randn([M_x, F]) / sqrt(F) per modality (seed 5): stand-in for the real-image LPIPS feature banks
+    (util_latent_aug.py:160-171); unit-norm rows, like LPIPS feature vectors."""
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn([M_x, F], generator=g) * (1.0 / F) ** 0.5 for _ in range(img_channels)]
+
+
 def make_discriminator_state_dict(img_resolution=256, img_channels=2, channel_base=32768, channel_max=512, seed=1000):
     """state_dict of a random-init SG2 discriminator (architecture 'resnet'), keys as in the reference's D
     (legacy.py:271-288): weights randn, biases 0."""

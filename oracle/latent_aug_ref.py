@@ -138,7 +138,7 @@ class LatentAugRef:
     def __init__(self, G, D=None, W=None, X=None, fea=None, feature_net=None, res=256, num_epochs=5,
                  opt_lr=0.01, w_latent=0.0, w_pix=0.0, w_disc=0.0, w_lpips=0.0, crop_size=64,
                  preprocess='center_random_crop', soft_aug=False, alpha=1.0, final_noise_mode='random',
-                 fused_modconv=True):
+                 fused_modconv=True, dtype=torch.float32):
         self.G, self.D, self.W, self.X, self.fea, self.feature_net = G, D, W, X, fea, feature_net
         self.res, self.num_epochs, self.opt_lr = res, num_epochs, opt_lr
         self.w_latent, self.w_pix, self.w_disc, self.w_lpips = w_latent, w_pix, w_disc, w_lpips
@@ -146,6 +146,7 @@ class LatentAugRef:
         self.soft_aug, self.alpha = soft_aug, alpha
         self.final_noise_mode = final_noise_mode
         self.fused_modconv = fused_modconv
+        self.dtype = dtype          # float64: tolerance anchor (the caller also moves G/D/banks and sets sg2_networks.COMPUTE_DTYPE)
         self.num_ws = G.num_ws
         self.trace = None
 
@@ -154,7 +155,7 @@ class LatentAugRef:
 
     def forward(self, w, crop_pos=None, record=False):
         """w [b,1,512] -> (img [b,C,r,r], w_aug [b,num_ws,512]).  crop_pos: (x,y) or None (draw)."""
-        w = w.detach().to(torch.float32)
+        w = w.detach().to(self.dtype)
         w_opt = w.clone()
         adam = AdamState(w_opt, self.opt_lr)
         if crop_pos is None:

@@ -18,6 +18,10 @@ import torch.nn as nn
 
 from . import sg2_ops as ops
 
+# The reference's networks force fp32 off-GPU; tests that anchor a tolerance against a float64 run of
+# the same definition set this to torch.float64 (and move the module with .double()) for the duration of that run.
+COMPUTE_DTYPE = torch.float32
+
 
 def channels_dict(img_resolution, channel_base=32768, channel_max=512):
     log2 = int(math.log2(img_resolution))
@@ -56,7 +60,7 @@ class MappingNetwork(nn.Module):
         self.register_buffer('w_avg', torch.zeros([w_dim]))
 
     def forward(self, z, c=None, truncation_psi=1.0, truncation_cutoff=None):
-        x = z.to(torch.float32)
+        x = z.to(COMPUTE_DTYPE)
         x = x * (x.square().mean(dim=1, keepdim=True) + 1e-8).rsqrt()
         for i in range(self.num_layers):
             x = getattr(self, f'fc{i}')(x)
@@ -174,7 +178,7 @@ class SynthesisNetwork(nn.Module):
 
     def forward(self, ws, noise_mode='random', fused_modconv=True, noises=None, return_features=False):
         """noises: optional list (one per SynthesisLayer, in execution order) of [B,1,r,r] unit noise."""
-        ws = ws.to(torch.float32)
+        ws = ws.to(COMPUTE_DTYPE)
         x = img = None
         w_idx = 0
         n_idx = 0
@@ -308,7 +312,7 @@ class Discriminator(nn.Module):
 
     def forward(self, img, c=None):
         x = None
-        img = img.to(torch.float32)
+        img = img.to(COMPUTE_DTYPE)
         for res in self.block_resolutions:
             x = getattr(self, f'b{res}')(x, img)
         return self.b4(x)

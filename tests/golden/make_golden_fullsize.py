@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Full-size golden vectors for BASELINE.json configs B, C, D, E -- made by RUNNING THE REFERENCE in the build container.
+
+Run from the repo root:   python tests/golden/make_golden_fullsize.py [B C D E]
+Needs /root/reference (read-only).  Never runs on the GPU box; only tests/golden/fullsize_<cfg>.npz travels.
+
+Per config two CPU runs on identical seeded inputs (latentaugment_amd.synthetic, BASELINE.md "Synthetic inputs"):
+  * ref32 -- the REFERENCE's own `LatentAug.forward` (augments/utils/util_latent_aug.py:207-310) on the reference's op
+    layer, float32: the reference CPU path the north-star names.  Same harness as tests/golden/make_golden.py (our SG2
+    network definition re-wired onto the reference ops, because the reference tree holds no network source).
+  * o64 -- the oracle restatement of the same loop in float64: the anchor that says how far float32 itself is from the
+    exact result, so that the GPU tests can state "HIP is no further from float64 than 1.5x the reference's float32 is".
+Stored: the optimised latent of every sample (both runs), the o64 latent after every step, the final image sub-sampled
+on a regular grid plus per-plane float64 moments of the whole image, and checksums of the inputs.
+"""
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg          # noqa: E402  (installs the absent-module stand-ins, imports the reference)
+
+from latentaugment_amd import synthetic          # noqa: E402
+from oracle import feature_net as fnets          # noqa: E402
+from oracle import latent_aug_ref as lar         # noqa: E402
+from oracle import sg2_networks as nets          # noqa: E402
+from oracle import sg2_ops as our_ops            # noqa: E402
+
+torch.set_num_threads(8)
+
+# (authors' criterion weights: backbone_latentaug.py:46-54)
+CONFIGS = {
+    'B': dict(res=256, channel_base=32768, batch=8, steps=20, M_w=1024, M_x=256, w_latent=0.001, w_pix=0.1, w_disc=0.0, w_lpips=0.0),
+    'C': dict(res=512, channel_base=32768, batch=4, steps=5, M_w=1024, M_x=256, w_latent=0.001, w_pix=0.1, w_disc=0.0, w_lpips=0.0),
+    'D': dict(res=1024, channel_base=32768, batch=2, steps=3, M_w=1024, M_x=64, w_latent=0.001, w_pix=0.1, w_disc=0.0, w_lpips=0.0),
+    'E': dict(res=256, channel_base=16384, batch=8, steps=5, M_w=6026, M_x=1572, w_latent=0.001, w_pix=0.1, w_disc=0.01, w_lpips=10.0),
+}
+CROP = 64
+CROP_SEED = 6
+
+
+def build_inputs(c):
+    """Everything both runs (and the GPU test) need, from seeds only."""
+    sd, meta = synthetic.make_generator_state_dict(img_resolution=c['res'], img_channels=2, channel_base=c['channel_base'], seed=0)
+    G = nets.Generator(img_resolution=c['res'], img_channels=2, channel_base=c['channel_base'])
+    G.load_state_dict(sd, strict=False)
+    G = G.eval().requires_grad_(False)
+    W, X = synthetic.make_banks(meta['num_ws'], res=c['res'], M_w=c['M_w'], M_x=c['M_x'])
+    w0 = synthetic.make_latents(c['batch'])
+    D = fnet = fea = None
+    if c['w_disc'] > 0:
+        dsd = synthetic.make_discriminator_state_dict(img_resolution=c['res'], img_channels=2, channel_base=c['channel_base'])
+        D = nets.Discriminator(img_resolution=c['res'], img_channels=2, channel_base=c['channel_base'])
+        D.load_state_dict(dsd, strict=True)
+        D = D.eval().requires_grad_(False)
+    if c['w_lpips'] > 0:
+        fnet = fnets.VGG16Features(seed=7, width=64)          # VGG16 topology at full width, random weights (vgg16.pt is a download)
+        fea = synthetic.make_feature_banks(c['M_x'], synthetic.lpips_num_features(CROP, 64))
+    return sd, meta, G, D, fnet, W, X, fea, w0
+
+
+def subsample(img, res):
+    st = res // 64
+    return img[:, :, st // 2::st, st // 2::st]
+
+
+def moments(img):
+    d = img.double()
+    return np.stack([d.sum(dim=(2, 3)).numpy(), d.square().sum(dim=(2, 3)).numpy()])
+
+
+def run(name):
+    c = CONFIGS[name]
+    t0 = time.time()
+    sd, meta, G, D, fnet, W, X, fea, w0 = build_inputs(c)
+    random.seed(CROP_SEED)
+    crop_pos = mg.ref_ud.get_params(c['res'], CROP, 'center_random_crop')['crop_pos']
+    out = dict(cfg=np.array(repr(c)), crop_pos=np.array(crop_pos), w0_sum=np.array(float(w0.double().sum())),
+               W_sum=np.array(float(W.double().sum())), X_sum=np.array(float(X.double().sum())))
+    if fea is not None:
+        out['fea_sum'] = np.array([float(f.double().sum()) for f in fea])
+    kw = dict(w_latent=c['w_latent'], w_pix=c['w_pix'], w_disc=c['w_disc'], w_lpips=c['w_lpips'])
+
+    # ---- ref32: the reference's loop on the reference's ops
+    nets.ops = mg._RefOpsAdapter
+    try:
+        m = mg.build_ref_module(G, D, W, X, fea, fnet, res=c['res'], batch=c['batch'], epochs=c['steps'], lr=0.01, crop=CROP, **kw)
+        random.seed(CROP_SEED)
+        torch.manual_seed(123)
+        img, w_aug = m.forward(w0.clone(), [f'f{i}' for i in range(c['batch'])])
+    finally:
+        nets.ops = our_ops
+    out['ref32_w'] = mg.T(w_aug[:, 0])
+    assert float((w_aug - w_aug[:, :1]).abs().max()) == 0.0
+    out['ref32_img_sub'] = mg.T(subsample(img, c['res']))
+    out['ref32_img_mom'] = moments(img.detach())
+    print(name, 'ref32 done', f'{time.time() - t0:.0f}s', 'max|dw|', float((w_aug[:, 0] - w0[:, 0]).abs().max()), flush=True)
+    del m
+
+    # ---- o64: the oracle restatement in float64
+    nets.COMPUTE_DTYPE = torch.float64
+    try:
+        G.double()
+        if D is not None:
+            D.double()
+        if fnet is not None:
+            fnet.double()
+        ref = lar.LatentAugRef(G, D, W=W.double(), X=X.double(), fea=[f.double() for f in fea] if fea is not None else None,
+                               feature_net=fnet, res=c['res'], num_epochs=c['steps'], opt_lr=0.01, crop_size=CROP,
+                               final_noise_mode='const', dtype=torch.float64, **kw)
+        img64, w64 = ref.forward(w0, crop_pos=tuple(crop_pos), record=True)
+    finally:
+        nets.COMPUTE_DTYPE = torch.float32
+        G.float()
+    out['o64_w'] = w64[:, 0].numpy()
+    out['o64_w_steps'] = torch.stack([t[:, 0] for t in ref.trace['w']]).to(torch.float32).numpy()
+    for k in ('loss_latent', 'loss_pix', 'loss_disc', 'loss_lpips'):
+        out['o64_' + k] = np.array(ref.trace[k])
+    out['o64_img_sub'] = subsample(img64, c['res']).numpy()
+    out['o64_img_mom'] = moments(img64)
+    e32 = np.abs(out['ref32_w'].astype(np.float64) - out['o64_w'])
+    print(name, 'o64 done', f'{time.time() - t0:.0f}s', 'ref32-vs-o64 latent err max', e32.max(), 'rms', np.sqrt((e32 ** 2).mean()), flush=True)
+    np.savez_compressed(os.path.join(HERE, f'fullsize_{name}.npz'), **out)
+    print(name, 'saved', os.path.getsize(os.path.join(HERE, f'fullsize_{name}.npz')) // 1024, 'KB', flush=True)
+
+
+if __name__ == '__main__':
+    for n in (sys.argv[1:] or ['B', 'C', 'D', 'E']):
+        run(n)

@@ -74,3 +74,53 @@ def test_network_pickle_loader_runs_no_embedded_code(tmp_path, fake_persistence_
     d.mkdir(parents=True)
     (d / 'net.pkl').write_bytes(blob)
     assert formats.find_network_pkl(str(tmp_path / 'models'), 'DS', 'DSNAME', ['A', 'B'], '00003', 'net.pkl') == str(d / 'net.pkl')
+
+
+class _Boom:
+    """Pickles to a call of os.getcwd -- harmless, but proves code execution if it ever runs inside the loader."""
+    fired = False
+
+    def __reduce__(self):
+        return (_boom_fire, ())
+
+
+def _boom_fire():
+    _Boom.fired = True
+    return 'fired'
+
+
+class _ViaLoadFromBytes:
+    def __init__(self, inner):
+        self.inner = inner
+
+    def __reduce__(self):
+        return (torch.storage._load_from_bytes, (self.inner,))
+
+
+def test_safe_loader_refuses_nested_pickle_through_load_from_bytes():
+    """torch.storage._load_from_bytes is a full torch.load(weights_only=False): a pickle that wraps a second pickle in it
+    must not get an unrestricted unpickle of the inner bytes (round-1 advisor finding), while real tensors carried that
+    way still load."""
+    inner = pickle.dumps(_Boom())
+    evil = pickle.dumps(_ViaLoadFromBytes(inner))
+    _Boom.fired = False
+    with pytest.raises(Exception) as ei:
+        formats._restricted_load(io.BytesIO(evil))
+    assert not _Boom.fired, 'inner payload was executed'
+    assert isinstance(ei.value, (pickle.UnpicklingError, RuntimeError))
+    # a genuine tensor through the same entry point
+    buf = io.BytesIO()
+    torch.save(torch.arange(5.0), buf)
+    good = pickle.dumps(_ViaLoadFromBytes(buf.getvalue()))
+    assert torch.equal(formats._restricted_load(io.BytesIO(good)), torch.arange(5.0))
+    # numpy: only the reconstruction helpers are reachable, not arbitrary attributes of numpy's core modules
+    class _NpAttr:
+        def __reduce__(self):
+            return (np.zeros, ((2,),))
+    with pytest.raises(pickle.UnpicklingError):
+        formats._restricted_load(io.BytesIO(pickle.dumps(_NpAttr())))
+    # ndarrays and the zip-member dicts still round-trip
+    a = {'A': np.arange(6, dtype=np.float32).reshape(2, 3), 'n': np.float64(3.5)}
+    b = formats._restricted_load(io.BytesIO(pickle.dumps(a)))
+    np.testing.assert_array_equal(a['A'], b['A'])
+    assert float(b['n']) == 3.5

@@ -121,7 +121,8 @@ def test_synthetic_state_dict_matches_reference_names():
 _WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from latentaugment_amd.latent_aug import shard_bounds, gather_shards
+import random
+from latentaugment_amd.latent_aug import shard_bounds, gather_shards, broadcast_controls, get_params
 dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%s' % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
 rank = dist.get_rank()
 for B in (5, 8, 1):
@@ -130,6 +131,13 @@ for B in (5, 8, 1):
     local = full[lo:hi] * 2.0          # stand-in for the per-rank optimisation of its own samples
     out = gather_shards(local, per, B)
     assert torch.equal(out, full * 2.0), (B, rank, out)
+# per-forward host draws: every rank ends with RANK 0's crop position and noise seed, whatever its own RNG state
+random.seed(100 + rank)
+mine = get_params(256, 64)['crop_pos']
+cx, cy, seed = broadcast_controls(mine)
+random.seed(100)
+want = get_params(256, 64)['crop_pos']
+assert (cx, cy) == tuple(want) and seed == random.getrandbits(48), (rank, cx, cy, seed)
 dist.barrier()
 dist.destroy_process_group()
 print('ok', rank)
