@@ -4,17 +4,29 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one batch through the plugin API (set_input -> forward -> get_output): B images, `--latent-steps` Adam steps
-of StyleGAN2 synthesis forward + backward-to-w each, then the final synthesis (reference loop: backbone_latentaug.py:99-106).
-Workload (BASELINE.json configs[1]): SG2 config-f 256x256, 2 channels, random-init G, B = 8 per GPU, 20 latent steps,
-criteria w_latent=0.001 / w_pix=0.1 (banks M_w=1024, M_x=256, scanned every step), synthetic inputs.
-Inputs (latents, banks, weights) are resident in HBM when the timed region starts; the image D2H copy of get_output()
-is inside the timed region, as it is in the reference's loop.
-Weak scaling: every rank optimises its own B images; one RCCL all_gather of the augmented batch per step.
+A "step" is one batch through the plugin API exactly as the reference's driver runs it (backbone_latentaug.py:99-106):
+    augment.set_input(data);  augment.forward();  out = augment.get_output()
+i.e. B images per GPU, `--latent-steps` Adam steps of StyleGAN2 synthesis forward + backward-to-w each, then the final
+synthesis.  Workload (BASELINE.json configs[1]): SG2 config-f 256x256, 2 channels, random-init G, B = 8 per GPU, 20 latent
+steps, criteria w_latent=0.001 / w_pix=0.1 (banks M_w=1024, M_x=256), synthetic inputs.  Weights, banks and
+the latent source are resident (HBM / host dict) when the timed region starts; the per-batch H2D of the latents and the D2H
+of the augmented batch in get_output() are inside the timed region, as they are in the reference's loop.
+
+N > 1 (one rank per GPU, RCCL): every rank holds the same global batch of 8*N samples and calls the same three plugin
+methods; `LatentAug.forward` hands rank k samples [8k, 8k+8) and returns the whole batch to every rank with ONE
+all_gather over xGMI (weak scaling: 8 images per GPU).
+
+Reported next to the metric:
+  * roofline -- HIP-event brackets around every launch of ONE extra batch run right after the timed region (the timed
+    region replays a captured step as a hipGraph and cannot be bracketed per launch; the extra batch launches the same
+    kernels eagerly), per kernel class, against gfx950 peaks;
+  * cpu_baseline -- the CPU oracle (a port pinned to outputs of the reference) on the host cores, bounded sample.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import platform
 import random
 import sys
 import time
@@ -26,16 +38,29 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
-# fp32-equivalent peak of each contraction mode: one fp32 product = 1 fp32 MFMA, or 6 / 3 bf16 MFMAs of the split scheme
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (not the 2:1-sparsity figure)
+# fp32-equivalent peak of each contraction mode: one fp32 product = 1 fp32 MFMA, or 6 / 3 16-bit MFMAs of the split scheme
 CONTRACTION = {
     'f32': dict(peak=MFMA_F32_PEAK_TFLOPS, kernel='la_conv_igemm_kernel (fp32 MFMA 32x32x2, exact fp32)', mfma_per_product=1),
-    'bf16x3': dict(peak=MFMA_BF16_PEAK_TFLOPS / 6, kernel='la_conv_bf16_halo_kernel / la_conv_bf16_kernel <FMT_BF16X3> (fp32 split into 3 bf16 terms, 6 bf16 '
+    'bf16x3': dict(peak=MFMA_BF16_PEAK_TFLOPS / 6, kernel='la_conv_bf16_halo_kernel<FMT_BF16X3> (fp32 split into 3 bf16 terms, 6 bf16 '
                    'MFMA 32x32x16 per product, fp32 accumulate; fp32-class error)', mfma_per_product=6),
-    'f16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_halo_kernel / la_conv_bf16_kernel <FMT_F16X2> (fp32 scaled by powers of two and split into '
+    'f16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_halo_kernel<FMT_F16X2> (fp32 scaled by powers of two and split into '
                   '2 fp16 terms, 3 fp16 MFMA 32x32x16 per product, fp32 accumulate; fp32-class error)', mfma_per_product=3),
-    'bf16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_kernel<NTERM=2> (2 bf16 terms, 3 bf16 MFMA per product; '
+    'bf16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_halo_kernel<NTERM=2> (2 bf16 terms, 3 bf16 MFMA per product; '
                    'approximate mode)', mfma_per_product=3),
+}
+# launch-profiler classes (include/latentaug_hip.h, la_prof_end_classes)
+CLASSES = ['conv_halo', 'conv_flat', 'conv_splitk', 'conv_f32', 'operand_prep', 'fir', 'seam_bwd', 'torgb_fwd', 'bank']
+CLASS_KERNELS = {
+    'conv_halo': 'la_conv_bf16_halo_kernel (stride-1 3x3 layers >= 64^2, fp32 input read directly)',
+    'conv_flat': 'la_conv_bf16_kernel<split=false> (transposed-conv phases and stride-2 backward of the up-sampling layers)',
+    'conv_splitk': 'la_conv_bf16_kernel<split=true> + la_conv_splitk_finish_kernel (layers <= 32^2)',
+    'conv_f32': 'la_conv_igemm_kernel (exact fp32 MFMA)',
+    'operand_prep': 'la_presplit_t_kernel / la_plane_absmax_kernel / la_xscale*_kernel (fp16 operand scale and pre-split copy)',
+    'fir': 'la_fir4x4_s1_kernel / la_upfirdn2d_kernel (upfirdn2d family, fwd with the layer epilogue, adjoint)',
+    'seam_bwd': 'la_seam_bwd_kernel (bias_act backward + ToRGB backward + demod-gradient reductions)',
+    'torgb_fwd': 'la_torgb_fwd_kernel (1x1 modulated ToRGB + clamp + skip add)',
+    'bank': 'la_bank_* (criteria bank scans)',
 }
 
 
@@ -56,6 +81,7 @@ def parse():
     p.add_argument('--preset', default='B', choices=['B', 'E'],
                    help="B: BASELINE.json configs[1] (the metric's config). E: configs[4] per-GPU shape -- config-e 256^2, all four "
                         "criteria at the authors' weights (w_lpips 10, w_pix 0.1, w_latent 0.001, w_disc 0.01), Pelvis-scale banks")
+    p.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured step')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true', help='skip the HIP-event leg (used under rocprofv3)')
     p.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
@@ -72,48 +98,131 @@ def apply_preset(args):
     return args
 
 
-def make_opt(args, local_rank):
+def make_opt(args, local_rank, global_batch):
     return types.SimpleNamespace(
         aug='latent', gpu_ids=[local_rank], gpu_ids_aug=str(local_rank), checkpoints_dir='/tmp', name='bench', phase='train',
-        img_resolution=args.res, batch_size=args.batch, modalities_aug='A,B', opt_num_epochs=args.latent_steps, opt_lr=0.01,
+        img_resolution=args.res, batch_size=global_batch, modalities_aug='A,B', opt_num_epochs=args.latent_steps, opt_lr=0.01,
         truncation_psi=1.0, w_pix=args.w_pix, w_lpips=args.w_lpips, w_latent=args.w_latent, w_disc=args.w_disc, crop_size_aug=64,
         preprocess_aug='center_random_crop', soft_aug=False, alpha=1.0, verbose_log=False, rand_aug=False,
         lower_bound_clip=False, p_thres=0.0, init_w='inv', criterion_mode=args.criterion_mode, final_noise_mode='random',
-        precision=args.precision)
+        precision=args.precision, hip_graph=not args.no_graph)
+
+
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or 'unknown'
 
 
 def cpu_baseline(sd, meta, args):
-    """The oracle (a CPU port pinned to reference goldens) on the host cores, bounded sample, scaled to images/s."""
+    """The oracle (a CPU port pinned to outputs of the reference) on the host cores: bounded sample of the SAME workload
+    (same G, banks and criteria; B=4, 4 latent steps + the final synthesis, timed), scaled to images/s of the full
+    20-step batch.  Run at all the host cores this process may use and again at 8 threads."""
     import torch
     from oracle import latent_aug_ref as lar
     from oracle import sg2_networks as nets
     from latentaugment_amd import synthetic
-    # the GPU box gives one GPU a 16-core CPU share; more threads than that only oversubscribes
-    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 16)
-    torch.set_num_threads(cores)
+    # "all cores" = the CPU share of one GPU on the box: 16 (more threads than the share only oversubscribes the cgroup)
+    avail = min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 16)
     G = nets.Generator(z_dim=meta['w_dim'], w_dim=meta['w_dim'], img_resolution=args.res, img_channels=2,
                        channel_base=args.channel_base)
     G.load_state_dict(sd, strict=False)
     G = G.eval().requires_grad_(False)
-    b = 4
-    W, X = synthetic.make_banks(G.num_ws, res=args.res, M_w=1024, M_x=256)
-    nstep = 4
-    ref = lar.LatentAugRef(G, None, W=W, X=X, res=args.res, num_epochs=nstep, opt_lr=0.01, crop_size=64, w_latent=0.001,
-                           w_pix=0.1)
+    b, nstep = 4, 4
+    W, X = synthetic.make_banks(G.num_ws, res=args.res, M_w=args.M_w, M_x=args.M_x)
+    ref = lar.LatentAugRef(G, None, W=W, X=X, res=args.res, num_epochs=nstep, opt_lr=0.01, crop_size=64, w_latent=args.w_latent,
+                           w_pix=args.w_pix)
     w0 = synthetic.make_latents(b)
-    with torch.no_grad():
-        G.synthesis(w0.repeat(1, G.num_ws, 1), noise_mode='const')      # warm the allocator / thread pool
+
+    def run(threads):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            G.synthesis(w0.repeat(1, G.num_ws, 1), noise_mode='const')      # warm the allocator / thread pool
+            t0 = time.time()
+            G.synthesis(w0.repeat(1, G.num_ws, 1), noise_mode='const')
+            t_fwd = time.time() - t0
         t0 = time.time()
-        G.synthesis(w0.repeat(1, G.num_ws, 1), noise_mode='const')
-        t_fwd = time.time() - t0
-    t0 = time.time()
-    ref.forward(w0, crop_pos=(0, 0))          # nstep optimisation steps (fwd + bwd + Adam) + the final synthesis
-    t_loop = time.time() - t0
-    t_step = max(t_loop - t_fwd, 1e-9) / nstep
-    per_batch = args.latent_steps * t_step + t_fwd
-    return {'value': b / per_batch, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle (CPU restatement pinned to reference goldens), same G/banks, B={b}: {nstep} latent steps + final '
-                      f'synthesis timed ({t_loop:.1f}s, of which final {t_fwd:.1f}s), extrapolated to {args.latent_steps} steps'}
+        ref.forward(w0, crop_pos=(0, 0))          # nstep optimisation steps (fwd + bwd + Adam) + the final synthesis
+        t_loop = time.time() - t0
+        t_step = max(t_loop - t_fwd, 1e-9) / nstep
+        return b / (args.latent_steps * t_step + t_fwd), t_loop, t_fwd
+
+    v_all, t_loop, t_fwd = run(avail)
+    out = {'value': v_all, 'unit': 'images/s', 'cores': avail, 'kind': 'port', 'cpu_model': cpu_model(),
+           'sample': f'oracle (CPU restatement pinned to outputs of the reference), same G / banks / criteria, B={b}: {nstep} latent '
+                     f'steps + final synthesis timed ({t_loop:.1f}s, of which final {t_fwd:.1f}s), scaled to {args.latent_steps} steps'}
+    if avail != 8:
+        v8, t8, _ = run(min(8, avail))
+        out['value_8_threads'] = v8
+        out['sample'] += f'; same sample at 8 threads: {t8:.1f}s'
+    return out
+
+
+def roofline_leg(lib, _lib, args, one_step, elapsed_per_step):
+    """HIP events around every launch of one extra batch (eager launches of the same kernels), per kernel class."""
+    _lib.check(lib.la_prof_set_stride(1), 'la_prof_set_stride')
+    _lib.check(lib.la_prof_begin(), 'la_prof_begin')
+    one_step()
+    n = lib.la_prof_num_classes()
+    ms, cnt, fl, by = (C.c_double * n)(), (C.c_long * n)(), (C.c_double * n)(), (C.c_double * n)()
+    rc = lib.la_prof_end_classes(ms, cnt, fl, by, n)
+    if rc != 0:
+        return None
+    cm = CONTRACTION[args.precision]
+    per = {}
+    for i, name in enumerate(CLASSES[:n]):
+        if cnt[i] == 0:
+            continue
+        t = ms[i] * 1e-3
+        e = {'kernel': CLASS_KERNELS[name], 'launches_per_batch': int(cnt[i]), 'ms_per_batch': ms[i], 'avg_launch_us': 1e3 * ms[i] / cnt[i],
+             'algorithmic_bytes_per_launch': by[i] / cnt[i], 'achieved_gbs': by[i] / t / 1e9, 'hbm_frac': by[i] / t / 1e9 / HBM_PEAK_GBS}
+        if fl[i] > 0 and name.startswith('conv'):
+            tf = fl[i] / t / 1e12
+            e.update({'algorithmic_flops_per_launch': fl[i] / cnt[i], 'achieved_tflops_fp32_equiv': tf, 'mfma_frac': tf / cm['peak'],
+                      'executed_mfma_tflops': tf * cm['mfma_per_product']})
+        per[name] = e
+    dom = max((k for k in per if k.startswith('conv')), key=lambda k: per[k]['ms_per_batch'], default=None)
+    if dom is None:
+        return None
+    d = per[dom]
+    tot_ms = sum(e['ms_per_batch'] for e in per.values())
+    conv_ms = sum(e['ms_per_batch'] for k, e in per.items() if k.startswith('conv'))
+    conv_fl = sum(fl[i] for i, k in enumerate(CLASSES[:n]) if k.startswith('conv'))
+    roof = {'bound': 'mfma', 'kernel': cm['kernel'] + f' [{dom}: the class with the most device time]',
+            'achieved': d['achieved_tflops_fp32_equiv'], 'peak': cm['peak'], 'unit': 'TFLOP/s', 'frac': d['mfma_frac'],
+            'peak_note': 'fp32-equivalent: dense MFMA peak of the instruction used / MFMAs issued per fp32 product '
+                         f"({cm['mfma_per_product']}); executed MFMA rate = {d['executed_mfma_tflops']:.0f} TFLOP/s",
+            'avg_launch_ms': d['avg_launch_us'] * 1e-3, 'launches_per_batch': d['launches_per_batch'],
+            'algorithmic_flops_per_launch': d['algorithmic_flops_per_launch'],
+            'algorithmic_bytes_per_launch': d['algorithmic_bytes_per_launch'],
+            'traffic': None,
+            'all_contractions': {'achieved': conv_fl / (conv_ms * 1e-3) / 1e12, 'frac': conv_fl / (conv_ms * 1e-3) / 1e12 / cm['peak'],
+                                 'ms_per_batch': conv_ms},
+            'bracketed_ms_per_batch': tot_ms, 'timed_ms_per_batch': elapsed_per_step,
+            'measured': 'HIP events around every launch of one extra batch right after the timed region (launched eagerly; the timed '
+                        'region replays the same launches from a captured hipGraph)',
+            'classes': per, 'hbm_peak_gbs': HBM_PEAK_GBS}
+    # whole-pass HBM view: SURVEY 8(d) algorithmic bytes of the G pass per batch over the timed time per batch
+    if args.preset == 'B' and args.res == 256 and args.channel_base == 32768 and args.w_disc == 0:
+        alg = (args.batch * (args.latent_steps * 700.2e6 + 274.6e6) + (2 * args.latent_steps + 1) * 94e6)
+        roof['whole_pass'] = {'algorithmic_bytes_per_batch': alg, 'achieved_gbs': alg / (elapsed_per_step * 1e-3) / 1e9,
+                              'hbm_frac': alg / (elapsed_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              'note': 'SURVEY 8(d): 700.2 MB per image-step (fwd+bwd) + 274.6 MB final forward per image + shared weights'}
+    # HBM bytes per launch of the dominant class from the committed PMC passes of this workload (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate passes, scripts/make_profiles.sh): counters cannot be read from inside the process
+    pmc = os.path.join(ROOT, 'profiles', f'r02_pmc_traffic_{args.precision}.json')
+    if os.path.isfile(pmc) and args.preset == 'B' and args.w_disc == 0 and args.batch == 8 and args.res == 256:
+        pj = json.load(open(pmc))
+        if pj.get('precision') == args.precision and dom in pj.get('classes', {}):
+            roof['traffic'] = pj['classes'][dom].get('bytes_per_launch')
+            roof['traffic_source'] = os.path.relpath(pmc, ROOT)
+            roof['traffic_note'] = pj.get('note')
+    return roof
 
 
 def main():
@@ -141,15 +250,13 @@ def main():
     from latentaugment_amd.augments import create_augment
     from latentaugment_amd.latent_aug import InMemoryLatentCodes
 
-    sd, meta = synthetic.make_generator_state_dict(img_resolution=args.res, img_channels=2, channel_base=args.channel_base,
-                                                   seed=0)
+    gb = args.batch * world      # the global batch every rank sees; LatentAug.forward shards it (8 per GPU: weak scaling)
+    sd, meta = synthetic.make_generator_state_dict(img_resolution=args.res, img_channels=2, channel_base=args.channel_base, seed=0)
     W, X = synthetic.make_banks(meta['num_ws'], res=args.res, M_w=args.M_w, M_x=args.M_x)
-    data = synthetic.make_batch(args.batch, res=args.res, seed=2 + rank)
-    w0 = synthetic.make_latents(args.batch, seed=1 + rank)
+    data = synthetic.make_batch(gb, res=args.res, seed=2)
+    w0 = synthetic.make_latents(gb, seed=1)
     codes = InMemoryLatentCodes({p: w0[i, 0].numpy() for i, p in enumerate(data['A_paths'])})
-    opt = make_opt(args, local_rank)
-    # each rank owns its own B images (weak scaling); the plugin itself is run un-sharded per rank, the gather of the
-    # whole job's output is done below with the same single collective the sharded plugin path uses
+    opt = make_opt(args, local_rank, gb)
     opt.inject = dict(generator=sd, banks={'W': W, 'X': X}, latent_codes=codes, group=None)
     if args.w_lpips > 0:
         # VGG16-shaped feature net with random weights (the real vgg16.pt is a download); feature banks drawn on the device
@@ -164,24 +271,12 @@ def main():
     import io
     with contextlib.redirect_stdout(io.StringIO()):
         aug = create_augment(opt)
-    la = aug.latent_aug
     random.seed(6)
 
     def one_step():
+        # the reference driver's loop body (backbone_latentaug.py:99-106)
         aug.set_input(data)
-        # plugin forward without the process-group sharding (each rank has distinct samples)
-        aug.w_AB = aug.sample_from_inversion(aug.fname).to(dev)
-        img, w_aug, _ = la.run_local(aug.w_AB)
-        if world > 1:
-            flat = torch.cat([img.reshape(args.batch, -1), w_aug.reshape(args.batch, -1)], dim=1)
-            if args.dist_backend == 'nccl':
-                out = torch.empty([world * args.batch, flat.shape[1]], device=dev)
-                dist.all_gather_into_tensor(out, flat)      # ONE RCCL collective per batch over xGMI
-            else:                                           # rehearsal path (gloo): same collective, staged through host
-                hflat = flat.cpu()
-                out = torch.empty([world * args.batch, hflat.shape[1]])
-                dist.all_gather_into_tensor(out, hflat)
-        aug.real_AB_aug, aug.w_AB_aug = img, w_aug
+        aug.forward()
         return aug.get_output()
 
     def barrier():
@@ -192,52 +287,22 @@ def main():
     for _ in range(args.warmup):
         one_step()
     lib = _lib.load()
-    prof = (not args.no_roofline)
     barrier()
-    if prof:
-        # HIP events around a hashed 1-in-8 sample of the contraction launches (bracketing all ~900 per batch costs ~3 % of the
-        # timed region); the averages below are over the sampled launches, 'launches' is the total
-        _lib.check(lib.la_prof_set_stride(8), 'la_prof_set_stride')
-        _lib.check(lib.la_prof_begin(), 'la_prof_begin')
     t0 = time.time()
     for _ in range(args.steps):
         out = one_step()
     barrier()
     elapsed = time.time() - t0
-    roof = None
-    if prof:
-        import ctypes as C
-        ms, n, fl, by = C.c_double(), C.c_long(), C.c_double(), C.c_double()
-        rc = lib.la_prof_end(C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
-        total_launches = max(int(lib.la_prof_total_launches()), 1)
-        if rc == 0 and ms.value > 0:
-            tf = fl.value / (ms.value * 1e-3) / 1e12
-            cm = CONTRACTION[args.precision]
-            roof = {'bound': 'mfma', 'kernel': cm['kernel'] + ', all contraction launches',
-                    'achieved': tf, 'peak': cm['peak'], 'unit': 'TFLOP/s', 'frac': tf / cm['peak'],
-                    'peak_note': 'fp32-equivalent: dense MFMA peak of the instruction used / MFMAs issued per fp32 product '
-                                 f"({cm['mfma_per_product']}); executed MFMA rate = {tf * cm['mfma_per_product']:.0f} TFLOP/s",
-                    'traffic': None, 'launches': int(total_launches), 'sampled_launches': n.value,
-                    'avg_launch_ms': ms.value / max(n.value, 1),
-                    'kernel_time_frac_of_wall': ms.value * 1e-3 * (total_launches / max(n.value, 1)) / elapsed,
-                    'algorithmic_gbs': by.value / (ms.value * 1e-3) / 1e9, 'hbm_peak_gbs': HBM_PEAK_GBS}
-            # HBM bytes per launch from the committed PMC passes of this exact workload (scripts/make_profiles.sh)
-            for pmc in (os.path.join(ROOT, 'profiles', f'r01_d_pmc_traffic_{args.precision}.json'),
-                        os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')):
-                if not os.path.isfile(pmc):
-                    continue
-                pj = json.load(open(pmc))
-                if pj.get('precision') == args.precision and args.w_disc == 0 and args.preset == 'B':
-                    roof['traffic'] = pj.get('bytes_per_launch')
-                    roof['traffic_note'] = pj.get('note')
-                    break
-            roof['algorithmic_bytes_per_launch'] = by.value / max(n.value, 1)
-    assert out['A'].shape == (args.batch, 1, args.res, args.res)
+    assert out['A'].shape == (gb, 1, args.res, args.res)
     if world > 1:
         t = torch.tensor([elapsed], device=dev if args.dist_backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    images = args.steps * args.batch * world
+    roof = None
+    if not args.no_roofline:
+        roof = roofline_leg(lib, _lib, args, one_step, 1e3 * elapsed / args.steps)      # (every rank runs it: forward() is collective)
+        barrier()
+    images = args.steps * gb
     line = {
         'metric': 'augmented images/sec (256^2, 20 latent steps)', 'value': images / elapsed, 'unit': 'images/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -248,9 +313,10 @@ def main():
         'config': {'workload': f'SG2 config-{"f" if args.channel_base == 32768 else "e"} {args.res}x{args.res} 2-ch, '
                                f'random-init G, batch={args.batch}/GPU, {args.latent_steps} latent steps, '
                                f'w_latent={args.w_latent:g} w_pix={args.w_pix:g} w_disc={args.w_disc:g} w_lpips={args.w_lpips:g} '
-                               f'(M_w={args.M_w}, M_x={args.M_x}, criterion_mode={args.criterion_mode}), '
-                               f'contraction={args.precision}',
-                   'global_batch': args.batch * world, 'parallelism': f'dp{world}'},
+                               f'(M_w={args.M_w}, M_x={args.M_x}), contraction={args.precision}, '
+                               f'timed call = set_input + LatentAugment.forward + get_output, '
+                               f'launch mode = {"eager" if args.no_graph else "captured step replayed (hipGraph)"}',
+                   'global_batch': gb, 'parallelism': f'dp{world}'},
     }
     if roof is not None:
         line['roofline'] = roof

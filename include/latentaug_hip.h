@@ -244,7 +244,8 @@ typedef struct la_opt_config {
     float lr;               /* opt_lr (latent_aug.py:82) */
     float beta1, beta2, eps;
     float w_latent, w_pix, w_disc, w_lpips; /* latent_aug.py:88-91 */
-    int criterion_mode;     /* 0: scan the banks every step (reference formulation); 1: cached bank column sums */
+    int criterion_mode;     /* 0 | 1, kept for ABI stability: both use bank column sums reduced once per handle for the gradient;
+                               loss scalars (only when losses_out is given) always use the reference's GEMM form over the banks */
     int soft_aug;           /* latent_aug.py:94 */
     float alpha;            /* latent_aug.py:95 */
     int loop_noise_mode;    /* 1 = 'const' (util_latent_aug.py:227) */
@@ -271,6 +272,10 @@ size_t la_latent_opt_lpips_workspace_bytes(int img_channels, int F, int S, long 
 int la_latent_opt_set_lpips(la_latent_opt* h, la_feat* f, const float* bankF, long Mf, int S, float pre_scale,
                             float pre_shift, void* ws, size_t ws_bytes);
 int la_latent_opt_set_crop_pos(la_latent_opt* h, int x, int y);
+/* Launch mode of the step loop (util_latent_aug.py:219-276).  1 (default): one optimisation step is captured as a hipGraph
+ * after its first eager execution and replayed for every further step and batch of the same size -- the loop is ~230 short
+ * launches per step and otherwise host-launch-bound at small batches.  0: every launch eager.  Results are identical. */
+int la_latent_opt_set_graph(la_latent_opt* h, int enable);
 /* w0 [B][w_dim] -> img_out [B][C][R][R], w_aug_out [B][num_ws][w_dim]; losses_out (may be NULL) [steps][4] =
  * weighted {latent, pix, disc, lpips} per step. */
 int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const float* const* final_noises, float* img_out,
@@ -307,6 +312,12 @@ int la_prof_end(double* total_ms, long* launches, double* flops, double* bytes);
  * the stream); la_prof_end then reports the sampled launches' ms / count / FLOPs / bytes, la_prof_total_launches() all of them. */
 int la_prof_set_stride(int stride);
 long la_prof_total_launches(void);
+/* Per kernel class (la_prof_num_classes() entries per array): 0 contraction / halo, 1 contraction / flat, 2 contraction /
+ * split-K incl. its finish pass, 3 contraction / exact-fp32 MFMA, 4 operand preparation (plane maxima, pre-split copy),
+ * 5 FIR (upfirdn2d family), 6 backward seam (bias_act backward + ToRGB backward), 7 ToRGB forward, 8 bank scans.
+ * Bytes are the algorithmic ones (each operand once).  While the profiler is on, the step loop launches eagerly. */
+int la_prof_num_classes(void);
+int la_prof_end_classes(double* ms, long* launches, double* flops, double* bytes, int nclass);
 
 #ifdef __cplusplus
 }

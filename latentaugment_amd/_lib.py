@@ -106,10 +106,13 @@ SIGNATURES = {
     'la_latent_opt_lpips_workspace_bytes': (_Z, [_I, _I, _I, _L, _I]),
     'la_latent_opt_set_lpips': (_I, [_P, _P, _P, _L, _I, _F, _F, _P, _Z]),
     'la_latent_opt_set_crop_pos': (_I, [_P, _I, _I]),
+    'la_latent_opt_set_graph': (_I, [_P, _I]),
     'la_prof_begin': (_I, []),
     'la_prof_end': (_I, [_P, _P, _P, _P]),
     'la_prof_set_stride': (_I, [_I]),
     'la_prof_total_launches': (_L, []),
+    'la_prof_num_classes': (_I, []),
+    'la_prof_end_classes': (_I, [_P, _P, _P, _P, _I]),
 }
 
 _lib = None

@@ -38,6 +38,13 @@ void la_set_error(const char* msg);
         }                                              \
     } while (0)
 
+// kernel classes of the launch profiler (la_prof.hip); the first four are the contraction classes
+enum { LA_PC_CONV_HALO = 0, LA_PC_CONV_FLAT, LA_PC_CONV_SPLITK, LA_PC_CONV_F32, LA_PC_PRESPLIT, LA_PC_FIR, LA_PC_SEAM, LA_PC_TORGB,
+       LA_PC_BANK, LA_PC_NCLASS };
+bool la_prof_enabled();      // profiler active: callers keep their launches eager
+int la_prof_open(int cls, double flops, double bytes, hipStream_t stream);     // -> slot or -1
+void la_prof_close(int slot, hipStream_t stream);
+
 static inline int la_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------- device helpers

@@ -7,6 +7,7 @@
 // modulation multiplied in on the way to LDS.  The next chunk's global loads are issued before the current
 // chunk's MFMAs (register-staged prefetch); fp32 MFMA takes 64 cycles per instruction so the loader has slack.
 #include "la_conv.h"
+#include <stdlib.h>
 #include "la_conv_device.h"
 
 #define KC 16
@@ -206,55 +207,6 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Opt-in launch profiler (bench.py's roofline leg): HIP events bracket every contraction launch on the launch stream.
-// Off by default; the only process-global state in the library.
-#define LA_PROF_MAX 8192
-static struct {
-    int enabled, count, overflow;
-    hipEvent_t ev0[LA_PROF_MAX], ev1[LA_PROF_MAX];
-    int created;
-    double flops, bytes;
-    int stride;              // 1 = bracket every launch; k > 1 = a hashed 1-in-k sample (the event pairs themselves cost ~3 us each)
-    unsigned seq;            // all contraction launches seen since la_prof_begin
-} g_prof;
-
-extern "C" int la_prof_set_stride(int stride) {
-    LA_CHECK_ARG(stride >= 1 && stride <= 64, "prof: stride must be 1..64");
-    g_prof.stride = stride;
-    return LA_OK;
-}
-extern "C" long la_prof_total_launches(void) { return (long)g_prof.seq; }
-
-extern "C" int la_prof_begin(void) {
-    if (g_prof.created < LA_PROF_MAX) {
-        for (int i = g_prof.created; i < LA_PROF_MAX; ++i) {
-            LA_HIP(hipEventCreate(&g_prof.ev0[i]));
-            LA_HIP(hipEventCreate(&g_prof.ev1[i]));
-            g_prof.created = i + 1;
-        }
-    }
-    g_prof.count = 0; g_prof.overflow = 0; g_prof.flops = 0; g_prof.bytes = 0; g_prof.seq = 0; g_prof.enabled = 1;
-    if (g_prof.stride < 1) g_prof.stride = 1;
-    return LA_OK;
-}
-
-// total device time (ms), launches, algorithmic FLOPs and algorithmic bytes of the contraction launches since la_prof_begin
-extern "C" int la_prof_end(double* total_ms, long* launches, double* flops, double* bytes) {
-    g_prof.enabled = 0;
-    double ms = 0;
-    for (int i = 0; i < g_prof.count; ++i) {
-        LA_HIP(hipEventSynchronize(g_prof.ev1[i]));
-        float t = 0.f;
-        LA_HIP(hipEventElapsedTime(&t, g_prof.ev0[i], g_prof.ev1[i]));
-        ms += t;
-    }
-    if (total_ms) *total_ms = ms;
-    if (launches) *launches = g_prof.count;
-    if (flops) *flops = g_prof.flops;
-    if (bytes) *bytes = g_prof.bytes;
-    return g_prof.overflow ? LA_ERR_WORKSPACE : LA_OK;
-}
 
 int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
     LA_CHECK_ARG(a.in && a.wgt && a.out, "conv: null pointer");
@@ -287,25 +239,6 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
             if (t > tiles) tiles = t;
         }
     }
-    int pslot = -1;
-    // (sampling is by a hash of the launch sequence number, so that no periodic launch pattern can alias with it)
-    if (g_prof.enabled && (g_prof.stride <= 1 || ((g_prof.seq++ * 2654435761u) >> 13) % (unsigned)g_prof.stride == 0)) {
-        if (g_prof.stride <= 1) ++g_prof.seq;
-        if (g_prof.count < LA_PROF_MAX) {
-            pslot = g_prof.count++;
-            // algorithmic work of this launch: 2*MACs; bytes = input read once + output written once (+ weights once)
-            double gt = (double)a.Gy * a.Gx * a.ntaps, gout = (double)a.Gy * a.Gx, ntw = a.ntaps;
-            if (nphase > 0) {
-                gt = gout = ntw = 0.0;
-                for (int p = 0; p < nphase; ++p) { gt += (double)a.ph[p].Gy * a.ph[p].Gx * a.ph[p].ntaps; gout += (double)a.ph[p].Gy * a.ph[p].Gx; ntw += a.ph[p].ntaps; }
-            }
-            g_prof.flops += 2.0 * a.B * gt * a.M * (double)a.C;
-            g_prof.bytes += 4.0 * ((double)a.B * a.C * a.Hin * a.Win * (a.in_bstride ? 1.0 : 1.0 / a.B) + (double)a.B * a.M * gout + ntw * a.C * a.M);
-            LA_HIP(hipEventRecord(g_prof.ev0[pslot], stream));
-        } else {
-            g_prof.overflow = 1;
-        }
-    }
     // split-K for the small-resolution layers (see kernel comment)
     LaConvArgs as = a;
     as.ksplit = 1;
@@ -314,10 +247,26 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
     LA_CHECK_ARG(!bf || (a.wgt_bf16 && a.wgt_bf16_term_elems > 0), "conv: split-bf16 precision needs packed bf16 weights");
     const int nck = la_cdiv(a.C, bf ? 32 : KC);
     // 32-row tiles only exist for the halo kernel (the 32-channel layers of the 1024^2 generators)
-    const int MTsel = a.M >= 128 ? 128 : ((a.M <= 32 && bf && !a.in_q && la_conv_bf16_uses_halo(a)) ? 32 : 64);
+    int MTsel = a.M >= 128 ? 128 : ((a.M <= 32 && bf && !a.in_q && la_conv_bf16_uses_halo(a)) ? 32 : 64);
+    {   // dev knob (kernel experiments only): LA_FORCE_MT=64 runs the >= 128-row layers on 64-row tiles
+        static const int force_mt = []() { const char* e = getenv("LA_FORCE_MT"); return e ? atoi(e) : 0; }();
+        if (force_mt == 64 && MTsel == 128) MTsel = 64;
+    }
     const int mtiles = la_cdiv(a.M, MTsel);
     // scratch: pre-split input first (split precisions only), split-K partials after it
     if (bf) { int rc = la_conv_prepare_input(as, stream); if (rc) return rc; }
+    // launch profiler: algorithmic work of this launch = 2*MACs; bytes = input read once + output written once (+ weights once)
+    int pslot = -1, pcls = LA_PC_CONV_F32;
+    double pflops = 0, pbytes = 0;
+    if (la_prof_enabled()) {
+        double gt = (double)a.Gy * a.Gx * a.ntaps, gout = (double)a.Gy * a.Gx, ntw = a.ntaps;
+        if (nphase > 0) {
+            gt = gout = ntw = 0.0;
+            for (int p = 0; p < nphase; ++p) { gt += (double)a.ph[p].Gy * a.ph[p].Gx * a.ph[p].ntaps; gout += (double)a.ph[p].Gy * a.ph[p].Gx; ntw += a.ph[p].ntaps; }
+        }
+        pflops = 2.0 * a.B * gt * a.M * (double)a.C;
+        pbytes = 4.0 * ((double)a.B * a.C * a.Hin * a.Win * (a.in_bstride ? 1.0 : 1.0 / a.B) + (double)a.B * a.M * gout + ntw * a.C * a.M);
+    }
     as.splitk_ws = nullptr;
     long splitk_floats = 0;
     if (as.ws && as.ws_bytes >= sizeof(float)) {
@@ -349,6 +298,7 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
             if ((long)ks * a.B * a.M * G <= splitk_floats && ks >= 2) {
                 as.ksplit = ks;
                 dim3 grid(ntiles_flat, mtiles, ks);
+                pslot = la_prof_open(bf ? LA_PC_CONV_SPLITK : LA_PC_CONV_F32, pflops, pbytes, stream);
                 if (bf) { int rc = la_conv_bf16_dispatch(as, MTsel, grid, true, stream); if (rc) return rc; }
                 else if (MTsel == 128) hipLaunchKernelGGL((la_conv_igemm_kernel<128, true>), grid, dim3(256), 0, stream, as);
                 else hipLaunchKernelGGL((la_conv_igemm_kernel<64, true>), grid, dim3(256), 0, stream, as);
@@ -359,11 +309,13 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
     }
     if (as.ksplit == 1) {
         dim3 grid(tiles, mtiles, a.B * (nphase > 0 ? nphase : 1));
+        if (bf) pcls = la_conv_bf16_uses_halo(as) ? LA_PC_CONV_HALO : LA_PC_CONV_FLAT;
+        pslot = la_prof_open(pcls, pflops, pbytes, stream);
         if (bf) { int rc = la_conv_bf16_dispatch(as, MTsel, grid, false, stream); if (rc) return rc; }
         else if (MTsel == 128) hipLaunchKernelGGL((la_conv_igemm_kernel<128, false>), grid, dim3(256), 0, stream, as);
         else hipLaunchKernelGGL((la_conv_igemm_kernel<64, false>), grid, dim3(256), 0, stream, as);
     }
     LA_CHECK_LAUNCH();
-    if (pslot >= 0) LA_HIP(hipEventRecord(g_prof.ev1[pslot], stream));
+    la_prof_close(pslot, stream);
     return LA_OK;
 }

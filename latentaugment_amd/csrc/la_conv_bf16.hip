@@ -346,7 +346,13 @@ bool la_conv_bf16_uses_halo(const LaConvArgs& a) {
 int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
     if (a.precision == LA_PREC_F32 || a.in_q) return LA_OK;
     const long HW = (long)a.Hin * a.Win;
-    if (la_conv_bf16_uses_halo(a)) return prepare_scale(a, stream);
+    // launch profiler: operand preparation = its own class (read the fp32 input once; the pre-split copy is written once)
+    struct Bracket { int slot; hipStream_t st; ~Bracket() { la_prof_close(slot, st); } };
+    if (la_conv_bf16_uses_halo(a)) {
+        Bracket br{la_prof_open(LA_PC_PRESPLIT, 0.0, a.in_pmax ? 0.0 : 4.0 * a.B * (double)a.C * HW * (a.in_bstride ? 1.0 : 1.0 / a.B), stream), stream};
+        return prepare_scale(a, stream);
+    }
+    Bracket br{la_prof_open(LA_PC_PRESPLIT, 0.0, 4.0 * a.B * (double)a.C * HW * ((a.in_bstride ? 1.0 : 1.0 / a.B) + 1.0), stream), stream};
     const size_t qb = la_conv_presplit_bytes(a.B, a.C, a.Hin, a.Win);
     LA_CHECK_ARG(a.ws && a.ws_bytes >= qb, "conv: split precisions need a workspace (la_modconv_workspace_bytes)");
     LA_CHECK_ARG(((size_t)a.ws & 15) == 0, "conv: workspace must be 16-byte aligned");

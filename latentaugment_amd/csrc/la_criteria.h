@@ -18,6 +18,11 @@ int la_latent_combine(const float* dws, const float* w, const float* colsumW, fl
                       float lat2, float mrows, hipStream_t stream);
 int la_broadcast_mix(const float* w_opt, const float* w0, float* w_aug, int B, int num_ws, int wdim, float alpha,
                      int soft, hipStream_t stream);
+// loop-engine Adam: bias corrections from a device table indexed by a device-side step counter (la_misc.hip)
+int la_adam_step_tab(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                     const float* tab, const int* ctr, hipStream_t stream);
+int la_step_advance(int* ctr, hipStream_t stream);
+void la_adam_fill_table(float* tab_host, int steps, float beta1, float beta2);
 extern "C" {
 long la_pairwise_l2_workspace_floats(int n, long m);
 int la_pairwise_l2_f32(const float* X, int n, const float* Y, long m, long K, float* D, float* mean_out,

@@ -24,3 +24,8 @@ int la_crop_repeat_f32(const float* img, float* xc, int B, int imgc, int R, int 
 int la_crop_repeat_grad_f32(const float* gxc, float* g_img, int B, int imgc, int R, int S, int y0, int x0, int rep, float scale,
                             hipStream_t stream);
 }
+// internal: window position read from device memory {y0, x0} when pos_dev != null (captured launches)
+int la_crop_repeat_ex(const float* img, float* xc, int B, int imgc, int R, int S, int y0, int x0, const int* pos_dev, int rep, float scale,
+                      float shift, hipStream_t stream);
+int la_crop_repeat_grad_ex(const float* gxc, float* g_img, int B, int imgc, int R, int S, int y0, int x0, const int* pos_dev, int rep,
+                           float scale, hipStream_t stream);

@@ -317,10 +317,13 @@ extern "C" int la_feat_backward(la_feat* h, const float* gfeat, float* gx, hipSt
 // ------------------------------------------------------------------------------------------------------------
 // criterion glue: crop (+ repeat to 3 channels, affine preprocess) and its adjoint
 //   xc[(c*B + b)][k][y][x] = img[b][c][y0+y][x0+x] * scale + shift      k = 0..rep-1
+// (pos != null: the window position {y0, x0} is read from device memory, so that a captured launch follows the position the
+//  host draws per forward)
 __global__ void la_crop_repeat_kernel(const float* __restrict__ img, float* __restrict__ xc, int B, int imgc, int R, int S, int y0,
-                                      int x0, int rep, float scale, float shift, long total) {
+                                      int x0, int rep, float scale, float shift, long total, const int* __restrict__ pos) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
+    if (pos) { y0 = pos[0]; x0 = pos[1]; }
     const int x = (int)(i % S), y = (int)((i / S) % S);
     const long rest = i / ((long)S * S);
     const long n = rest / rep;
@@ -330,9 +333,10 @@ __global__ void la_crop_repeat_kernel(const float* __restrict__ img, float* __re
 
 // g_img[b][c][y0+y][x0+x] += scale * sum_k gxc[(c*B+b)][k][y][x]
 __global__ void la_crop_repeat_bwd_kernel(const float* __restrict__ gxc, float* __restrict__ g_img, int B, int imgc, int R, int S,
-                                          int y0, int x0, int rep, float scale, long total) {
+                                          int y0, int x0, int rep, float scale, long total, const int* __restrict__ pos) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
+    if (pos) { y0 = pos[0]; x0 = pos[1]; }
     const int x = (int)(i % S), y = (int)((i / S) % S);
     const long n = i / ((long)S * S);
     const int c = (int)(n / B), b = (int)(n - (long)c * B);
@@ -341,22 +345,30 @@ __global__ void la_crop_repeat_bwd_kernel(const float* __restrict__ gxc, float* 
     g_img[(((long)b * imgc + c) * R + y0 + y) * R + x0 + x] += acc * scale;
 }
 
-extern "C" int la_crop_repeat_f32(const float* img, float* xc, int B, int imgc, int R, int S, int y0, int x0, int rep, float scale,
-                                  float shift, hipStream_t stream) {
+int la_crop_repeat_ex(const float* img, float* xc, int B, int imgc, int R, int S, int y0, int x0, const int* pos_dev, int rep, float scale,
+                      float shift, hipStream_t stream) {
     LA_CHECK_ARG(img && xc && y0 >= 0 && x0 >= 0 && y0 + S <= R && x0 + S <= R && rep >= 1, "crop_repeat: bad arguments");
     const long total = (long)B * imgc * rep * S * S;
     hipLaunchKernelGGL(la_crop_repeat_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, stream, img, xc, B, imgc, R, S, y0, x0, rep, scale,
-                       shift, total);
+                       shift, total, pos_dev);
     LA_CHECK_LAUNCH();
     return LA_OK;
 }
+extern "C" int la_crop_repeat_f32(const float* img, float* xc, int B, int imgc, int R, int S, int y0, int x0, int rep, float scale,
+                                  float shift, hipStream_t stream) {
+    return la_crop_repeat_ex(img, xc, B, imgc, R, S, y0, x0, nullptr, rep, scale, shift, stream);
+}
 
-extern "C" int la_crop_repeat_grad_f32(const float* gxc, float* g_img, int B, int imgc, int R, int S, int y0, int x0, int rep,
-                                       float scale, hipStream_t stream) {
+int la_crop_repeat_grad_ex(const float* gxc, float* g_img, int B, int imgc, int R, int S, int y0, int x0, const int* pos_dev, int rep,
+                           float scale, hipStream_t stream) {
     LA_CHECK_ARG(gxc && g_img && y0 >= 0 && x0 >= 0 && y0 + S <= R && x0 + S <= R && rep >= 1, "crop_repeat_grad: bad arguments");
     const long total = (long)B * imgc * S * S;
     hipLaunchKernelGGL(la_crop_repeat_bwd_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, stream, gxc, g_img, B, imgc, R, S, y0, x0, rep,
-                       scale, total);
+                       scale, total, pos_dev);
     LA_CHECK_LAUNCH();
     return LA_OK;
+}
+extern "C" int la_crop_repeat_grad_f32(const float* gxc, float* g_img, int B, int imgc, int R, int S, int y0, int x0, int rep,
+                                       float scale, hipStream_t stream) {
+    return la_crop_repeat_grad_ex(gxc, g_img, B, imgc, R, S, y0, x0, nullptr, rep, scale, stream);
 }

@@ -8,7 +8,8 @@ typedef struct la_opt_config {
     float lr;               // opt_lr                               (latent_aug.py:82)
     float beta1, beta2, eps;  // Adam (0.9, 0.999, 1e-8)            (util_latent_aug.py:213)
     float w_latent, w_pix, w_disc, w_lpips;   //                    (latent_aug.py:88-91)
-    int criterion_mode;     // 0: scan the banks every step (reference formulation); 1: cached bank column sums
+    int criterion_mode;     // 0 | 1, kept for ABI stability: both use bank column sums reduced once per handle for the gradient;
+                            // loss scalars (only when losses_out is given) always use the reference's GEMM form over the banks
     int soft_aug;           //                                      (latent_aug.py:94)
     float alpha;            //                                      (latent_aug.py:95)
     int loop_noise_mode;    // 1 = 'const'                          (util_latent_aug.py:227)
@@ -31,6 +32,7 @@ size_t la_latent_opt_lpips_workspace_bytes(int img_channels, int F, int S, long 
 int la_latent_opt_set_lpips(la_latent_opt* h, la_feat* f, const float* bankF, long Mf, int S, float pre_scale, float pre_shift,
                             void* ws, size_t ws_bytes);
 int la_latent_opt_set_crop_pos(la_latent_opt* h, int x, int y);
+int la_latent_opt_set_graph(la_latent_opt* h, int enable);
 int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const float* const* final_noises, float* img_out,
                       float* w_aug_out, float* losses_out, hipStream_t stream);
 }

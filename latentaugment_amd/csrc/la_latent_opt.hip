@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "la_conv.h"
 #include "la_criteria.h"
 #include "la_disc.h"
 #include "la_feat.h"
@@ -26,6 +27,18 @@ struct la_latent_opt {
     float pre_scale, pre_shift;
     float *l_xc, *l_feat, *l_gfeat, *l_gxc, *l_colsum, *l_yx, *l_yy, *l_xx;
     int l_colsum_valid;
+    // step-invariant launch sequence: device-side step counter + Adam bias-correction table + crop position, so that ONE
+    // captured step (hipGraph) is replayed for every step of every batch of the same size
+    float* adam_tab;        // device [steps][2]
+    float* adam_tab_host;   // host copy (malloc), uploaded at the head of every run
+    int* step_ctr;          // device
+    int* crop_dev;          // device {y0, x0}
+    int crop_host[2];
+    int graph_mode;         // 0 eager, 1 replay a captured step (default)
+    int graph_B;            // batch the captured step was built for (0: none)
+    hipGraph_t graph;
+    hipGraphExec_t graph_exec;
+    hipStream_t cap_stream; // capture needs a non-default stream; the replay goes to the caller's stream
 };
 
 static size_t al(size_t n) { return ((n * sizeof(float)) + 63) & ~(size_t)63; }
@@ -43,6 +56,9 @@ static size_t carve(la_latent_opt* h, char* base) {
     h->yx = take(LA_YX_FLOATS(mm ? mm : 1, B)); h->yy = take(LA_YY_FLOATS(mm ? mm : 1)); h->xx = take(LA_XX_FLOATS(B));
     h->xc = take(B * h->imgc * cc2);
     h->losses = take((size_t)(h->cfg.steps > 0 ? h->cfg.steps : 1) * 4);
+    h->adam_tab = take((size_t)(h->cfg.steps > 0 ? h->cfg.steps : 1) * 2);
+    h->step_ctr = reinterpret_cast<int*>(take(16));
+    h->crop_dev = h->step_ctr + 4;
     return off;
 }
 
@@ -73,16 +89,41 @@ extern "C" int la_latent_opt_create(la_synth* g, int img_resolution, int img_cha
     h->bankW = bankW; h->Mw = cfg->w_latent != 0.f ? Mw : 0; h->bankX = bankXc; h->Mx = cfg->w_pix != 0.f ? Mx : 0;
     const size_t need = carve(h, (char*)workspace);
     if (need > workspace_bytes) { free(h); la_set_error("latent_opt_create: workspace too small"); return LA_ERR_WORKSPACE; }
+    h->adam_tab_host = (float*)malloc(sizeof(float) * 2 * (size_t)(cfg->steps > 0 ? cfg->steps : 1));
+    if (!h->adam_tab_host) { free(h); la_set_error("latent_opt_create: out of host memory"); return LA_ERR_ARG; }
+    la_adam_fill_table(h->adam_tab_host, cfg->steps, cfg->beta1, cfg->beta2);
+    h->graph_mode = 1;
     *out = h;
     return LA_OK;
 }
 
-extern "C" void la_latent_opt_destroy(la_latent_opt* h) { free(h); }
+static void drop_graph(la_latent_opt* h) {
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    h->graph_B = 0;
+}
+
+extern "C" void la_latent_opt_destroy(la_latent_opt* h) {
+    if (!h) return;
+    drop_graph(h);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    free(h->adam_tab_host);
+    free(h);
+}
+
+// 1 (default): steps 2..N of the first batch and every step of later batches replay ONE captured step; 0: every launch eager
+extern "C" int la_latent_opt_set_graph(la_latent_opt* h, int enable) {
+    LA_CHECK_ARG(h, "latent_opt_set_graph: null handle");
+    h->graph_mode = enable ? 1 : 0;
+    if (!enable) drop_graph(h);
+    return LA_OK;
+}
 
 // attach the discriminator engine used by the w_disc criterion (required before la_latent_opt_run when w_disc != 0)
 extern "C" int la_latent_opt_set_disc(la_latent_opt* h, la_disc* d) {
     LA_CHECK_ARG(h, "latent_opt_set_disc: null handle");
     h->d = d;
+    drop_graph(h);
     return LA_OK;
 }
 
@@ -112,6 +153,7 @@ extern "C" int la_latent_opt_set_lpips(la_latent_opt* h, la_feat* f, const float
     h->l_colsum = take((size_t)h->imgc * F);
     h->l_yx = take(LA_YX_FLOATS(Mf, h->maxB)); h->l_yy = take(LA_YY_FLOATS(Mf)); h->l_xx = take(LA_XX_FLOATS(h->maxB));
     h->l_colsum_valid = 0;
+    drop_graph(h);
     return LA_OK;
 }
 
@@ -157,6 +199,10 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     LA_HIP(hipMemcpyAsync(h->w_opt, w0, nw * sizeof(float), hipMemcpyDeviceToDevice, stream));
     LA_HIP(hipMemsetAsync(h->m, 0, nw * sizeof(float), stream));
     LA_HIP(hipMemsetAsync(h->v, 0, nw * sizeof(float), stream));
+    LA_HIP(hipMemsetAsync(h->step_ctr, 0, sizeof(int), stream));
+    if (c.steps > 0) LA_HIP(hipMemcpyAsync(h->adam_tab, h->adam_tab_host, sizeof(float) * 2 * (size_t)c.steps, hipMemcpyHostToDevice, stream));
+    h->crop_host[0] = h->crop_y; h->crop_host[1] = h->crop_x;
+    LA_HIP(hipMemcpyAsync(h->crop_dev, h->crop_host, sizeof(int) * 2, hipMemcpyHostToDevice, stream));
     const bool use_disc = c.w_disc != 0.f;
     LA_CHECK_ARG(!use_disc || h->d, "latent_opt_run: w_disc != 0 but no discriminator attached (la_latent_opt_set_disc)");
     const bool use_lpips = c.w_lpips != 0.f;
@@ -164,79 +210,110 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     LA_CHECK_ARG(!use_lpips || (h->crop_x + h->S <= h->R && h->crop_y + h->S <= h->R), "latent_opt_run: LPIPS crop outside the image");
     const bool img_crit = c.w_pix != 0.f || use_disc || use_lpips;
     const float lp_coef = use_lpips ? c.w_lpips / ((float)h->imgc * (float)h->Mf * nb) : 0.f;
-    const bool want_losses = (c.criterion_mode == 0) || losses_out;
-    if (c.criterion_mode == 1 && !h->colsums_valid) {
+    // The loss SCALARS only feed the reference's log lines (:234-271); they are computed when the caller asks for them
+    // (losses_out, i.e. verbose_log).  The gradient needs the bank column sums only, and the banks are constants of the handle:
+    // reduced once (deterministic summation order, so this is bit-identical to re-reducing them every step).
+    const bool want_losses = losses_out != nullptr;
+    if (!h->colsums_valid) {
         if ((rc = refresh_colsums(h, stream))) return rc;
         h->colsums_valid = 1;
+    }
+    if (use_lpips && !h->l_colsum_valid) {
+        for (int ch = 0; ch < h->imgc; ++ch)
+            if ((rc = la_bank_colsum(h->bankF + (long)ch * h->Mf * h->F, h->Mf, h->F, h->l_colsum + (long)ch * h->F, stream))) return rc;
+        h->l_colsum_valid = 1;
     }
     if (want_losses && c.steps > 0) LA_HIP(hipMemsetAsync(h->losses, 0, (size_t)c.steps * 4 * sizeof(float), stream));
     // loss = -loss_latent - loss_pix - loss_lpips + loss_disc  (:270): the diversity terms enter with a minus sign
     const float lat_coef = h->Mw ? c.w_latent / ((float)h->Mw * nb * (float)h->num_ws * (float)wd) : 0.f;
     const float pix_coef = h->Mx ? c.w_pix / ((float)h->imgc * (float)h->Mx * nb * (float)cc2) : 0.f;
 
-    for (int step = 1; step <= c.steps; ++step) {
-        if ((rc = la_synth_forward(h->g, h->w_opt, wd, 0, B, c.loop_noise_mode, nullptr, nullptr, stream))) return rc;
+    // one optimisation step; L = this step's row of loss scalars or null.  Everything it launches is independent of the step
+    // number (the Adam bias corrections and the LPIPS window position are read from device memory), so the same launch
+    // sequence can be captured once and replayed.
+    auto run_step = [&](float* L, hipStream_t st) -> int {
+        int rc;
+        if ((rc = la_synth_forward(h->g, h->w_opt, wd, 0, B, c.loop_noise_mode, nullptr, nullptr, st))) return rc;
         const float* img = la_synth_image(h->g);
-        if (c.criterion_mode == 0 && (rc = refresh_colsums(h, stream))) return rc;
-        if (want_losses) {
-            float* L = h->losses + (size_t)(step - 1) * 4;
+        if (L) {
             if (h->Mw && (rc = la_l2_mean_from_bank(h->bankW, h->Mw, (long)h->num_ws * wd, h->w_opt, B, wd, wd, h->yx, h->yy,
-                                                    h->xx, lat_coef, L + 0, 0, stream)))
+                                                    h->xx, lat_coef, L + 0, 0, st)))
                 return rc;
             if (h->Mx) {
-                if ((rc = la_center_crop_f32(img, h->xc, (long)B * h->imgc, h->R, cc, off, stream))) return rc;
+                if ((rc = la_center_crop_f32(img, h->xc, (long)B * h->imgc, h->R, cc, off, st))) return rc;
                 for (int ch = 0; ch < h->imgc; ++ch)
                     if ((rc = la_l2_mean_from_bank(h->bankX + (long)ch * h->Mx * cc2, h->Mx, cc2, h->xc + (long)ch * cc2, B,
-                                                   (long)h->imgc * cc2, 0, h->yx, h->yy, h->xx, pix_coef, L + 1, ch > 0,
-                                                   stream)))
+                                                   (long)h->imgc * cc2, 0, h->yx, h->yy, h->xx, pix_coef, L + 1, ch > 0, st)))
                         return rc;
             }
         }
         const float* dws = nullptr;
         if (img_crit) {
             if (c.w_pix != 0.f &&
-                (rc = la_pix_grad(img, h->colsumX, h->g_img, B, h->imgc, h->R, cc, off, -2.f * pix_coef, (float)h->Mx, stream)))
+                (rc = la_pix_grad(img, h->colsumX, h->g_img, B, h->imgc, h->R, cc, off, -2.f * pix_coef, (float)h->Mx, st)))
                 return rc;
             if (use_disc) {
                 // loss_disc = softplus(-D(x)).mean() * w_disc enters the total with a plus sign (:270)
-                if ((rc = la_disc_forward(h->d, img, B, stream))) return rc;
-                if ((rc = la_disc_loss(h->d, c.w_disc, c.norm_batch, want_losses ? h->losses + (size_t)(step - 1) * 4 + 2 : nullptr, stream)))
-                    return rc;
-                if ((rc = la_disc_backward(h->d, nullptr, h->g_img, c.w_pix != 0.f, stream))) return rc;
+                if ((rc = la_disc_forward(h->d, img, B, st))) return rc;
+                if ((rc = la_disc_loss(h->d, c.w_disc, c.norm_batch, L ? L + 2 : nullptr, st))) return rc;
+                if ((rc = la_disc_backward(h->d, nullptr, h->g_img, c.w_pix != 0.f, st))) return rc;
             }
             if (use_lpips) {
                 // loss_lpips = mean_modes( sum_{m,n} |f_n - F_m|^2 / (n*m) ) * w_lpips, entering the total with a minus sign (:270)
                 const int N = h->imgc * B;
                 const long FF = h->F;
-                if (c.w_pix == 0.f && !use_disc) LA_HIP(hipMemsetAsync(h->g_img, 0, sizeof(float) * (size_t)B * h->imgc * h->R * h->R, stream));
-                if ((rc = la_crop_repeat_f32(img, h->l_xc, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, 3, h->pre_scale, h->pre_shift, stream))) return rc;
-                if ((rc = la_feat_forward(h->f, h->l_xc, N, h->l_feat, stream))) return rc;
-                if (c.criterion_mode == 0 || !h->l_colsum_valid) {
-                    for (int ch = 0; ch < h->imgc; ++ch)
-                        if ((rc = la_bank_colsum(h->bankF + (long)ch * h->Mf * FF, h->Mf, FF, h->l_colsum + (long)ch * FF, stream))) return rc;
-                    h->l_colsum_valid = 1;
-                }
-                if (want_losses) {
-                    float* L = h->losses + (size_t)(step - 1) * 4 + 3;
+                if (c.w_pix == 0.f && !use_disc) LA_HIP(hipMemsetAsync(h->g_img, 0, sizeof(float) * (size_t)B * h->imgc * h->R * h->R, st));
+                if ((rc = la_crop_repeat_ex(img, h->l_xc, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, h->crop_dev, 3, h->pre_scale, h->pre_shift, st))) return rc;
+                if ((rc = la_feat_forward(h->f, h->l_xc, N, h->l_feat, st))) return rc;
+                if (L) {
                     for (int ch = 0; ch < h->imgc; ++ch)
                         if ((rc = la_l2_mean_from_bank(h->bankF + (long)ch * h->Mf * FF, h->Mf, FF, h->l_feat + (long)ch * B * FF, B, FF, 0,
-                                                       h->l_yx, h->l_yy, h->l_xx, lp_coef, L, ch > 0, stream)))
+                                                       h->l_yx, h->l_yy, h->l_xx, lp_coef, L + 3, ch > 0, st)))
                             return rc;
                 }
                 const long total = (long)N * FF;
-                hipLaunchKernelGGL(la_lpips_gfeat_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, stream, h->l_feat, h->l_colsum, h->l_gfeat,
+                hipLaunchKernelGGL(la_lpips_gfeat_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, st, h->l_feat, h->l_colsum, h->l_gfeat,
                                    B, (int)FF, -2.f * lp_coef, (float)h->Mf, total);
-                if ((rc = la_feat_backward(h->f, h->l_gfeat, h->l_gxc, stream))) return rc;
-                if ((rc = la_crop_repeat_grad_f32(h->l_gxc, h->g_img, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, 3, h->pre_scale, stream)))
+                if ((rc = la_feat_backward(h->f, h->l_gfeat, h->l_gxc, st))) return rc;
+                if ((rc = la_crop_repeat_grad_ex(h->l_gxc, h->g_img, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, h->crop_dev, 3, h->pre_scale, st)))
                     return rc;
             }
-            if ((rc = la_synth_backward(h->g, h->g_img, h->dws, stream))) return rc;
+            if ((rc = la_synth_backward(h->g, h->g_img, h->dws, st))) return rc;
             dws = h->dws;
         }
         if ((rc = la_latent_combine(dws, h->w_opt, h->Mw ? h->colsumW : nullptr, h->dw, B, h->num_ws, wd, -2.f * lat_coef,
-                                    (float)h->Mw, stream)))
+                                    (float)h->Mw, st)))
             return rc;
-        if ((rc = la_adam_step_f32(h->w_opt, h->dw, h->m, h->v, nw, step, c.lr, c.beta1, c.beta2, c.eps, stream))) return rc;
+        if ((rc = la_adam_step_tab(h->w_opt, h->dw, h->m, h->v, nw, c.lr, c.beta1, c.beta2, c.eps, h->adam_tab, h->step_ctr, st))) return rc;
+        return la_step_advance(h->step_ctr, st);
+    };
+
+    // Replay of a captured step.  The step is captured AFTER one eager execution with the same batch size (module loading,
+    // per-device attribute opt-ins and every other first-use effect happen outside the capture).  While the launch profiler
+    // (la_prof_begin .. la_prof_end) is on, launches stay eager so that its event brackets see them.  If capture is refused the handle falls back to eager launches of the same kernels.
+    const bool replay = h->graph_mode == 1 && !want_losses && c.steps > 0 && !la_prof_enabled();
+    int first_graph_step = 1;
+    if (replay && (!h->graph_exec || h->graph_B != B)) {
+        drop_graph(h);
+        if ((rc = run_step(nullptr, stream))) return rc;          // step 1, eager
+        first_graph_step = 2;
+        bool ok = c.steps >= 2;
+        if (ok && !h->cap_stream) ok = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) == hipSuccess;
+        if (ok) {
+            ok = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+            if (ok) {
+                const int rcs = run_step(nullptr, h->cap_stream);
+                const hipError_t e = hipStreamEndCapture(h->cap_stream, &h->graph);
+                ok = rcs == LA_OK && e == hipSuccess && h->graph;
+            }
+            if (ok) ok = hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0) == hipSuccess;
+        }
+        if (ok) h->graph_B = B;
+        else { drop_graph(h); (void)hipGetLastError(); if (c.steps >= 2) h->graph_mode = 0; }
+    }
+    for (int step = first_graph_step; step <= c.steps; ++step) {
+        if (replay && h->graph_exec && h->graph_B == B) LA_HIP(hipGraphLaunch(h->graph_exec, stream));
+        else if ((rc = run_step(want_losses ? h->losses + (size_t)(step - 1) * 4 : nullptr, stream))) return rc;
     }
     if ((rc = la_broadcast_mix(h->w_opt, w0, w_aug_out, B, h->num_ws, wd, c.alpha, c.soft_aug, stream))) return rc;
     if ((rc = la_synth_forward(h->g, w_aug_out, (long)h->num_ws * wd, wd, B, c.final_noise_mode, final_noises, img_out, stream)))

@@ -109,6 +109,44 @@ __global__ void la_adam_kernel(float* __restrict__ p, const float* __restrict__ 
     p[i] = p[i] - (lr / bc1) * (mv / denom);
 }
 
+// Loop-engine variant: the bias corrections of step t = *ctr + 1 come from a device table {1 - b1^t, sqrt(1 - b2^t)} (filled by
+// the host with the same powf as la_adam_step_f32), so that one captured launch serves every step; la_step_advance bumps the
+// counter at the end of a step.
+__global__ void la_adam_tab_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                   long n, float lr, float b1, float b2, float eps, const float2* __restrict__ tab,
+                                   const int* __restrict__ ctr) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 bc = tab[*ctr];
+    const float gv = g[i];
+    const float mv = b1 * m[i] + (1.f - b1) * gv;
+    const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+    m[i] = mv; v[i] = vv;
+    const float denom = sqrtf(vv) / bc.y + eps;
+    p[i] = p[i] - (lr / bc.x) * (mv / denom);
+}
+__global__ void la_step_advance_kernel(int* ctr) { if (threadIdx.x == 0 && blockIdx.x == 0) *ctr += 1; }
+
+int la_adam_step_tab(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                     const float* tab, const int* ctr, hipStream_t stream) {
+    if (n == 0) return LA_OK;
+    hipLaunchKernelGGL(la_adam_tab_kernel, dim3(la_cdiv(n, 256)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       reinterpret_cast<const float2*>(tab), ctr);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+int la_step_advance(int* ctr, hipStream_t stream) {
+    hipLaunchKernelGGL(la_step_advance_kernel, dim3(1), dim3(64), 0, stream, ctr);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+void la_adam_fill_table(float* tab_host, int steps, float beta1, float beta2) {
+    for (int t = 1; t <= steps; ++t) {
+        tab_host[2 * (t - 1)] = 1.f - powf(beta1, (float)t);
+        tab_host[2 * (t - 1) + 1] = sqrtf(1.f - powf(beta2, (float)t));
+    }
+}
+
 extern "C" int la_adam_step_f32(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1,
                                 float beta2, float eps, hipStream_t stream) {
     LA_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "adam: bad arguments");

@@ -36,81 +36,110 @@ int la_pack_conv_weights(const float* w, float* wf, float* wb, float* wsq, int c
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// affine forward: s[b][row] = (dot(ws[b][widx_l], A_l[i]) * wgain + ab_l[i]) * post_gain_l      one wave per row
+// affine forward: s[b][row] = (dot(ws[b][widx_l], A_l[i]) * wgain + ab_l[i]) * post_gain_l
+// One wave per 4 consecutive rows (never straddling a layer: channel counts are multiples of 4), 16-byte loads: per 64-lane
+// step 4 row loads + BCH latent loads in flight (the first version: one dword row load per step, 37 us for 20 MB of rows).
 #define BCH 8
 __global__ __launch_bounds__(256) void la_affine_fwd_kernel(LaStyleTable t, const float* __restrict__ ws,
                                                            long ws_bstride, long ws_lstride, int B, int wdim,
                                                            float wgain, float* __restrict__ s_all) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
     const int lane = threadIdx.x & 63;
     if (row >= t.total_rows) return;
     int l = 0;
     while (l + 1 < t.nlayers && row >= t.row_start[l + 1]) ++l;
     const int i = row - t.row_start[l];
     const float* arow = t.aw[l] + (long)i * wdim;
-    const float ab = t.ab[l][i];
+    const int w4 = wdim >> 2;
     for (int b0 = 0; b0 < B; b0 += BCH) {
-        float acc[BCH];
+        float acc[4][BCH];
 #pragma unroll
-        for (int q = 0; q < BCH; ++q) acc[q] = 0.f;
-        for (int j = lane; j < wdim; j += 64) {
-            const float av = arow[j];
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < BCH; ++q) acc[r][q] = 0.f;
+        for (int j = lane; j < w4; j += 64) {
+            float4 av[4], wv[BCH];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) av[r] = reinterpret_cast<const float4*>(arow + (long)r * wdim)[j];
 #pragma unroll
             for (int q = 0; q < BCH; ++q)
-                if (b0 + q < B) acc[q] += av * ws[(long)(b0 + q) * ws_bstride + (long)t.widx[l] * ws_lstride + j];
+                wv[q] = b0 + q < B ? reinterpret_cast<const float4*>(ws + (long)(b0 + q) * ws_bstride + (long)t.widx[l] * ws_lstride)[j]
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < BCH; ++q)
+                    acc[r][q] += av[r].x * wv[q].x + av[r].y * wv[q].y + av[r].z * wv[q].z + av[r].w * wv[q].w;
         }
 #pragma unroll
-        for (int q = 0; q < BCH; ++q) {
-            const float v = la_wave_sum(acc[q]);
-            if (lane == 0 && b0 + q < B) s_all[(long)(b0 + q) * t.total_rows + row] = (v * wgain + ab) * t.post_gain[l];
+        for (int r = 0; r < 4; ++r) {
+            const float ab = t.ab[l][i + r];
+#pragma unroll
+            for (int q = 0; q < BCH; ++q) {
+                const float v = la_wave_sum(acc[r][q]);
+                if (lane == 0 && b0 + q < B) s_all[(long)(b0 + q) * t.total_rows + row + r] = (v * wgain + ab) * t.post_gain[l];
+            }
         }
     }
 }
 
 int la_affine_forward(const LaStyleTable& t, const float* ws, long ws_bstride, long ws_lstride, int B, int wdim,
                       float* s_all, hipStream_t stream) {
-    hipLaunchKernelGGL(la_affine_fwd_kernel, dim3(la_cdiv(t.total_rows, 4)), dim3(256), 0, stream, t, ws, ws_bstride,
+    LA_CHECK_ARG(wdim % 4 == 0 && ws_bstride % 4 == 0 && ws_lstride % 4 == 0 && ((size_t)ws & 15) == 0 && t.total_rows % 4 == 0,
+                 "affine_forward: w_dim / latent strides must be multiples of 4 floats (16-byte rows)");
+    hipLaunchKernelGGL(la_affine_fwd_kernel, dim3(la_cdiv(t.total_rows, 16)), dim3(256), 0, stream, t, ws, ws_bstride,
                        ws_lstride, B, wdim, 1.0f / sqrtf((float)wdim), s_all);
     LA_CHECK_LAUNCH();
     return LA_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// demod: d[b][doff_l + o] = rsqrt(sum_i s[b][soff_l+i]^2 * wsq_l[o][i] + 1e-8)          one wave per (l, o)
+// demod: d[b][doff_l + o] = rsqrt(sum_i s[b][soff_l+i]^2 * wsq_l[o][i] + 1e-8)     one wave per 4 rows (l, o .. o+3), 16-byte loads
 __global__ __launch_bounds__(256) void la_demod_kernel(LaDemodTable t, const float* __restrict__ s_all, int s_stride,
                                                       int B, float* __restrict__ d_all) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
     const int lane = threadIdx.x & 63;
     if (row >= t.total_rows) return;
     int l = 0;
     while (l + 1 < t.nlayers && row >= t.row_start[l + 1]) ++l;
     const int o = row - t.row_start[l];
-    const int cin = t.cin[l];
+    const int cin = t.cin[l], c4 = cin >> 2;
     const float* wrow = t.wsq[l] + (long)o * cin;
     for (int b0 = 0; b0 < B; b0 += BCH) {
-        float acc[BCH];
+        float acc[4][BCH];
 #pragma unroll
-        for (int q = 0; q < BCH; ++q) acc[q] = 0.f;
-        for (int i = lane; i < cin; i += 64) {
-            const float wv = wrow[i];
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int q = 0; q < BCH; ++q)
-                if (b0 + q < B) {
-                    const float sv = s_all[(long)(b0 + q) * s_stride + t.s_off[l] + i];
-                    acc[q] += sv * sv * wv;
-                }
+            for (int q = 0; q < BCH; ++q) acc[r][q] = 0.f;
+        for (int i = lane; i < c4; i += 64) {
+            float4 wv[4], sv[BCH];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wv[r] = reinterpret_cast<const float4*>(wrow + (long)r * cin)[i];
+#pragma unroll
+            for (int q = 0; q < BCH; ++q) {
+                sv[q] = b0 + q < B ? reinterpret_cast<const float4*>(s_all + (long)(b0 + q) * s_stride + t.s_off[l])[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                sv[q].x *= sv[q].x; sv[q].y *= sv[q].y; sv[q].z *= sv[q].z; sv[q].w *= sv[q].w;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < BCH; ++q)
+                    acc[r][q] += sv[q].x * wv[r].x + sv[q].y * wv[r].y + sv[q].z * wv[r].z + sv[q].w * wv[r].w;
         }
 #pragma unroll
-        for (int q = 0; q < BCH; ++q) {
-            const float v = la_wave_sum(acc[q]);
-            if (lane == 0 && b0 + q < B) d_all[(long)(b0 + q) * t.total_rows + row] = rsqrtf(v + 1e-8f);
-        }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < BCH; ++q) {
+                const float v = la_wave_sum(acc[r][q]);
+                if (lane == 0 && b0 + q < B) d_all[(long)(b0 + q) * t.total_rows + row + r] = rsqrtf(v + 1e-8f);
+            }
     }
 }
 
 int la_demod_forward(const LaDemodTable& t, const float* s_all, int s_stride, int B, float* d_all,
                      hipStream_t stream) {
-    hipLaunchKernelGGL(la_demod_kernel, dim3(la_cdiv(t.total_rows, 4)), dim3(256), 0, stream, t, s_all, s_stride, B,
+    LA_CHECK_ARG(t.total_rows % 4 == 0 && s_stride % 4 == 0, "demod_forward: channel counts must be multiples of 4");
+    hipLaunchKernelGGL(la_demod_kernel, dim3(la_cdiv(t.total_rows, 16)), dim3(256), 0, stream, t, s_all, s_stride, B,
                        d_all);
     LA_CHECK_LAUNCH();
     return LA_OK;
@@ -236,6 +265,9 @@ int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_st
     const long HW = (long)H * W;
     LA_CHECK_ARG(HW % 4 == 0, "torgb: H*W must be a multiple of 4");
     LA_CHECK_ARG(imgc >= 1 && imgc <= 4, "torgb: img_channels must be 1..4");
+    // launch profiler: x streamed once (+ the image-sized outputs / skip)
+    struct Bracket { int slot; hipStream_t st; ~Bracket() { la_prof_close(slot, st); } }
+        br{la_prof_open(LA_PC_TORGB, 2.0 * B * imgc * (double)C * HW, 4.0 * B * ((double)C * HW + (skip ? 3.0 : 2.0) * imgc * (double)HW), stream), stream};
     if (HW <= 4096) {
         const long nq = HW / 4;
         int px_lanes = 1;
@@ -348,9 +380,12 @@ int la_seam_backward(const LaSeamArgs& a, int B, int imgc, hipStream_t stream) {
     LA_CHECK_ARG(a.HW % 4 == 0, "seam: H*W must be a multiple of 4");
     LA_CHECK_ARG(imgc >= 0 && imgc <= 4, "seam: img_channels must be 0..4");
     dim3 grid(la_seam_slabs(a.HW), a.C, B);
+    // launch profiler: read y and the incoming gradient, write gz (+ the image-sized ToRGB operands)
+    const int pslot = la_prof_open(LA_PC_SEAM, 0.0, 4.0 * B * ((double)a.C * a.HW * (a.gx_next ? 3.0 : 2.0) + 2.0 * imgc * (double)a.HW), stream);
 #define LAUNCH(N) hipLaunchKernelGGL(la_seam_bwd_kernel<N>, grid, dim3(256), 0, stream, a)
     switch (imgc) { case 0: LAUNCH(0); break; case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
+    la_prof_close(pslot, stream);
     LA_CHECK_LAUNCH();
     return LA_OK;
 }
@@ -460,7 +495,7 @@ int la_style_backward_rgb(const float* dweff_part, int nslabs, const float* wrgb
 // affine backward: dws[b][slot][j] = wgain * sum_{l: widx_l == slot} post_gain_l * sum_i ds[b][row_l + i] * A_l[i][j]
 // stage 1: one block per 64-row chunk of a layer -> part[chunk][b][j] (thread = 2 consecutive j, coalesced A rows)
 // stage 2: per (b, slot, j): sum the chunks of the layers feeding that slot in a fixed order (deterministic).
-#define AFF_ROWS 64
+#define AFF_ROWS 16
 __device__ __forceinline__ int la_chunk_layer(const LaStyleTable& t, int chunk, int* row0) {
     int l = 0, c0 = 0;
     for (; l < t.nlayers; ++l) {
@@ -472,30 +507,65 @@ __device__ __forceinline__ int la_chunk_layer(const LaStyleTable& t, int chunk, 
     return l;
 }
 
+// part[chunk][b][j] = sum_{i in chunk} A_l[i][j] * post_gain_l * ds[b][row_start_l + i]
+// One workgroup per chunk of AFF_ROWS rows of one layer: thread = (float4 column group, row half); every thread keeps
+// AFF_ROWS / 2 independent 16-byte row loads in flight (the first version walked 64 rows with one dword load each from 150
+// workgroups: 93 us for 20 MB), the two row halves are combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void la_affine_bwd_part_kernel(LaStyleTable t, const float* __restrict__ ds_all, int B,
                                                                 int wdim, float* __restrict__ part, int nchunks) {
+    __shared__ float dsl[BCH][AFF_ROWS];
+    __shared__ float4 comb[128][BCH];
     const int chunk = blockIdx.x;
     int row0;
     const int l = la_chunk_layer(t, chunk, &row0);
     if (l >= t.nlayers) return;
     const int rows = t.row_start[l + 1] - t.row_start[l];
-    const int r1 = row0 + AFF_ROWS < rows ? row0 + AFF_ROWS : rows;
+    const int nr = row0 + AFF_ROWS < rows ? AFF_ROWS : rows - row0;
     const float pg = t.post_gain[l];
-    const float* A = t.aw[l];
+    const float* A = t.aw[l] + (long)row0 * wdim;
+    const int jq = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const int w4 = wdim >> 2;                 // (wdim % 4 == 0 is checked by the host)
     for (int b0 = blockIdx.y * BCH; b0 < B; b0 += gridDim.y * BCH) {
-        for (int j = threadIdx.x; j < wdim; j += blockDim.x) {
-            float acc[BCH];
+        __syncthreads();
+        for (int k = threadIdx.x; k < BCH * AFF_ROWS; k += 256) {
+            const int q = k / AFF_ROWS, i = k - q * AFF_ROWS;
+            dsl[q][i] = (b0 + q < B && i < nr) ? ds_all[(long)(b0 + q) * t.total_rows + t.row_start[l] + row0 + i] * pg : 0.f;
+        }
+        __syncthreads();
+        for (int j0 = 0; j0 < w4; j0 += 128) {          // (uniform trip count: the body holds barriers)
+            const int j4 = j0 + jq;
+            const bool jok = j4 < w4;
+            float4 av[AFF_ROWS / 2];
 #pragma unroll
-            for (int q = 0; q < BCH; ++q) acc[q] = 0.f;
-            for (int i = row0; i < r1; ++i) {
-                const float av = A[(long)i * wdim + j] * pg;
+            for (int r = 0; r < AFF_ROWS / 2; ++r) {
+                const int i = half * (AFF_ROWS / 2) + r;
+                av[r] = (jok && i < nr) ? reinterpret_cast<const float4*>(A + (long)i * wdim)[j4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float4 acc[BCH];
+#pragma unroll
+            for (int q = 0; q < BCH; ++q) {
+                acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int r = 0; r < AFF_ROWS / 2; ++r) {
+                    const float d = dsl[q][half * (AFF_ROWS / 2) + r];
+                    acc[q].x += av[r].x * d; acc[q].y += av[r].y * d; acc[q].z += av[r].z * d; acc[q].w += av[r].w * d;
+                }
+            }
+            if (half == 1) {
+#pragma unroll
+                for (int q = 0; q < BCH; ++q) comb[jq][q] = acc[q];
+            }
+            __syncthreads();
+            if (half == 0) {
 #pragma unroll
                 for (int q = 0; q < BCH; ++q)
-                    if (b0 + q < B) acc[q] += av * ds_all[(long)(b0 + q) * t.total_rows + t.row_start[l] + i];
+                    if (jok && b0 + q < B) {
+                        const float4 o = comb[jq][q];
+                        reinterpret_cast<float4*>(part + ((long)chunk * B + b0 + q) * wdim)[j4] =
+                            make_float4(acc[q].x + o.x, acc[q].y + o.y, acc[q].z + o.z, acc[q].w + o.w);
+                    }
             }
-#pragma unroll
-            for (int q = 0; q < BCH; ++q)
-                if (b0 + q < B) part[((long)chunk * B + b0 + q) * wdim + j] = acc[q];
+            __syncthreads();
         }
     }
 }
@@ -525,6 +595,7 @@ int la_affine_bwd_chunks(const LaStyleTable& t) {
 int la_affine_backward(const LaStyleTable& t, const float* ds_all, int B, int wdim, float* dws, int num_ws, float* part,
                        hipStream_t stream) {
     const int nchunks = la_affine_bwd_chunks(t);
+    LA_CHECK_ARG(wdim % 4 == 0 && (((size_t)part | (size_t)t.aw[0]) & 15) == 0, "affine_backward: w_dim must be a multiple of 4 (16-byte rows)");
     hipLaunchKernelGGL(la_affine_bwd_part_kernel, dim3(nchunks, la_cdiv(B, BCH)), dim3(256), 0, stream, t, ds_all, B, wdim,
                        part, nchunks);
     hipLaunchKernelGGL(la_affine_bwd_sum_kernel, dim3(la_cdiv(wdim, 256), num_ws, B), dim3(256), 0, stream, t, part, B, wdim,

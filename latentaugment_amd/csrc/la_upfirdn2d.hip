@@ -168,7 +168,16 @@ static int fir_fill(FirArgs& a, const float* in, float* out, int B, int C, int H
 
 int la_fir4x4_segments(int Hout, int Wout) { return la_cdiv(Wout, 64) * la_cdiv(Hout, 4 * FIR_ROWS); }
 
+static int fir_launch_inner(const FirArgs& a, hipStream_t stream);
 static int fir_launch(const FirArgs& a, hipStream_t stream) {
+    // launch profiler: one read of the input planes + one write of the output planes
+    const int slot = la_prof_open(LA_PC_FIR, 2.0 * a.fw * a.fh * (double)a.P * a.Hout * a.Wout,
+                                  4.0 * a.P * ((double)a.Hin * a.Win + (double)a.Hout * a.Wout), stream);
+    const int rc = fir_launch_inner(a, stream);
+    la_prof_close(slot, stream);
+    return rc;
+}
+static int fir_launch_inner(const FirArgs& a, hipStream_t stream) {
     if (a.upx == 1 && a.upy == 1 && a.dnx == 1 && a.dny == 1 && a.fw == 4 && a.fh == 4) {
         dim3 g(la_cdiv(a.Wout, 64), la_cdiv(a.Hout, 4 * FIR_ROWS), a.P < 4096 ? a.P : 4096);
         LA_CHECK_ARG(g.y <= 65535, "upfirdn2d: output too tall");

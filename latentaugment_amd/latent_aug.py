@@ -132,7 +132,16 @@ class LatentAug:
             generator = nets_['G_ema']
             if discriminator is None:
                 discriminator = nets_.get('D')
+        # per-process capacity: the whole batch, or -- with an active process group, where forward() hands this rank only its
+        # shard -- ceil(batch / world) (`opt.max_local_batch` overrides)
         max_local = self.batch_size
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+                max_local = (self.batch_size + dist.get_world_size(group) - 1) // dist.get_world_size(group)
+        except (RuntimeError, ValueError):
+            pass
+        max_local = int(getattr(opt, 'max_local_batch', 0) or max_local)
         self.engine = SynthesisEngine.from_generator(generator, self.device, max_local, precision=self.precision)
         assert self.engine.img_resolution == self.res, 'opt.img_resolution does not match the generator'
         assert self.engine.img_channels == len(self.modalities), 'one image channel per modality expected'
@@ -198,6 +207,9 @@ class LatentAug:
                                             _lib.ptr(self._workspace), self._workspace.numel(), C.byref(h)),
                    'la_latent_opt_create')
         self._h = h
+        # launch mode of the step loop: one captured step replayed (default) or every launch eager (`opt.hip_graph = False`)
+        self.hip_graph = bool(getattr(opt, 'hip_graph', True))
+        _lib.check(lib.la_latent_opt_set_graph(h, int(self.hip_graph)), 'la_latent_opt_set_graph')
         self.disc = None
         if self.w_disc > 0:
             if discriminator is None:

@@ -33,40 +33,24 @@ from oracle import sg2_ops as our_ops            # noqa: E402
 
 torch.set_num_threads(8)
 
-# (authors' criterion weights: backbone_latentaug.py:46-54)
-CONFIGS = {
-    'B': dict(res=256, channel_base=32768, batch=8, steps=20, M_w=1024, M_x=256, w_latent=0.001, w_pix=0.1, w_disc=0.0, w_lpips=0.0),
-    'C': dict(res=512, channel_base=32768, batch=4, steps=5, M_w=1024, M_x=256, w_latent=0.001, w_pix=0.1, w_disc=0.0, w_lpips=0.0),
-    'D': dict(res=1024, channel_base=32768, batch=2, steps=3, M_w=1024, M_x=64, w_latent=0.001, w_pix=0.1, w_disc=0.0, w_lpips=0.0),
-    'E': dict(res=256, channel_base=16384, batch=8, steps=5, M_w=6026, M_x=1572, w_latent=0.001, w_pix=0.1, w_disc=0.01, w_lpips=10.0),
-}
-CROP = 64
-CROP_SEED = 6
+sys.path.insert(0, os.path.dirname(HERE))
+from fullsize_common import CONFIGS, CROP, CROP_SEED, LPIPS_WIDTH, build_tensors, subsample      # noqa: E402
 
 
 def build_inputs(c):
-    """Everything both runs (and the GPU test) need, from seeds only."""
-    sd, meta = synthetic.make_generator_state_dict(img_resolution=c['res'], img_channels=2, channel_base=c['channel_base'], seed=0)
+    """The seeded tensors plus the oracle's network objects around them."""
+    sd, meta, dsd, W, X, fea, w0 = build_tensors(c)
     G = nets.Generator(img_resolution=c['res'], img_channels=2, channel_base=c['channel_base'])
     G.load_state_dict(sd, strict=False)
     G = G.eval().requires_grad_(False)
-    W, X = synthetic.make_banks(meta['num_ws'], res=c['res'], M_w=c['M_w'], M_x=c['M_x'])
-    w0 = synthetic.make_latents(c['batch'])
-    D = fnet = fea = None
-    if c['w_disc'] > 0:
-        dsd = synthetic.make_discriminator_state_dict(img_resolution=c['res'], img_channels=2, channel_base=c['channel_base'])
+    D = fnet = None
+    if dsd is not None:
         D = nets.Discriminator(img_resolution=c['res'], img_channels=2, channel_base=c['channel_base'])
-        D.load_state_dict(dsd, strict=True)
+        D.load_state_dict(dsd, strict=False)
         D = D.eval().requires_grad_(False)
-    if c['w_lpips'] > 0:
-        fnet = fnets.VGG16Features(seed=7, width=64)          # VGG16 topology at full width, random weights (vgg16.pt is a download)
-        fea = synthetic.make_feature_banks(c['M_x'], synthetic.lpips_num_features(CROP, 64))
+    if fea is not None:
+        fnet = fnets.VGG16Features(seed=7, width=LPIPS_WIDTH)     # VGG16 topology at full width, random weights (vgg16.pt is a download)
     return sd, meta, G, D, fnet, W, X, fea, w0
-
-
-def subsample(img, res):
-    st = res // 64
-    return img[:, :, st // 2::st, st // 2::st]
 
 
 def moments(img):
@@ -112,7 +96,9 @@ def run(name):
             fnet.double()
         ref = lar.LatentAugRef(G, D, W=W.double(), X=X.double(), fea=[f.double() for f in fea] if fea is not None else None,
                                feature_net=fnet, res=c['res'], num_epochs=c['steps'], opt_lr=0.01, crop_size=CROP,
-                               final_noise_mode='const', dtype=torch.float64, **kw)
+                               final_noise_mode='const', dtype=torch.float64, fused_modconv=False, **kw)
+        # (non-fused modulated conv: equal to the fused form in exact arithmetic, and the float64 CPU convolution only
+        #  parallelises over the batch dimension, which the fused form collapses to 1)
         img64, w64 = ref.forward(w0, crop_pos=tuple(crop_pos), record=True)
     finally:
         nets.COMPUTE_DTYPE = torch.float32
