@@ -72,9 +72,15 @@ struct LaConvArgs {
     const float* acc_scale_w;      // [1]
     // Merged output phases (transposed stride-2 conv, 16-bit direct kernel only): nphase > 0 runs all phases in ONE launch,
     // blockIdx.z = phase * B + sample, each phase with its own grid / output offset / tap table (<= 4 taps).  One launch of
-    // ~4x the workgroups instead of four launches that each end in a nearly empty last round.
+    // ~4x the workgroups instead of four launches that each end in a nearly empty last round.  Phase grids at the split-K sizes
+    // (<= 34x34) run the same way through the split-K kernel: blockIdx.x walks the phases' flattened-pixel tiles back to back,
+    // one finish launch serves all phases (blockIdx.z = phase).
     int nphase;
-    struct Phase { int Gy, Gx, out_oy, out_ox, ntaps; int tap_dy[LA_CONV_PHASE_TAPS], tap_dx[LA_CONV_PHASE_TAPS], tap_w[LA_CONV_PHASE_TAPS]; } ph[LA_CONV_MAX_PHASES];
+    struct Phase {
+        int Gy, Gx, out_oy, out_ox, ntaps; int tap_dy[LA_CONV_PHASE_TAPS], tap_dx[LA_CONV_PHASE_TAPS], tap_w[LA_CONV_PHASE_TAPS];
+        int tile0;           // split-K form (filled by la_conv_launch): first flattened-pixel tile of the phase on blockIdx.x ...
+        long ws_off;         // ... and the float offset of its slice partials inside splitk_ws
+    } ph[LA_CONV_MAX_PHASES];
 };
 
 long la_conv_bf16_pack_elems(int M, int C, int ktaps);   // elements per term
@@ -84,6 +90,7 @@ int la_conv_bf16_dispatch(const LaConvArgs& as, int MTsel, dim3 grid, bool split
 
 // scratch floats that let every <= 32x32 launch of a (B, M) problem use split-K: slices * B * M * G, G <= 1024
 long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx, int precision);
+long la_conv_splitk_floats_phases(int B, int M, int C, int nphase, const int* Gy, const int* Gx, int precision);
 // bytes of the pre-split copy of an input [B][C][Hin][Win] (split paths; sized for the larger, 8 B/element format)
 size_t la_conv_presplit_bytes(int B, int C, int Hin, int Win);
 // bytes of one weight pack serving every split precision
@@ -92,6 +99,8 @@ size_t la_conv_split_pack_bytes(int M, int C, int ktaps);
 // a.in_q / a.acc_scale_x at it and advance a.ws / a.ws_bytes past it.  Callers that launch several phases over one input
 // call this once.  bf16: {hi | mid << 16, lo} (8 B / element);  fp16: per-sample power-of-two scale, {hi | lo << 16} (4 B).
 int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream);
+int la_conv_xscale_from_pmax(const float* pmax, int nseg, const float* scale, int scale_stride, float mult, float* xscale, int B, int C,
+                             hipStream_t stream);
 bool la_conv_bf16_uses_halo(const LaConvArgs& a);     // fp32-input halo kernel (no pre-split copy needed)
 
 // number of pixel tiles per sample for a launch (the ds_part leading dimension)

@@ -15,18 +15,47 @@
 int la_conv_tiles_per_sample(int Gy, int Gx) { return la_cdiv((long)Gy * Gx, NT); }
 
 #define SPLITK_MAX_G 1156     // up to 34x34 grids (covers the 33x33 phases of the 32 -> 64 up-sampling layer)
-long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx, int precision) {
-    const long G = (long)Gy * Gx;
-    const int nck = la_cdiv(C, precision == LA_PREC_F32 ? KC : 32);
-    if (G > SPLITK_MAX_G || nck < 2) return 0;
-    const int mtiles = la_cdiv(M, M >= 128 ? 128 : 64);
-    const int ntiles_flat = la_cdiv((long)B * G, NT);
-    // upper bound over the slice counts la_conv_launch may choose (fp32: ceil(768 / tiles); 16-bit: cost model, <= 16)
-    int ks = la_cdiv(768, (long)ntiles_flat * mtiles);
-    if (precision != LA_PREC_F32 && ks < 16) ks = 16;
+// K slices of a split-K launch over `tiles` (flattened-pixel tiles x row tiles) workgroups.  The 16-bit kernels keep 2
+// workgroups per CU = 512 resident slots: a launch costs rounds(ks) * (1/ks + c) of one full K loop (c ~ prologue + epilogue +
+// its share of the finish kernel), so pick the slice count that minimises it -- e.g. 256 tiles -> 2 slices in one round,
+// 276 tiles -> 3 slices in two rounds.  (The fp32 kernel keeps 3 workgroups per CU: 768 slots, rounded up.)
+static int choose_ksplit(bool bf, long tiles, int nck) {
+    int ks;
+    if (bf) {
+        float best = 1e30f;
+        ks = 1;
+        for (int k = 1; k <= nck && k <= 16; ++k) {
+            const float cost = (float)la_cdiv(tiles * k, 512) * (1.f / k + 0.08f);
+            if (cost < best - 1e-6f) { best = cost; ks = k; }
+        }
+    } else {
+        ks = la_cdiv(768, tiles);
+    }
     if (ks > nck) ks = nck;
-    if (ks < 2) return 0;
-    return (long)ks * B * M * G;
+    if (ks < 2) return 1;
+    const int per = la_cdiv(nck, ks);
+    return la_cdiv(nck, per);
+}
+
+// scratch floats of the split-K form of a launch whose nphase (>= 1) output phases have the grids Gy[p] x Gx[p]; 0 if the launch
+// would not be split
+long la_conv_splitk_floats_phases(int B, int M, int C, int nphase, const int* Gy, const int* Gx, int precision) {
+    const bool bf = precision != LA_PREC_F32;
+    const int nck = la_cdiv(C, bf ? 32 : KC);
+    if (nck < 2 || nphase < 1 || (nphase > 1 && !bf)) return 0;
+    const int mtiles = la_cdiv(M, M >= 128 ? 128 : 64);
+    long tiles = 0, Gsum = 0;
+    for (int p = 0; p < nphase; ++p) {
+        const long G = (long)Gy[p] * Gx[p];
+        if (G > SPLITK_MAX_G) return 0;
+        tiles += la_cdiv((long)B * G, NT);
+        Gsum += G;
+    }
+    const int ks = choose_ksplit(bf, tiles * mtiles, nck);
+    return ks >= 2 ? (long)ks * B * M * Gsum : 0;
+}
+long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx, int precision) {
+    return la_conv_splitk_floats_phases(B, M, C, 1, &Gy, &Gx, precision);
 }
 
 // SPLIT = false: one workgroup owns a (sample, 128-pixel tile, MT-channel tile) and runs the whole K loop, epilogue fused.
@@ -159,8 +188,14 @@ __global__ __launch_bounds__(256) void la_conv_igemm_kernel(LaConvArgs a) {
 // One wave per (b, m) plane for grids below 256 positions, a whole workgroup per plane above (the kernel is pure latency:
 // a wave walking a 32x32 plane makes 16 dependent round trips).
 template <int PPB>      // planes per workgroup: 4 (one wave each) or 1
-__global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a) {
+__global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a_in) {
     __shared__ float wpart[4];
+    LaConvArgs a = a_in;
+    if (a_in.nphase > 0) {        // merged phases: blockIdx.z = phase (grid, output offset and partials of that phase)
+        const LaConvArgs::Phase& P = a_in.ph[blockIdx.z];
+        a.Gy = P.Gy; a.Gx = P.Gx; a.out_oy = P.out_oy; a.out_ox = P.out_ox;
+        a.splitk_ws = a_in.splitk_ws + P.ws_off;
+    }
     constexpr int T = 256 / PPB;                    // threads per plane
     const int lane = threadIdx.x & 63;
     const int tp = threadIdx.x % T;
@@ -234,7 +269,6 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
             LA_CHECK_ARG(P.Gy > 0 && P.Gx > 0 && P.ntaps >= 1 && P.ntaps <= LA_CONV_PHASE_TAPS, "conv: bad phase");
             LA_CHECK_ARG((P.Gy - 1) * a.out_sy + P.out_oy < a.Hout && (P.Gx - 1) * a.out_sx + P.out_ox < a.Wout && P.out_oy >= 0 && P.out_ox >= 0,
                          "conv: phase grid exceeds output tensor");
-            LA_CHECK_ARG((long)P.Gy * P.Gx > SPLITK_MAX_G, "conv: merged phases are for grids above the split-K sizes");
             const int t = la_conv_tiles_per_sample(P.Gy, P.Gx);
             if (t > tiles) tiles = t;
         }
@@ -273,37 +307,35 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
         as.splitk_ws = reinterpret_cast<float*>(as.ws);
         splitk_floats = (long)(as.ws_bytes / sizeof(float));
     }
-    if (nphase == 0 && as.splitk_ws && G <= SPLITK_MAX_G && nck >= 2) {
-        const int ntiles_flat = la_cdiv((long)a.B * G, NT);
-        // K slices: the 16-bit kernels keep 2 workgroups per CU = 512 resident slots.  A launch costs
-        // rounds(ks) * (1/ks + c) of one full K loop (c ~ prologue + epilogue + its share of the finish kernel), so pick the
-        // slice count that minimises it -- e.g. 256 tiles -> 2 slices in one round, 276 tiles -> 3 slices in two rounds.
-        // (the fp32 kernel keeps 3 workgroups per CU: 768 slots, rounded up as before)
-        int ks;
-        if (bf) {
-            const long base = (long)ntiles_flat * mtiles;
-            float best = 1e30f;
-            ks = 1;
-            for (int k = 1; k <= nck && k <= 16; ++k) {
-                const float cost = (float)la_cdiv(base * k, 512) * (1.f / k + 0.08f);
-                if (cost < best - 1e-6f) { best = cost; ks = k; }
-            }
-        } else {
-            ks = la_cdiv(768, (long)ntiles_flat * mtiles);
+    bool small = G <= SPLITK_MAX_G;
+    long Gsum = G, Gmax = G, tiles_flat = la_cdiv((long)a.B * G, NT);
+    if (nphase > 0) {
+        Gsum = 0; Gmax = 0; tiles_flat = 0;
+        for (int p = 0; p < nphase; ++p) {
+            const long Gp = (long)a.ph[p].Gy * a.ph[p].Gx;
+            small = small && Gp <= SPLITK_MAX_G;
+            Gsum += Gp; if (Gp > Gmax) Gmax = Gp;
+            as.ph[p].tile0 = (int)tiles_flat;
+            tiles_flat += la_cdiv((long)a.B * Gp, NT);
         }
-        if (ks > nck) ks = nck;
-        if (ks >= 2) {
-            const int per = la_cdiv(nck, ks);
-            ks = la_cdiv(nck, per);
-            if ((long)ks * a.B * a.M * G <= splitk_floats && ks >= 2) {
+        small = small && bf;       // (merged phases exist for the 16-bit kernels only)
+    }
+    if (as.splitk_ws && small && nck >= 2) {
+        const int ntiles_flat = (int)tiles_flat;
+        const int ks = choose_ksplit(bf, (long)ntiles_flat * mtiles, nck);
+        {
+            if ((long)ks * a.B * a.M * Gsum <= splitk_floats && ks >= 2) {
                 as.ksplit = ks;
+                long off = 0;
+                for (int p = 0; p < nphase; ++p) { as.ph[p].ws_off = off; off += (long)ks * a.B * a.M * a.ph[p].Gy * a.ph[p].Gx; }
                 dim3 grid(ntiles_flat, mtiles, ks);
                 pslot = la_prof_open(bf ? LA_PC_CONV_SPLITK : LA_PC_CONV_F32, pflops, pbytes, stream);
                 if (bf) { int rc = la_conv_bf16_dispatch(as, MTsel, grid, true, stream); if (rc) return rc; }
                 else if (MTsel == 128) hipLaunchKernelGGL((la_conv_igemm_kernel<128, true>), grid, dim3(256), 0, stream, as);
                 else hipLaunchKernelGGL((la_conv_igemm_kernel<64, true>), grid, dim3(256), 0, stream, as);
-                if (G >= 256) hipLaunchKernelGGL(la_conv_splitk_finish_kernel<1>, dim3(a.M, a.B), dim3(256), 0, stream, as);
-                else hipLaunchKernelGGL(la_conv_splitk_finish_kernel<4>, dim3(la_cdiv(a.M, 4), a.B), dim3(256), 0, stream, as);
+                const unsigned nz = nphase > 0 ? nphase : 1;
+                if (Gmax >= 256) hipLaunchKernelGGL(la_conv_splitk_finish_kernel<1>, dim3(a.M, a.B, nz), dim3(256), 0, stream, as);
+                else hipLaunchKernelGGL(la_conv_splitk_finish_kernel<4>, dim3(la_cdiv(a.M, 4), a.B, nz), dim3(256), 0, stream, as);
             }
         }
     }

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void la_xscale_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void la_xscale_pmax_kernel(const float* __restrict__ pmax, int nseg, const float* __restrict__ scale,
-                                                            int scale_stride, float* __restrict__ xscale, int C) {
+                                                            int scale_stride, float* __restrict__ xscale, int C, float mult) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     const float* pb = pmax + (long)b * C * nseg;
@@ -234,7 +234,16 @@ __global__ __launch_bounds__(256) void la_xscale_pmax_kernel(const float* __rest
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) xscale[b] = la_pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (threadIdx.x == 0) xscale[b] = la_pow2_scale(mult * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+// xscale[b] = power-of-two operand scale of a tensor bounded by mult * max_c(|scale[b][c]| * max_seg pmax[b][c][seg])
+int la_conv_xscale_from_pmax(const float* pmax, int nseg, const float* scale, int scale_stride, float mult, float* xscale, int B, int C,
+                             hipStream_t stream) {
+    LA_CHECK_ARG(pmax && xscale && nseg >= 1 && B >= 1 && C >= 1, "xscale_from_pmax: bad arguments");
+    hipLaunchKernelGGL(la_xscale_pmax_kernel, dim3(B), dim3(256), 0, stream, pmax, nseg, scale, scale_stride, xscale, C, mult);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
 }
 
 // Pre-split copy for the flat kernel, CHANNEL-INTERLEAVED: q[b][chunk][pixel][32 channels] (4 B per element fp16 {h | l<<16},
@@ -316,7 +325,7 @@ static int prepare_scale(LaConvArgs& a, hipStream_t stream) {
     ns = ns < 1 ? 1 : (ns > PM_NS ? PM_NS : ns);
     if (a.in_pmax) {      // the producer of `in` already reduced every plane: max over the sample of |style| * plane max
         hipLaunchKernelGGL(la_xscale_pmax_kernel, dim3(a.B), dim3(256), 0, stream, a.in_pmax, a.in_pmax_nseg > 0 ? a.in_pmax_nseg : 1, a.in_scale,
-                           a.scale_stride, xscale, a.C);
+                           a.scale_stride, xscale, a.C, 1.f);
     } else {
         hipLaunchKernelGGL(la_plane_absmax_kernel, dim3(ns, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,
                            a.scale_stride, pm, a.C, HW, ns);
@@ -406,9 +415,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     // merged output phases: blockIdx.z = phase * B + sample; the phase's grid, output offset and taps replace the launch-wide ones
     LaConvArgs a = a_in;
     int bz = blockIdx.z;
-    if (!SPLIT && a_in.nphase > 0) {
-        const int ph = bz / a_in.B;
-        bz -= ph * a_in.B;
+    int bx = blockIdx.x;
+    if (a_in.nphase > 0) {
+        int ph;
+        if (SPLIT) {      // split-K form: blockIdx.x walks the phases' tiles back to back, blockIdx.z stays the K slice
+            ph = 0;
+#pragma unroll
+            for (int q = 1; q < LA_CONV_MAX_PHASES; ++q)
+                if (q < a_in.nphase && bx >= a_in.ph[q].tile0) ph = q;
+            bx -= a_in.ph[ph].tile0;
+            a.splitk_ws = a_in.splitk_ws + a_in.ph[ph].ws_off;
+        } else {
+            ph = bz / a_in.B;
+            bz -= ph * a_in.B;
+        }
         a.Gy = a_in.ph[ph].Gy; a.Gx = a_in.ph[ph].Gx; a.out_oy = a_in.ph[ph].out_oy; a.out_ox = a_in.ph[ph].out_ox; a.ntaps = a_in.ph[ph].ntaps;
 #pragma unroll
         for (int t = 0; t < LA_CONV_PHASE_TAPS; ++t) { a.tap_dy[t] = a_in.ph[ph].tap_dy[t]; a.tap_dx[t] = a_in.ph[ph].tap_dx[t]; a.tap_w[t] = a_in.ph[ph].tap_w[t]; }
@@ -430,7 +450,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     const int wm = wid / WN_, wn = wid % WN_;
     // XCD-aware tile order (direct mode): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
     // run of pixel tiles -- vertically adjacent tiles (which share the +-1 row halos of the 3x3 taps) then hit the same L2.
-    int ntile = blockIdx.x;
+    int ntile = bx;
     if (!SPLIT && (gridDim.x & 7) == 0) ntile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int m0 = blockIdx.y * MT;
     const int G = a.Gy * a.Gx;

@@ -20,6 +20,12 @@ int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, con
                          const float* xin, long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
                          int res, hipStream_t stream);
 
+// gz_pmax [B][cout][gz_nseg]: partial max |gz| per plane (left by the seam kernel); with it the fp16 mode builds the contraction's
+// operand in one fused pass (FIR adjoint + scale + split + interleave)
+int la_modconv3x3_up2_bwd_ex(const float* gz, const float* gz_pmax, int gz_nseg, const float* wb, const void* wq, int precision, const float* s,
+                             int s_stride, const float* xin, long xin_bstride, const float* fir_host, float* scratch, float* gx,
+                             float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, hipStream_t stream);
+
 extern "C" {
 int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps, hipStream_t);
 int la_modconv3x3_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride, const float* d,

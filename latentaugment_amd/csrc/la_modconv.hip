@@ -70,8 +70,9 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
         int rc = la_conv_prepare_input(a, stream);
         if (rc) return rc;
     }
-    // 16-bit kernels above the split-K sizes: the four phases in ONE launch (each phase launch would end in a nearly empty round)
-    const bool merged = precision != LA_PREC_F32 && (long)hin * hin > 1156;
+    // 16-bit kernels: the four phases in ONE launch -- above the split-K sizes each phase launch would end in a nearly empty
+    // round, at the split-K sizes (<= 34x34 phase grids) four launches + four finish passes become one of each
+    const bool merged = precision != LA_PREC_F32;
     int np = 0;
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
@@ -136,12 +137,40 @@ extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const voi
     return la_modconv3x3_bwd_ex(gz, nullptr, 0, wb, wq, precision, s, s_stride, xin, xin_bstride, gx, ds_part, ws, ws_bytes, B, cin, cout, res, stream);
 }
 
-extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
-                                         long xin_bstride, const float* fir_host, float* scratch, float* gx,
-                                         float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
-                                         int res, hipStream_t stream) {
+int la_modconv3x3_up2_bwd_ex(const float* gz, const float* gz_pmax, int gz_nseg, const float* wb, const void* wq, int precision, const float* s,
+                             int s_stride, const float* xin, long xin_bstride, const float* fir_host, float* scratch, float* gx,
+                             float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, hipStream_t stream) {
     LA_CHECK_ARG(gz && wb && gx && scratch && fir_host, "modconv_up2_bwd: null pointer");
     const int hin = res / 2;
+    LaConvArgs a; base_args(a);
+    a.wgt = wb; a.out = gx;
+    a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cin, cout, 9);
+    a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = res + 1; a.Hout = a.Wout = a.Gy = a.Gx = hin;
+    a.in_sy = a.in_sx = 2; a.ntaps = 9;
+    for (int t = 0; t < 9; ++t) { a.tap_dy[t] = t / 3; a.tap_dx[t] = t % 3; a.tap_w[t] = t; }
+    a.epi = LA_EPI_BWD;
+    a.out_scale = s; a.oscale_stride = s_stride;
+    a.xin = xin; a.xin_bstride = xin_bstride;
+    a.ds_part = ds_part; a.tiles_per_sample = la_conv_tiles_per_sample(hin, hin);
+    a.in_bstride = (long)cout * (res + 1) * (res + 1);
+    const size_t qbytes = (size_t)B * la_cdiv(cout, 32) * 32 * (res + 1) * (res + 1) * 4;
+    const size_t fused_need = 512 + ((qbytes + 255) & ~(size_t)255);
+    if (precision == LA_PREC_F16X2 && gz_pmax && gz_nseg >= 1 && res % 4 == 0 && ws && ws_bytes > fused_need && (((size_t)ws | (size_t)gz) & 15) == 0) {
+        // fp16 mode with the plane maxima of gz at hand (left by the seam kernel): ONE pass turns gz into the contraction's
+        // operand -- FIR adjoint (pad 2, flipped taps, gain 4; upfirdn2d.py:255-266) + operand scale + fp16 split + channel
+        // interleave.  The scale comes from the bound |adjoint(gz)| <= 4 * sum(f) * max|gz| = 4 * max|gz| (see la_upfirdn2d.hip).
+        float* xscale = static_cast<float*>(ws);
+        unsigned* q = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + 512);
+        float fsum = 0.f;
+        for (int i = 0; i < 16; ++i) fsum += fabsf(fir_host[i]);
+        int rc = la_conv_xscale_from_pmax(gz_pmax, gz_nseg, nullptr, 0, 4.f * fsum, xscale, B, cout, stream);
+        if (rc) return rc;
+        if ((rc = la_fir4x4_adjoint_pack_f16(gz, q, xscale, B, cout, res, res, fir_host, 4.f, stream))) return rc;
+        a.in = gz;                       // (not read: the launch takes its operand from in_q)
+        a.in_q = q; a.acc_scale_x = xscale;
+        a.ws = static_cast<char*>(ws) + fused_need; a.ws_bytes = ws_bytes - fused_need;
+        return la_conv_launch(a, stream);
+    }
     // adjoint of [pad (1,1,1,1) -> FIR]: pad fw-1-pad = 2 per side, flipped filter, same gain (upfirdn2d.py:255-266)
     // (fp16 mode: the FIR kernel also leaves the plane maxima of the scratch at the head of ws, so the contraction below
     //  needs no absmax pass)
@@ -155,18 +184,17 @@ extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const
     }
     int rc = la_upfirdn2d_ex(gz, scratch, B, cout, res, res, fir_host, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, 1, 4.f, nullptr, stream, pmax);
     if (rc) return rc;
-    LaConvArgs a; base_args(a);
-    a.in = scratch; a.in_bstride = (long)cout * (res + 1) * (res + 1); a.wgt = wb; a.out = gx; a.in_pmax = pmax; a.in_pmax_nseg = nseg;
+    a.in = scratch; a.in_pmax = pmax; a.in_pmax_nseg = nseg;
     a.ws = ws; a.ws_bytes = ws_bytes;
-    a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cin, cout, 9);
-    a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = res + 1; a.Hout = a.Wout = a.Gy = a.Gx = hin;
-    a.in_sy = a.in_sx = 2; a.ntaps = 9;
-    for (int t = 0; t < 9; ++t) { a.tap_dy[t] = t / 3; a.tap_dx[t] = t % 3; a.tap_w[t] = t; }
-    a.epi = LA_EPI_BWD;
-    a.out_scale = s; a.oscale_stride = s_stride;
-    a.xin = xin; a.xin_bstride = xin_bstride;
-    a.ds_part = ds_part; a.tiles_per_sample = la_conv_tiles_per_sample(hin, hin);
     return la_conv_launch(a, stream);
+}
+
+extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,
+                                         long xin_bstride, const float* fir_host, float* scratch, float* gx,
+                                         float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
+                                         int res, hipStream_t stream) {
+    return la_modconv3x3_up2_bwd_ex(gz, nullptr, 0, wb, wq, precision, s, s_stride, xin, xin_bstride, fir_host, scratch, gx, ds_part, ws, ws_bytes,
+                                    B, cin, cout, res, stream);
 }
 
 extern "C" int la_modconv_ds_tiles(int grid_res) { return la_conv_tiles_per_sample(grid_res, grid_res); }
@@ -180,7 +208,11 @@ extern "C" size_t la_modconv_workspace_bytes(int B, int cin, int cout, int res, 
         long f, b;
         size_t qf = 0, qb = 0;
         if (up) {
-            f = la_conv_splitk_floats(B, cout, cin, hin + 1, hin + 1, prec);   // largest forward phase grid
+            if (prec == LA_PREC_F32) f = la_conv_splitk_floats(B, cout, cin, hin + 1, hin + 1, prec);   // one phase per launch
+            else {      // four phases' partials side by side
+                const int gy[4] = {hin + 1, hin + 1, hin, hin}, gx[4] = {hin + 1, hin, hin + 1, hin};
+                f = la_conv_splitk_floats_phases(B, cout, cin, 4, gy, gx, prec);
+            }
             b = la_conv_splitk_floats(B, cin, cout, hin, hin, prec);
             if (prec) { qf = la_conv_presplit_bytes(B, cin, hin, hin); qb = la_conv_presplit_bytes(B, cout, res + 1, res + 1); }
         } else {

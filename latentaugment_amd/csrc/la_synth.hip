@@ -377,11 +377,12 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
         s.noise = L0.noise_used; s.noise_bstride = L0.noise_bstride; s.noise_strength = L0.noise_strength;
         s.act = LA_ACT_LRELU; s.alpha = 0.2f; s.gain = sqrtf(2.f); s.clamp = h->clamp;
         s.ddn_part = h->ddn_part;
+        if (f16) s.pmax_out = h->pmax;      // plane maxima of gz: bound for the operand scale of the fused FIR-adjoint + split pass
         if ((rc = la_seam_backward(s, B, 0, stream))) return rc;
         {
             const int hin = res / 2;
             const int tiles = la_modconv_ds_tiles(hin);
-            if ((rc = la_modconv3x3_up2_bwd_f32(h->G1, L0.wb, L0.wqb, h->precision, h->s_all + L0.s_off, h->S, h->conv[ci - 1].y,
+            if ((rc = la_modconv3x3_up2_bwd_ex(h->G1, f16 ? h->pmax : nullptr, slabs, L0.wb, L0.wqb, h->precision, h->s_all + L0.s_off, h->S, h->conv[ci - 1].y,
                                                 (long)L0.cin * hin * hin, h->fir, h->zT, h->G0, h->ds_part, h->cws, h->cws_bytes, B, L0.cin, L0.cout,
                                                 res, stream)))
                 return rc;

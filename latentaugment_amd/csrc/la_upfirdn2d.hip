@@ -222,6 +222,119 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
     return fir_launch(a, stream);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Adjoint of the FIR that follows a transposed stride-2 conv (pad 2, flipped taps; upfirdn2d.py:255-266), writing its result
+// ALREADY in the form the stride-2 backward contraction reads: channel-interleaved [b][chunk][pixel][32 channels], each
+// element scaled by xscale[b] and split into two fp16 terms {h | l << 16}.  One pass replaces FIR adjoint + plane maxima +
+// pre-split copy (three passes over a [B][C][(2h+1)^2] tensor).
+// The power-of-two operand scale must be known before the first element is written, so it comes from a BOUND on the output,
+// |out| <= gain * sum|f| * max|in| (la_xscale_pmax with that factor), not from the output's exact maximum.  A looser scale costs
+// nothing measurable: the 2-term split keeps 22 significand bits of every element whatever the scale; only the absolute floor
+// (fp16 subnormals, 2^-24 in scaled units) moves, from <= 2^-39 to <= 2^-36 of the sample maximum for a bound 8x too large.
+// Workgroup = 8 rows x 64 columns x 32 channels; thread = 4 rows x 4 columns x 4 channels from 16-byte row loads (1.3 loads per
+// output; the plain FIR kernel issues 5.5), results transposed through LDS (16-byte slots XOR-swizzled by the pixel quad) so
+// that every store is a full 128-byte [pixel][32 channels] line.
+struct FirPackArgs {
+    const float* in;       // [B][C][H][W], W % 4 == 0, 16-byte aligned planes
+    unsigned* out;         // [B][nck][Hz*Wz][32]
+    const float* xscale;   // [B]
+    int B, C, H, W, Hz, Wz, nck, pad;
+    float f[16];           // effective correlation taps (flip and gain folded in)
+};
+
+__global__ __launch_bounds__(256) void la_fir4x4_adj_pack_kernel(FirPackArgs a) {
+    __shared__ uint4 tile[512 * 8];                       // [8 rows x 64 cols][8 slots of 4 channels]
+    const int tid = threadIdx.x;
+    const int xg = tid & 15, rs = (tid >> 4) & 1, cg = tid >> 5;
+    const int b = blockIdx.z / a.nck, ck = blockIdx.z - b * a.nck;
+    const int Xb = blockIdx.x * 64, Yb = blockIdx.y * 8;
+    const int X0 = Xb + xg * 4, Y0 = Yb + rs * 4;
+    const float xs = a.xscale[b];
+    unsigned pk[4][4][4];                                 // [row][col][channel of the group]
+    const bool lo_ok = X0 - 4 >= 0, mid_ok = X0 < a.W, hi_ok = X0 + 4 < a.W;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = ck * 32 + cg * 4 + j;
+        float acc[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
+        if (c < a.C) {
+            const float* ip = a.in + ((long)b * a.C + c) * a.H * a.W;
+#pragma unroll
+            for (int wr = 0; wr < 7; ++wr) {
+                const int iy = Y0 - a.pad + wr;
+                float v[8];                               // v[t] = in[iy][X0 - 2 + t], t = 0..6
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = 0.f;
+                if (iy >= 0 && iy < a.H) {
+                    const float* rp = ip + (long)iy * a.W;
+                    if (lo_ok) { const float4 q = *reinterpret_cast<const float4*>(rp + X0 - 4); v[0] = q.z; v[1] = q.w; }
+                    if (mid_ok) { const float4 q = *reinterpret_cast<const float4*>(rp + X0); v[2] = q.x; v[3] = q.y; v[4] = q.z; v[5] = q.w; }
+                    if (hi_ok) v[6] = rp[X0 + 4];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ta = wr - r;
+                    if (ta >= 0 && ta < 4) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int tb = 0; tb < 4; ++tb) acc[r][k] += v[k + tb] * a.f[ta * 4 + tb];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float s = acc[r][k] * xs;
+                const _Float16 h = (_Float16)s;
+                const _Float16 l = (_Float16)(s - (float)h);
+                pk[r][k][j] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pl = (rs * 4 + r) * 64 + xg * 4 + k;
+            tile[pl * 8 + (cg ^ ((pl >> 2) & 7))] = make_uint4(pk[r][k][0], pk[r][k][1], pk[r][k][2], pk[r][k][3]);
+        }
+    __syncthreads();
+    const long plane = (long)a.Hz * a.Wz;
+    uint4* op = reinterpret_cast<uint4*>(a.out) + ((long)b * a.nck + ck) * plane * 8;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int idx = it * 256 + tid;
+        const int pl = idx >> 3, slot = idx & 7;
+        const int Y = Yb + (pl >> 6), X = Xb + (pl & 63);
+        if (Y < a.Hz && X < a.Wz) op[((long)Y * a.Wz + X) * 8 + (slot ^ ((pl >> 2) & 7))] = tile[idx];
+    }
+}
+
+// in [B][C][H][W] -> q [B][ceil(C/32)][(H+1)*(W+1)][32] packed fp16 pairs of  xscale[b] * (FIR adjoint of `in`)
+int la_fir4x4_adjoint_pack_f16(const float* in, unsigned* q, const float* xscale, int B, int C, int H, int W, const float* f_host,
+                               float gain, hipStream_t stream) {
+    LA_CHECK_ARG(in && q && xscale && f_host, "fir_adjoint_pack: null pointer");
+    LA_CHECK_ARG(W % 4 == 0 && (((size_t)in | (size_t)q) & 15) == 0, "fir_adjoint_pack: rows must be 16-byte aligned");
+    FirPackArgs a;
+    a.in = in; a.out = q; a.xscale = xscale; a.B = B; a.C = C; a.H = H; a.W = W; a.Hz = H + 1; a.Wz = W + 1; a.nck = la_cdiv(C, 32);
+    a.pad = 2;         // adjoint of pad (1,1,1,1): fw - 1 - pad = 2 per side (upfirdn2d.py:255-266)
+    // adjoint = correlation with the flipped filter = flip_filter of the forward op negated; the forward (flip_filter = False)
+    // correlates with the flipped taps, so the adjoint correlates with the taps as given
+    for (int i = 0; i < 16; ++i) a.f[i] = gain * f_host[i];
+    dim3 grid(la_cdiv(a.Wz, 64), la_cdiv(a.Hz, 8), B * a.nck);
+    LA_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "fir_adjoint_pack: grid too large");
+    const int slot = la_prof_open(LA_PC_FIR, 32.0 * B * C * (double)a.Hz * a.Wz, 4.0 * B * C * ((double)H * W + (double)a.Hz * a.Wz), stream);
+    hipLaunchKernelGGL(la_fir4x4_adj_pack_kernel, grid, dim3(256), 0, stream, a);
+    la_prof_close(slot, stream);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
 extern "C" int la_upfirdn2d_out_size(int in_size, int up, int down, int pad0, int pad1, int taps) {
     return (in_size * up + pad0 + pad1 - taps + down) / down;
 }
