@@ -64,6 +64,16 @@ __device__ __forceinline__ float la_block_sum_256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// power-of-two operand scale of the fp16 split (la_conv_bf16.hip): brings a tensor's max magnitude into [2^14, 2^15)
+__device__ __forceinline__ float la_pow2_scale(float amax) {
+    if (!(amax > 0.f) || !isfinite(amax)) return 1.f;
+    int e;
+    frexpf(amax, &e);                    // amax = f * 2^e, f in [0.5, 1)
+    int s = 15 - e;                      // scaled max in [2^14, 2^15): fp16 never overflows, 3 more bits above the subnormals
+    s = s > 100 ? 100 : (s < -100 ? -100 : s);
+    return ldexpf(1.f, s);
+}
+
 // activation ids follow the reference's cuda_idx (bias_act.py:20-30): 1 linear, 2 relu, 3 lrelu
 #define LA_ACT_LINEAR 1
 #define LA_ACT_RELU 2

@@ -101,6 +101,7 @@ size_t la_conv_split_pack_bytes(int M, int C, int ktaps);
 int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream);
 int la_conv_xscale_from_pmax(const float* pmax, int nseg, const float* scale, int scale_stride, float mult, float* xscale, int B, int C,
                              hipStream_t stream);
+int la_absmax_bits(const float* w, long n, unsigned* amax_bits, hipStream_t stream);      // max |w| as a float bit pattern (zero it first)
 bool la_conv_bf16_uses_halo(const LaConvArgs& a);     // fp32-input halo kernel (no pre-split copy needed)
 
 // number of pixel tiles per sample for a launch (the ds_part leading dimension)

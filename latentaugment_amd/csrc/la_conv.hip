@@ -15,22 +15,31 @@
 int la_conv_tiles_per_sample(int Gy, int Gx) { return la_cdiv((long)Gy * Gx, NT); }
 
 #define SPLITK_MAX_G 1156     // up to 34x34 grids (covers the 33x33 phases of the 32 -> 64 up-sampling layer)
-// K slices of a split-K launch over `tiles` (flattened-pixel tiles x row tiles) workgroups.  The 16-bit kernels keep 2
-// workgroups per CU = 512 resident slots: a launch costs rounds(ks) * (1/ks + c) of one full K loop (c ~ prologue + epilogue +
-// its share of the finish kernel), so pick the slice count that minimises it -- e.g. 256 tiles -> 2 slices in one round,
-// 276 tiles -> 3 slices in two rounds.  (The fp32 kernel keeps 3 workgroups per CU: 768 slots, rounded up.)
-static int choose_ksplit(bool bf, long tiles, int nck) {
+// K slices of a split-K launch over `tiles` (flattened-pixel tiles x row tiles) workgroups, each walking nck chunks x `taps`
+// (chunk, tap) steps.  The 16-bit kernels keep 2 workgroups per CU = 512 resident slots.  Cost model in microseconds, fitted to
+// the kernel trace of the config-f generator (profiles/): a step costs ~1.7 us of a resident slot, a workgroup ~10 us of
+// prologue + epilogue, and slicing adds a finish pass that reads ks partial copies of the output and writes it once at
+// ~3.5 TB/s (+5 us of launch).  E.g. 256 tiles x 144 steps -> 2 slices; the 4 merged 33x33 phases of the 32 -> 64 layer
+// (1060 tiles x 36 steps, 69 MB of output) -> no slices: their finish pass would cost more than the tail it removes.
+// (The fp32 kernel keeps 3 workgroups per CU: 768 slots, rounded up as before.)
+static int choose_ksplit(bool bf, long tiles, int nck, float taps, double out_bytes) {
     int ks;
     if (bf) {
         float best = 1e30f;
         ks = 1;
         for (int k = 1; k <= nck && k <= 16; ++k) {
-            const float cost = (float)la_cdiv(tiles * k, 512) * (1.f / k + 0.08f);
-            if (cost < best - 1e-6f) { best = cost; ks = k; }
+            const int per = la_cdiv(nck, k);
+            const int kk = la_cdiv(nck, per);                       // slices actually launched
+            if (kk != k) continue;
+            const float slots = (float)(tiles * kk) / 512.f;
+            const float rounds = slots <= 1.f ? 1.f : slots;          // (dynamic dispatch: beyond one round, work / slots)
+            float cost = rounds * ((float)per * taps * 1.7f + 10.f);
+            if (kk > 1) cost += 5.f + (float)((kk + 1) * out_bytes / 3.5e6);
+            if (cost < best - 1e-3f) { best = cost; ks = kk; }
         }
-    } else {
-        ks = la_cdiv(768, tiles);
+        return ks;
     }
+    ks = la_cdiv(768, tiles);
     if (ks > nck) ks = nck;
     if (ks < 2) return 1;
     const int per = la_cdiv(nck, ks);
@@ -51,7 +60,11 @@ long la_conv_splitk_floats_phases(int B, int M, int C, int nphase, const int* Gy
         tiles += la_cdiv((long)B * G, NT);
         Gsum += G;
     }
-    const int ks = choose_ksplit(bf, tiles * mtiles, nck);
+    // (upper bound over the tap counts a launch of these grids may have: fewer taps never ask for more slices ... except that
+    //  cheaper steps favour fewer slices; size for the densest case, 9 taps, and for the 9/4 of transposed-conv phases)
+    int ks = choose_ksplit(bf, tiles * mtiles, nck, nphase > 1 ? 2.25f : 9.f, 4.0 * B * M * (double)Gsum);
+    const int ks1 = choose_ksplit(bf, tiles * mtiles, nck, 1.f, 4.0 * B * M * (double)Gsum);
+    if (ks1 > ks) ks = ks1;
     return ks >= 2 ? (long)ks * B * M * Gsum : 0;
 }
 long la_conv_splitk_floats(int B, int M, int C, int Gy, int Gx, int precision) {
@@ -322,7 +335,9 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
     }
     if (as.splitk_ws && small && nck >= 2) {
         const int ntiles_flat = (int)tiles_flat;
-        const int ks = choose_ksplit(bf, (long)ntiles_flat * mtiles, nck);
+        float taps = (float)a.ntaps;
+        if (nphase > 0) { taps = 0.f; for (int p = 0; p < nphase; ++p) taps += (float)a.ph[p].ntaps * ((float)a.ph[p].Gy * a.ph[p].Gx / (float)Gsum); }
+        const int ks = choose_ksplit(bf, (long)ntiles_flat * mtiles, nck, taps, 4.0 * a.B * a.M * (double)Gsum);
         {
             if ((long)ks * a.B * a.M * Gsum <= splitk_floats && ks >= 2) {
                 as.ksplit = ks;

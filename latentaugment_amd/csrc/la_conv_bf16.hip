@@ -87,6 +87,8 @@ __global__ void la_pack_bf16_kernel(const float* __restrict__ w, __bf16* __restr
     }
 }
 
+// max |w| of a tensor into *amax_bits as a float bit pattern (the caller zeroes it first)
+int la_absmax_bits(const float* w, long n, unsigned* amax_bits, hipStream_t stream);
 long la_conv_bf16_pack_elems(int M, int C, int ktaps) { return (long)ktaps * la_cdiv(C, KCB) * pack_mp(M) * KCB; }
 
 // pack layout: [3 bf16 terms][2 fp16 terms][pad to 16 B][wscale float]
@@ -108,14 +110,11 @@ __global__ void la_absmax_kernel(const float* __restrict__ w, long n, float scal
     if (threadIdx.x == 0) atomicMax(amax_bits, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
-// power-of-two scale that brings a tensor's max magnitude to ~2^12 (fp16 max is 2^16; products accumulate in fp32)
-__device__ __forceinline__ float la_pow2_scale(float amax) {
-    if (!(amax > 0.f) || !isfinite(amax)) return 1.f;
-    int e;
-    frexpf(amax, &e);                    // amax = f * 2^e, f in [0.5, 1)
-    int s = 15 - e;                      // scaled max in [2^14, 2^15): fp16 never overflows, 3 more bits above the subnormals
-    s = s > 100 ? 100 : (s < -100 ? -100 : s);
-    return ldexpf(1.f, s);
+int la_absmax_bits(const float* w, long n, unsigned* amax_bits, hipStream_t stream) {
+    long b2 = la_cdiv(n, 256); if (b2 > 1024) b2 = 1024;
+    hipLaunchKernelGGL(la_absmax_kernel, dim3((unsigned)b2), dim3(256), 0, stream, w, n, 1.f, amax_bits);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
 }
 
 __global__ void la_pack_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, const unsigned* __restrict__ amax_bits,
@@ -312,7 +311,7 @@ size_t la_conv_presplit_bytes(int B, int C, int Hin, int Win) {      // channel-
 
 // fp16 path: per-sample operand scale (segment maxima -> xscale[b]) in the header of the workspace; advances a.ws past it
 static int prepare_scale(LaConvArgs& a, hipStream_t stream) {
-    if (a.precision != LA_PREC_F16X2) return LA_OK;
+    if (a.precision != LA_PREC_F16X2 || a.acc_scale_x) return LA_OK;      // (a preset scale: e.g. from the clamp bound of the producer)
     const long HW = (long)a.Hin * a.Win;
     const size_t hb = presplit_hdr_bytes(a.B, a.C);
     LA_CHECK_ARG(a.ws && a.ws_bytes >= hb, "conv: split precisions need a workspace (la_modconv_workspace_bytes)");

@@ -24,9 +24,10 @@ extern "C" int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, fl
 int la_modconv3x3_fwd_ex(const float* x, long x_bstride, const float* in_pmax, int in_nseg, const float* wf, const void* wq, int precision, const float* s,
                          int s_stride, const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                          const float* bias, int act, float alpha, float gain, float clamp, float* y, void* ws, size_t ws_bytes, int B,
-                         int cin, int cout, int res, hipStream_t stream) {
+                         int cin, int cout, int res, hipStream_t stream, const float* xscale) {
     LA_CHECK_ARG(x && wf && y, "modconv_fwd: null pointer");
     LaConvArgs a; base_args(a);
+    if (precision == LA_PREC_F16X2) a.acc_scale_x = xscale;      // preset operand scale (bound-based): no absmax / plane-maxima pass
     a.in = x; a.in_bstride = x_bstride; a.wgt = wf; a.out = y; a.in_pmax = in_pmax; a.in_pmax_nseg = in_nseg;
     a.in_scale = s; a.scale_stride = s_stride;
     a.ws = ws; a.ws_bytes = ws_bytes;
@@ -53,7 +54,7 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
                              const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                              const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
                              float* scratch, float* y, float* y_pmax, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
-                             hipStream_t stream) {
+                             hipStream_t stream, const float* xscale) {
     LA_CHECK_ARG(x && wf && y && scratch && fir_host, "modconv_up2_fwd: null pointer");
     LA_CHECK_ARG(res >= 2 && res % 2 == 0, "modconv_up2_fwd: output resolution must be even");
     // transposed stride-2 conv as 4 output phases: row Y = 2*qy + py receives taps ky with (Y - ky) even
@@ -65,6 +66,7 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
     a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cout, cin, 9);
     a.B = B; a.C = cin; a.M = cout; a.Hin = a.Win = hin; a.Hout = a.Wout = res + 1;
     a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW;
+    if (precision == LA_PREC_F16X2) a.acc_scale_x = xscale;      // preset operand scale (bound-based): no absmax pass
     if (precision != LA_PREC_F32) {
         // split the (modulated) input once for the four phase launches
         int rc = la_conv_prepare_input(a, stream);

@@ -49,6 +49,8 @@ int la_pack_conv_weights(const float* w, float* wf, float* wb, float* wsq, int c
                          float scale = 1.f, int wb_ld = 0);   // wb_ld > cin: backward slab rows padded with zero columns
 int la_affine_forward(const LaStyleTable& t, const float* ws, long ws_bstride, long ws_lstride, int B, int wdim,
                       float* s_all, hipStream_t);
+// xs[l][b] = power-of-two fp16 operand scale of conv layer l's forward contraction from the bound  bound[l] * max_i |s[b][i]|
+int la_xscale_from_bounds(const LaDemodTable& t, const float* s_all, int s_stride, const float* bound, float* xs, int B, hipStream_t);
 int la_demod_forward(const LaDemodTable& t, const float* s_all, int s_stride, int B, float* d_all, hipStream_t);
 int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_stride, const float* bias,
                      const float* skip, float* rgb_pre, float* img, int B, int C, int imgc, int H, int W, float clamp,

@@ -146,6 +146,31 @@ int la_demod_forward(const LaDemodTable& t, const float* s_all, int s_stride, in
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// fp16 operand scales of the FORWARD contractions of every conv layer in one launch: the input of layer l is the clamped output
+// of layer l-1 (|x| <= conv_clamp; layer 0: the constant input, |x| <= max|const|), so  |x * s| <= bound_l * max_i |s[b][i]|
+// is known as soon as the styles are -- no pass over the activations (plane maxima / absmax kernels) is needed.  A bound
+// instead of the exact maximum only moves the absolute floor of the 2-term fp16 split (see la_upfirdn2d.hip).
+__global__ __launch_bounds__(256) void la_xscale_bound_kernel(LaDemodTable t, const float* __restrict__ s_all, int s_stride,
+                                                             const float* __restrict__ bound, float* __restrict__ xs, int B) {
+    __shared__ float red[4];
+    const int l = blockIdx.x, b = blockIdx.y;
+    const float* sp = s_all + (long)b * s_stride + t.s_off[l];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < t.cin[l]; i += 256) m = fmaxf(m, fabsf(sp[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) xs[(long)l * B + b] = la_pow2_scale(bound[l] * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+int la_xscale_from_bounds(const LaDemodTable& t, const float* s_all, int s_stride, const float* bound, float* xs, int B, hipStream_t stream) {
+    hipLaunchKernelGGL(la_xscale_bound_kernel, dim3(t.nlayers, B), dim3(256), 0, stream, t, s_all, s_stride, bound, xs, B);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // ToRGB forward (+ skip add):  rgb_pre[b][c][p] = sum_i wrgb[c][i] * s[b][i] * x[b][i][p] + bias[c]
 //                              img[b][c][p]     = clamp(rgb_pre) + (skip ? skip[b][c][p] : 0)
 // Streams x once (HBM-bound); lanes = consecutive pixels, 4 pixels per thread (float4).

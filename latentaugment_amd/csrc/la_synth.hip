@@ -51,6 +51,8 @@ struct la_synth {
     void* cws;
     size_t cws_bytes;
     float* pmax;             // [maxB][max channels]: plane maxima handed from a producing kernel to the next contraction (fp16 mode)
+    float* xs_fwd;           // [nconv][B]: fp16 operand scales of the forward contractions (from the clamp bound, one launch per pass)
+    float* xs_bound;         // [nconv]: bound on |input| of conv layer k: max|const| for the first, conv_clamp for the rest
     int lastB;
     int precision;
     float* final_img;   // where the last forward put the full-resolution image
@@ -127,6 +129,8 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
         }
         h->pmax = c.take(mb * pmx);
     }
+    h->xs_fwd = c.take((size_t)h->nconv * mb);
+    h->xs_bound = c.take((size_t)h->nconv + 16);
     *need = c.off;
     return LA_OK;
 }
@@ -242,6 +246,15 @@ extern "C" int la_synth_create(int img_resolution, int img_channels, int w_dim, 
         T.affine_w = params[p++]; T.affine_b = params[p++]; T.weight = params[p++]; T.bias = params[p++];
         h->st.aw[T.style_idx] = T.affine_w; h->st.ab[T.style_idx] = T.affine_b;
     }
+    {   // input bounds of the forward contractions: |const| <= its maximum (reduced once, here), every later layer's input is a
+        // clamped layer output (|y| <= conv_clamp).  Without a clamp the data-dependent scale path is used instead.
+        float hb[2 * MAX_BLOCKS];
+        for (int k = 0; k < h->nconv; ++k) hb[k] = h->clamp > 0.f ? h->clamp : 0.f;
+        LA_HIP(hipMemcpyAsync(h->xs_bound, hb, sizeof(float) * h->nconv, hipMemcpyHostToDevice, stream));
+        LA_HIP(hipMemsetAsync(h->xs_bound, 0, sizeof(float), stream));
+        if ((rc = la_absmax_bits(h->cst, (long)h->channels[0] * 16, reinterpret_cast<unsigned*>(h->xs_bound), stream))) { free(h); return rc; }
+        LA_HIP(hipStreamSynchronize(stream));      // (hb is a stack buffer)
+    }
     h->lastB = 0;
     *out = h;
     return LA_OK;
@@ -274,10 +287,12 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
     if ((rc = la_affine_forward(h->st, ws, ws_bstride, ws_lstride, B, h->wdim, h->s_all, stream))) return rc;
     if ((rc = la_demod_forward(h->dt, h->s_all, h->S, B, h->d_all, stream))) return rc;
     h->lastB = B;
+    const bool f16 = h->precision == LA_PREC_F16X2;
+    const bool bound_scale = f16 && h->clamp > 0.f;
+    if (bound_scale && (rc = la_xscale_from_bounds(h->dt, h->s_all, h->S, h->xs_bound, h->xs_fwd, B, stream))) return rc;
     int ci = 0;
     const float* x = h->cst;
     long x_bstride = 0;
-    const bool f16 = h->precision == LA_PREC_F16X2;
     const float* x_pmax = nullptr;      // plane maxima of x when its producer (the FIR epilogue of an up-sampling layer) left them
     int x_nseg = 0;
     for (int k = 0; k < h->nblocks; ++k) {
@@ -294,14 +309,14 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
             if (!L.up) {
                 rc = la_modconv3x3_fwd_ex(x, x_bstride, x_pmax, x_nseg, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                           L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f, sq2,
-                                          h->clamp, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream);
+                                          h->clamp, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream, bound_scale ? h->xs_fwd + (long)ci * B : nullptr);
                 x_pmax = nullptr;
             } else {
                 rc = la_modconv3x3_up2_fwd_ex(x, x_bstride, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                               L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f,
-                                              sq2, h->clamp, h->fir, h->zT, L.y, f16 ? h->pmax : nullptr, h->cws, h->cws_bytes, B, L.cin,
-                                              L.cout, res, stream);
-                x_pmax = f16 ? h->pmax : nullptr;
+                                              sq2, h->clamp, h->fir, h->zT, L.y, (f16 && !bound_scale) ? h->pmax : nullptr, h->cws, h->cws_bytes, B, L.cin,
+                                              L.cout, res, stream, bound_scale ? h->xs_fwd + (long)ci * B : nullptr);
+                x_pmax = (f16 && !bound_scale) ? h->pmax : nullptr;
                 x_nseg = la_fir4x4_segments(res, res);
             }
             if (rc) return rc;
