@@ -54,6 +54,17 @@ struct LaConvArgs {
     long xin_bstride;
     float* ds_part;          // [B][M][tiles_per_sample]
     int tiles_per_sample;
+    // LA_EPI_BWD with seam_ddn_part != null (16-bit kernels and the split-K finish pass only): the backward "seam" of the layer
+    // that PRODUCED xin is applied to the outgoing gradient in the same epilogue -- xin is that layer's saved output y, which the
+    // epilogue loads anyway for ds_part -- instead of a separate pass over y and the gradient (la_seam_bwd_kernel<0>):
+    //   g = acc * out_scale;  g1 = g * act'(y);  seam_ddn_part[b][m][tile] = sum_px g1 * (act^-1(y) - seam_bias[m] - noise*strength);
+    //   out = g1 * seam_demod[b][m];  seam_pmax[b][m][tile] = max_px |out|   (plane maxima for the next contraction's operand scale)
+    const float* seam_demod; int seam_demod_stride;
+    const float* seam_bias;
+    const float* seam_noise; long seam_noise_bstride; float seam_noise_strength;
+    int seam_act; float seam_alpha, seam_gain, seam_clamp;
+    float* seam_ddn_part;    // [B][M][tiles_per_sample]
+    float* seam_pmax;        // [B][M][tiles_per_sample] or null
     // optional caller-provided scratch (la_conv_workspace_bytes): [fp16 scale header | pre-split input | split-K slice partials]
     void* ws;
     size_t ws_bytes;

@@ -225,7 +225,11 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
     const float bv = (a.epi == LA_EPI_FWD && a.bias) ? a.bias[m] : 0.f;
     const float sc = (a.epi == LA_EPI_BWD && a.out_scale) ? a.out_scale[(long)b * a.oscale_stride + m] : 1.f;
     const float* xin_p = (a.epi == LA_EPI_BWD && a.xin) ? a.xin + (long)b * a.xin_bstride + (long)m * HWout : nullptr;
-    float part = 0.f;
+    // fused seam of the layer that produced xin (LaConvArgs::seam_*): same arithmetic as the direct kernels' epilogue
+    const bool seam = a.epi == LA_EPI_BWD && a.seam_ddn_part != nullptr && xin_p != nullptr;
+    const float dm0 = (seam && a.seam_demod) ? a.seam_demod[(long)b * a.seam_demod_stride + m] : 1.f;
+    const float b0 = (seam && a.seam_bias) ? a.seam_bias[m] : 0.f;
+    float part = 0.f, dd = 0.f, mx = 0.f;
     for (int g = tp; g < G; g += T) {
         float v = 0.f;
         for (int k = 0; k < a.ksplit; ++k) v += wsp[(long)k * slice + g];
@@ -239,19 +243,40 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
                 a.out2[o2] = v + (a.addend ? a.addend[o2] : 0.f);
             }
         } else if (a.epi == LA_EPI_BWD) {
-            if (xin_p) part += v * xin_p[pos];
+            const float y = xin_p ? xin_p[pos] : 0.f;
+            part += v * y;
             v *= sc;
+            if (seam) {
+                const float nz0 = a.seam_noise ? a.seam_noise[(long)b * a.seam_noise_bstride + pos] * a.seam_noise_strength : 0.f;
+                const float g1 = v * la_act_bwd_from_y(y, a.seam_act, a.seam_alpha, a.seam_gain, a.seam_clamp);
+                dd += g1 * (la_act_inv(y, a.seam_act, a.seam_alpha, a.seam_gain) - b0 - nz0);
+                v = g1 * dm0;
+                mx = fmaxf(mx, fabsf(v));
+            }
         }
         out_p[pos] = v;
     }
-    if (a.epi == LA_EPI_BWD && a.ds_part) {
+    if (a.epi == LA_EPI_BWD && (a.ds_part || seam)) {
         part = la_wave_sum(part);
+        dd = la_wave_sum(dd);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         if (PPB == 1) {
-            if (lane == 0) wpart[threadIdx.x >> 6] = part;
+            __shared__ float wdd[4], wmx[4];
+            if (lane == 0) { wpart[threadIdx.x >> 6] = part; wdd[threadIdx.x >> 6] = dd; wmx[threadIdx.x >> 6] = mx; }
             __syncthreads();
             part = (wpart[0] + wpart[1]) + (wpart[2] + wpart[3]);
+            dd = (wdd[0] + wdd[1]) + (wdd[2] + wdd[3]);
+            mx = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
         }
-        if (tp < a.tiles_per_sample) a.ds_part[((long)b * a.M + m) * a.tiles_per_sample + tp] = tp == 0 ? part : 0.f;
+        if (tp < a.tiles_per_sample) {
+            const long slot = ((long)b * a.M + m) * a.tiles_per_sample + tp;
+            if (a.ds_part) a.ds_part[slot] = tp == 0 ? part : 0.f;
+            if (seam) {
+                a.seam_ddn_part[slot] = tp == 0 ? dd : 0.f;
+                if (a.seam_pmax) a.seam_pmax[slot] = tp == 0 ? mx : 0.f;
+            }
+        }
     }
 }
 

@@ -72,6 +72,27 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
             const float* os_b = a.out_scale ? a.out_scale + (long)b * a.oscale_stride : nullptr;
             if (tid < MT) prm[tid] = os_b ? os_b[m0 + tid] : 1.f;
             const float* x0 = a.xin ? a.xin + (long)b * a.xin_bstride + (long)(m0 + mw) * HWo : nullptr;
+            // fused seam of the layer that produced xin (see LaConvArgs): LDS rows 6, 7 = its demod / bias, 8.. = ddn partials,
+            // 12.. = maxima (the 16-bit kernels' LDS is large enough; the fp32 kernel never sets seam_ddn_part)
+            const bool seam = a.seam_ddn_part != nullptr && x0 != nullptr;
+            // (activation backward from the saved output as straight-line selects with reciprocals: same values as
+            //  la_act_bwd_from_y / la_act_inv up to the rounding of 1/gain, 1/alpha)
+            const float s_pos = a.seam_gain, s_neg = a.seam_act == LA_ACT_LRELU ? a.seam_gain * a.seam_alpha : (a.seam_act == LA_ACT_RELU ? 0.f : a.seam_gain);
+            const float i_gain = 1.f / a.seam_gain, i_neg = a.seam_act == LA_ACT_LRELU ? 1.f / (a.seam_gain * a.seam_alpha) : 1.f / a.seam_gain;
+            const float s_cl = a.seam_clamp >= 0.f ? a.seam_clamp : __builtin_huge_valf();
+            float nz0[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) nz0[j] = 0.f;
+            if (seam) {
+                if (tid < MT) {
+                    red[6][tid] = a.seam_demod ? a.seam_demod[(long)b * a.seam_demod_stride + m0 + tid] : 1.f;
+                    red[7][tid] = a.seam_bias ? a.seam_bias[m0 + tid] : 0.f;
+                }
+                if (a.seam_noise) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) nz0[j] = a.seam_noise[(long)b * a.seam_noise_bstride + np[j]] * a.seam_noise_strength;
+                }
+            }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -86,27 +107,58 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                 for (int r = 0; r < 16; ++r) {
                     const int mr = i * 32 + (r & 3) + 8 * (r >> 2);
                     const float sc = prm[mw + mr];
-                    float part = 0.f;
+                    float part = 0.f, dd = 0.f, mx = 0.f;
+                    if (seam) {
+                        const float dm0 = red[6][mw + mr], b0 = red[7][mw + mr];
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const float v = acc[i][j][r];
-                        o0[(long)mr * HWo + np[j]] = v * sc;
-                        if (x0) part += v * xv[r][j];
+                        for (int j = 0; j < NJ; ++j) {
+                            const float v = acc[i][j][r], y = xv[r][j];
+                            const bool pos = y > 0.f;
+                            const float sl = fabsf(y) >= s_cl ? 0.f : (pos ? s_pos : s_neg);
+                            const float g1 = v * sc * sl;
+                            dd += g1 * (y * (pos ? i_gain : i_neg) - b0 - nz0[j]);
+                            const float gz = g1 * dm0;
+                            o0[(long)mr * HWo + np[j]] = gz;
+                            mx = fmaxf(mx, fabsf(gz));
+                            part += v * y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const float v = acc[i][j][r];
+                            o0[(long)mr * HWo + np[j]] = v * sc;
+                            if (x0) part += v * xv[r][j];
+                        }
                     }
                     if (a.ds_part) {
 #pragma unroll
                         for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
                         if (l31 == 0) red[wn][mw + mr] = part;
                     }
+                    if (seam) {
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) { dd += __shfl_xor(dd, o, 64); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+                        if (l31 == 0) { red[8 + wn][mw + mr] = dd; red[12 + wn][mw + mr] = mx; }
+                    }
                 }
             }
-            if (a.ds_part) {
+            if (a.ds_part || seam) {
                 __syncthreads();
                 if (tid < MT) {
-                    float t = red[0][tid];
+                    const long slot = ((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile;
+                    if (a.ds_part) {
+                        float t = red[0][tid];
 #pragma unroll
-                    for (int w = 1; w < WN_; ++w) t += red[w][tid];
-                    a.ds_part[((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile] = t;
+                        for (int w = 1; w < WN_; ++w) t += red[w][tid];
+                        a.ds_part[slot] = t;
+                    }
+                    if (seam) {
+                        float t = red[8][tid], m = red[12][tid];
+#pragma unroll
+                        for (int w = 1; w < WN_; ++w) { t += red[8 + w][tid]; m = fmaxf(m, red[12 + w][tid]); }
+                        a.seam_ddn_part[slot] = t;
+                        if (a.seam_pmax) a.seam_pmax[slot] = m;
+                    }
                 }
             }
             return;
@@ -188,6 +240,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
     if (a.epi == LA_EPI_BWD) {
         const float* xin_b = a.xin ? a.xin + (long)b * a.xin_bstride : nullptr;
         const float* os_b = a.out_scale ? a.out_scale + (long)b * a.oscale_stride : nullptr;
+        const bool seam = a.seam_ddn_part != nullptr && xin_b != nullptr;      // fused seam of the layer that produced xin (LaConvArgs)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -196,13 +249,24 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                 const int m = m0 + ml;
                 const bool mok = m < a.M;
                 const float sc = (os_b && mok) ? os_b[m] : 1.f;
-                float part = 0.f;
+                const float dm0 = (seam && mok && a.seam_demod) ? a.seam_demod[(long)b * a.seam_demod_stride + m] : 1.f;
+                const float b0 = (seam && mok && a.seam_bias) ? a.seam_bias[m] : 0.f;
+                float part = 0.f, dd = 0.f, mx = 0.f;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const float v = acc[i][j][r];
                     if (mok && pix_ok[j]) {
-                        out_b[(long)m * HWout + npos[j]] = v * sc;
-                        if (xin_b) part += v * xin_b[(long)m * HWout + npos[j]];
+                        const float y = xin_b ? xin_b[(long)m * HWout + npos[j]] : 0.f;
+                        float g = v * sc;
+                        if (seam) {
+                            const float nz0 = a.seam_noise ? a.seam_noise[(long)b * a.seam_noise_bstride + npos[j]] * a.seam_noise_strength : 0.f;
+                            const float g1 = g * la_act_bwd_from_y(y, a.seam_act, a.seam_alpha, a.seam_gain, a.seam_clamp);
+                            dd += g1 * (la_act_inv(y, a.seam_act, a.seam_alpha, a.seam_gain) - b0 - nz0);
+                            g = g1 * dm0;
+                            mx = fmaxf(mx, fabsf(g));
+                        }
+                        out_b[(long)m * HWout + npos[j]] = g;
+                        part += v * y;
                     }
                 }
                 if (a.ds_part) {
@@ -211,17 +275,31 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                     for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
                     if (l31 == 0) red[wn][ml] = part;
                 }
+                if (seam) {
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) { dd += __shfl_xor(dd, o, 64); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+                    if (l31 == 0) { red[8 + wn][ml] = dd; red[12 + wn][ml] = mx; }
+                }
             }
         }
-        if (a.ds_part) {
+        if (a.ds_part || seam) {
             __syncthreads();
-            if (tid < MT && m0 + tid < a.M)
-                {
+            if (tid < MT && m0 + tid < a.M) {
+                const long slot = ((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile;
+                if (a.ds_part) {
                     float t = red[0][tid];
 #pragma unroll
                     for (int w = 1; w < WN_; ++w) t += red[w][tid];
-                    a.ds_part[((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile] = t;
+                    a.ds_part[slot] = t;
                 }
+                if (seam) {
+                    float t = red[8][tid], mm = red[12][tid];
+#pragma unroll
+                    for (int w = 1; w < WN_; ++w) { t += red[8 + w][tid]; mm = fmaxf(mm, red[12 + w][tid]); }
+                    a.seam_ddn_part[slot] = t;
+                    if (a.seam_pmax) a.seam_pmax[slot] = mm;
+                }
+            }
         }
         return;
     }

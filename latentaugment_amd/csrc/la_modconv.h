@@ -17,9 +17,19 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
                              float* scratch, float* y, float* y_pmax, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
                              hipStream_t stream, const float* xscale = nullptr);
 // xscale (optional, [B]): preset power-of-two fp16 operand scale of the input (e.g. from the clamp bound of the producing layer)
+// Backward seam of the layer that produced `xin`, applied inside the backward contraction's epilogue (LaConvArgs::seam_*):
+// its demod / bias / noise / activation, and where its demod-gradient partials and plane maxima go ([B][cin][la_modconv_ds_tiles(res)]).
+struct LaSeamFuse {
+    const float* demod; int demod_stride;
+    const float* bias;
+    const float* noise; long noise_bstride; float noise_strength;
+    int act; float alpha, gain, clamp;
+    float* ddn_part;
+    float* pmax;
+};
 int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, const float* wb, const void* wq, int precision, const float* s, int s_stride,
                          const float* xin, long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
-                         int res, hipStream_t stream);
+                         int res, hipStream_t stream, const LaSeamFuse* seam = nullptr);
 
 // gz_pmax [B][cout][gz_nseg]: partial max |gz| per plane (left by the seam kernel); with it the fp16 mode builds the contraction's
 // operand in one fused pass (FIR adjoint + scale + split + interleave)

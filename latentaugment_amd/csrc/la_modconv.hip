@@ -117,8 +117,9 @@ extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const f
 
 int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, const float* wb, const void* wq, int precision, const float* s, int s_stride,
                          const float* xin, long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
-                         int res, hipStream_t stream) {
+                         int res, hipStream_t stream, const LaSeamFuse* seam) {
     LA_CHECK_ARG(gz && wb && gx, "modconv_bwd: null pointer");
+    LA_CHECK_ARG(!seam || (precision != LA_PREC_F32 && xin && seam->ddn_part), "modconv_bwd: the fused seam needs a 16-bit contraction and xin");
     LaConvArgs a; base_args(a);
     a.in = gz; a.in_bstride = (long)cout * res * res; a.wgt = wb; a.out = gx; a.in_pmax = in_pmax; a.in_pmax_nseg = in_nseg;
     a.ws = ws; a.ws_bytes = ws_bytes;
@@ -130,6 +131,12 @@ int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, con
     a.out_scale = s; a.oscale_stride = s_stride;
     a.xin = xin; a.xin_bstride = xin_bstride;
     a.ds_part = ds_part; a.tiles_per_sample = la_conv_tiles_per_sample(res, res);
+    if (seam) {
+        a.seam_demod = seam->demod; a.seam_demod_stride = seam->demod_stride; a.seam_bias = seam->bias;
+        a.seam_noise = seam->noise; a.seam_noise_bstride = seam->noise_bstride; a.seam_noise_strength = seam->noise_strength;
+        a.seam_act = seam->act; a.seam_alpha = seam->alpha; a.seam_gain = seam->gain; a.seam_clamp = seam->clamp;
+        a.seam_ddn_part = seam->ddn_part; a.seam_pmax = seam->pmax;
+    }
     return la_conv_launch(a, stream);
 }
 

@@ -51,6 +51,8 @@ struct la_synth {
     void* cws;
     size_t cws_bytes;
     float* pmax;             // [maxB][max channels]: plane maxima handed from a producing kernel to the next contraction (fp16 mode)
+    float *ddn2, *pmax2;     // [maxB][cout][tiles]: demod-gradient partials / plane maxima of an up-sampling layer's seam when it is fused
+                             // into the epilogue of the conv1 backward contraction above it
     float* xs_fwd;           // [nconv][B]: fp16 operand scales of the forward contractions (from the clamp bound, one launch per pass)
     float* xs_bound;         // [nconv]: bound on |input| of conv layer k: max|const| for the first, conv_clamp for the rest
     int lastB;
@@ -128,6 +130,15 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
             if (b2 > pmx) pmx = b2;
         }
         h->pmax = c.take(mb * pmx);
+    }
+    {
+        size_t f2 = 0;
+        for (int k = 0; k < h->nconv; ++k) {
+            const ConvLayer& L = h->conv[k];
+            if (L.up) { const size_t n = mb * L.cout * (size_t)la_conv_tiles_per_sample(L.res, L.res); if (n > f2) f2 = n; }
+        }
+        h->ddn2 = c.take(f2 ? f2 : 16);
+        h->pmax2 = c.take(f2 ? f2 : 16);
     }
     h->xs_fwd = c.take((size_t)h->nconv * mb);
     h->xs_bound = c.take((size_t)h->nconv + 16);
@@ -369,39 +380,55 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
         const int slabs = la_seam_slabs(HW);
         if ((rc = la_style_backward_rgb(h->dweff_part, slabs, T.weight, T.cin, h->imgc, B, h->ds_all + T.s_off, h->S, stream)))
             return rc;
-        // ---- conv1 backward-data (+ style-gradient partials)
+        // ---- conv1 backward-data (+ style-gradient partials).  16-bit modes, blocks above the first: the seam of the up-sampling
+        // layer L0 (whose saved output is this contraction's xin) is applied in the same epilogue -- no separate pass over y0 and
+        // the gradient; its demod-gradient partials and plane maxima come out per pixel tile.
+        static const bool no_fuse = getenv("LA_NO_SEAM_FUSE") != nullptr;      // dev knob: A/B of the fused seam on one box
+        const bool fuse_seam = k > 0 && h->precision != LA_PREC_F32 && !no_fuse;
+        const int tiles1 = la_modconv_ds_tiles(res);
         {
             const float* xin = (k == 0) ? h->cst : h->conv[ci - 1].y;
             const long xin_bs = (k == 0) ? 0 : (long)L1.cin * HW;
-            const int tiles = la_modconv_ds_tiles(res);
+            LaSeamFuse sf; memset(&sf, 0, sizeof(sf));
+            if (fuse_seam) {
+                const ConvLayer& L0f = h->conv[ci - 1];
+                sf.demod = h->d_all + L0f.d_off; sf.demod_stride = h->Dt; sf.bias = L0f.bias;
+                sf.noise = L0f.noise_used; sf.noise_bstride = L0f.noise_bstride; sf.noise_strength = L0f.noise_strength;
+                sf.act = LA_ACT_LRELU; sf.alpha = 0.2f; sf.gain = sqrtf(2.f); sf.clamp = h->clamp;
+                sf.ddn_part = h->ddn2; sf.pmax = f16 ? h->pmax2 : nullptr;
+            }
             if ((rc = la_modconv3x3_bwd_ex(h->G0, f16 ? h->pmax : nullptr, slabs, L1.wb, L1.wqb, h->precision, h->s_all + L1.s_off, h->S, xin, xin_bs, h->G1,
-                                           h->ds_part, h->cws, h->cws_bytes, B, L1.cin, L1.cout, res, stream)))
+                                           h->ds_part, h->cws, h->cws_bytes, B, L1.cin, L1.cout, res, stream, fuse_seam ? &sf : nullptr)))
                 return rc;
-            if ((rc = la_style_backward_conv(h->ds_part, tiles, h->ddn_part, slabs, h->d_all + L1.d_off, h->Dt,
+            if ((rc = la_style_backward_conv(h->ds_part, tiles1, h->ddn_part, slabs, h->d_all + L1.d_off, h->Dt,
                                              h->s_all + L1.s_off, h->S, L1.wsq, L1.cin, L1.cout, B,
                                              h->ds_all + L1.s_off, h->S, stream)))
                 return rc;
         }
         --ci;
         if (k == 0) break;
-        // ---- conv0 (up-sampling layer): act backward -> FIR adjoint -> stride-2 backward-data
+        // ---- conv0 (up-sampling layer): act backward (unless fused above) -> FIR adjoint -> stride-2 backward-data
         ConvLayer& L0 = h->conv[ci];
-        memset(&s, 0, sizeof(s));
-        s.y = L0.y; s.gx_next = h->G1; s.gz = h->G1; s.HW = HW; s.C = L0.cout;
-        s.demod = h->d_all + L0.d_off; s.demod_stride = h->Dt; s.bias = L0.bias;
-        s.noise = L0.noise_used; s.noise_bstride = L0.noise_bstride; s.noise_strength = L0.noise_strength;
-        s.act = LA_ACT_LRELU; s.alpha = 0.2f; s.gain = sqrtf(2.f); s.clamp = h->clamp;
-        s.ddn_part = h->ddn_part;
-        if (f16) s.pmax_out = h->pmax;      // plane maxima of gz: bound for the operand scale of the fused FIR-adjoint + split pass
-        if ((rc = la_seam_backward(s, B, 0, stream))) return rc;
+        if (!fuse_seam) {
+            memset(&s, 0, sizeof(s));
+            s.y = L0.y; s.gx_next = h->G1; s.gz = h->G1; s.HW = HW; s.C = L0.cout;
+            s.demod = h->d_all + L0.d_off; s.demod_stride = h->Dt; s.bias = L0.bias;
+            s.noise = L0.noise_used; s.noise_bstride = L0.noise_bstride; s.noise_strength = L0.noise_strength;
+            s.act = LA_ACT_LRELU; s.alpha = 0.2f; s.gain = sqrtf(2.f); s.clamp = h->clamp;
+            s.ddn_part = h->ddn_part;
+            if (f16) s.pmax_out = h->pmax;      // plane maxima of gz: bound for the operand scale of the fused FIR-adjoint + split pass
+            if ((rc = la_seam_backward(s, B, 0, stream))) return rc;
+        }
         {
             const int hin = res / 2;
             const int tiles = la_modconv_ds_tiles(hin);
-            if ((rc = la_modconv3x3_up2_bwd_ex(h->G1, f16 ? h->pmax : nullptr, slabs, L0.wb, L0.wqb, h->precision, h->s_all + L0.s_off, h->S, h->conv[ci - 1].y,
-                                                (long)L0.cin * hin * hin, h->fir, h->zT, h->G0, h->ds_part, h->cws, h->cws_bytes, B, L0.cin, L0.cout,
-                                                res, stream)))
+            float* ddn0 = fuse_seam ? h->ddn2 : h->ddn_part;
+            const int nseg0 = fuse_seam ? tiles1 : slabs;
+            if ((rc = la_modconv3x3_up2_bwd_ex(h->G1, f16 ? (fuse_seam ? h->pmax2 : h->pmax) : nullptr, nseg0, L0.wb, L0.wqb, h->precision, h->s_all + L0.s_off, h->S,
+                                               h->conv[ci - 1].y, (long)L0.cin * hin * hin, h->fir, h->zT, h->G0, h->ds_part, h->cws, h->cws_bytes, B,
+                                               L0.cin, L0.cout, res, stream)))
                 return rc;
-            if ((rc = la_style_backward_conv(h->ds_part, tiles, h->ddn_part, slabs, h->d_all + L0.d_off, h->Dt,
+            if ((rc = la_style_backward_conv(h->ds_part, tiles, ddn0, nseg0, h->d_all + L0.d_off, h->Dt,
                                              h->s_all + L0.s_off, h->S, L0.wsq, L0.cin, L0.cout, B,
                                              h->ds_all + L0.s_off, h->S, stream)))
                 return rc;
