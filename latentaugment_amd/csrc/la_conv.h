@@ -33,6 +33,7 @@ struct LaConvArgs {
     int Gy, Gx;              // output grid per sample handled by this launch
     int in_sy, in_sx;
     int out_sy, out_sx, out_oy, out_ox;
+    int out_pitch; long out_plane;   // LA_EPI_RAW only, 0 = dense: row pitch / plane stride of `out` in floats (padded scratch rows, 16-byte aligned)
     int ntaps;
     int tap_dy[LA_CONV_MAX_TAPS], tap_dx[LA_CONV_MAX_TAPS], tap_w[LA_CONV_MAX_TAPS];
     int epi;

@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
     const bool live = m < a.M;
     if (!live && PPB > 1) return;
     const int G = a.Gy * a.Gx;
-    const long HWout = (long)a.Hout * a.Wout;
+    const int wpitch = (a.epi == LA_EPI_RAW && a.out_pitch > 0) ? a.out_pitch : a.Wout;
+    const long HWout = (a.epi == LA_EPI_RAW && a.out_plane > 0) ? a.out_plane : (long)a.Hout * a.Wout;
     const long slice = (long)a.B * a.M * G;
     const float* wsp = a.splitk_ws + ((long)b * a.M + m) * G;
     float* out_p = a.out + ((long)b * a.M + m) * HWout;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
         float v = 0.f;
         for (int k = 0; k < a.ksplit; ++k) v += wsp[(long)k * slice + g];
         const int gy = g / a.Gx, gx = g - gy * a.Gx;
-        const long pos = (long)(gy * a.out_sy + a.out_oy) * a.Wout + gx * a.out_sx + a.out_ox;
+        const long pos = (long)(gy * a.out_sy + a.out_oy) * wpitch + gx * a.out_sx + a.out_ox;
         if (a.epi == LA_EPI_FWD) {
             const float nz = a.noise ? a.noise[(long)b * a.noise_bstride + pos] * a.noise_strength : 0.f;
             v = la_conv_epi_fwd(a, v, dmv, nz, bv);

@@ -220,27 +220,40 @@ __global__ __launch_bounds__(256) void la_xscale_kernel(const float* __restrict_
     if (threadIdx.x == 0) xscale[b] = la_pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
-__global__ __launch_bounds__(256) void la_xscale_pmax_kernel(const float* __restrict__ pmax, int nseg, const float* __restrict__ scale,
-                                                            int scale_stride, float* __restrict__ xscale, int C, float mult) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(1024) void la_xscale_pmax_kernel(const float* __restrict__ pmax, int nseg, const float* __restrict__ scale,
+                                                             int scale_stride, float* __restrict__ xscale, int C, float mult) {
+    __shared__ float red[16];
     const int b = blockIdx.x;
     const float* pb = pmax + (long)b * C * nseg;
     const float* sb = scale ? scale + (long)b * scale_stride : nullptr;
     const int n = C * nseg;
     float m = 0.f;
-    for (int k = threadIdx.x; k < n; k += 256) m = fmaxf(m, pb[k] * fabsf(sb ? sb[k / nseg] : 1.f));
+    if (!sb && (n & 3) == 0 && (((size_t)pb) & 15) == 0) {      // plain maximum of a contiguous array: 16-byte loads
+        const float4* p4 = reinterpret_cast<const float4*>(pb);
+        for (int k = threadIdx.x; k < (n >> 2); k += 1024) {
+            const float4 v = p4[k];
+            m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        }
+    } else {
+        for (int k = threadIdx.x; k < n; k += 1024) m = fmaxf(m, pb[k] * fabsf(sb ? sb[k / nseg] : 1.f));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) xscale[b] = la_pow2_scale(mult * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (threadIdx.x == 0) {
+        float t = red[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) t = fmaxf(t, red[w]);
+        xscale[b] = la_pow2_scale(mult * t);
+    }
 }
 
 // xscale[b] = power-of-two operand scale of a tensor bounded by mult * max_c(|scale[b][c]| * max_seg pmax[b][c][seg])
 int la_conv_xscale_from_pmax(const float* pmax, int nseg, const float* scale, int scale_stride, float mult, float* xscale, int B, int C,
                              hipStream_t stream) {
     LA_CHECK_ARG(pmax && xscale && nseg >= 1 && B >= 1 && C >= 1, "xscale_from_pmax: bad arguments");
-    hipLaunchKernelGGL(la_xscale_pmax_kernel, dim3(B), dim3(256), 0, stream, pmax, nseg, scale, scale_stride, xscale, C, mult);
+    hipLaunchKernelGGL(la_xscale_pmax_kernel, dim3(B), dim3(1024), 0, stream, pmax, nseg, scale, scale_stride, xscale, C, mult);
     LA_CHECK_LAUNCH();
     return LA_OK;
 }
@@ -323,7 +336,7 @@ static int prepare_scale(LaConvArgs& a, hipStream_t stream) {
     int ns = (int)(HW / 8192);
     ns = ns < 1 ? 1 : (ns > PM_NS ? PM_NS : ns);
     if (a.in_pmax) {      // the producer of `in` already reduced every plane: max over the sample of |style| * plane max
-        hipLaunchKernelGGL(la_xscale_pmax_kernel, dim3(a.B), dim3(256), 0, stream, a.in_pmax, a.in_pmax_nseg > 0 ? a.in_pmax_nseg : 1, a.in_scale,
+        hipLaunchKernelGGL(la_xscale_pmax_kernel, dim3(a.B), dim3(1024), 0, stream, a.in_pmax, a.in_pmax_nseg > 0 ? a.in_pmax_nseg : 1, a.in_scale,
                            a.scale_stride, xscale, a.C, 1.f);
     } else {
         hipLaunchKernelGGL(la_plane_absmax_kernel, dim3(ns, a.C, a.B), dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale,

@@ -46,6 +46,9 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
     }
 
     const int b = b_sel >= 0 ? b_sel : (int)blockIdx.z;      // (merged-phase launches pass the sample explicitly)
+    // row pitch / plane stride of `out`: raw (epilogue-free) launches may write a padded scratch layout (LaConvArgs::out_pitch)
+    const int wpitch = (a.epi == LA_EPI_RAW && a.out_pitch > 0) ? a.out_pitch : a.Wout;
+    const long oplane = (a.epi == LA_EPI_RAW && a.out_plane > 0) ? a.out_plane : (long)a.Hout * a.Wout;
     // ---- fast path: the whole MT x 128 tile is inside the output (block-uniform).  Straight-line code: per-row parameters
     // come from LDS (staged with one coalesced load), every global load is unconditional and issued in one batch, so the
     // 64 stores of a lane are not serialised behind 32 dependent round trips to L2/HBM.
@@ -63,9 +66,9 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                 const int g = ntile * NT + (wn * NJ + j) * 32 + l31;
                 gy = g / a.Gx; gx = g - gy * a.Gx;
             }
-            np[j] = (long)(gy * a.out_sy + a.out_oy) * a.Wout + (gx * a.out_sx + a.out_ox);
+            np[j] = (long)(gy * a.out_sy + a.out_oy) * wpitch + (gx * a.out_sx + a.out_ox);
         }
-        const long HWo = (long)a.Hout * a.Wout;
+        const long HWo = oplane;
         const int mw = wm * (MT / WM_) + 4 * lh;          // first row of this lane inside the tile
         float* o0 = a.out + ((long)b * a.M + m0 + mw) * HWo;
         if (a.epi == LA_EPI_BWD) {
@@ -232,9 +235,9 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
             gx = pix_ok[j] ? g - gy * a.Gx : 0;
         }
         const int oy = gy * a.out_sy + a.out_oy, ox = gx * a.out_sx + a.out_ox;
-        npos[j] = (long)oy * a.Wout + ox;
+        npos[j] = (long)oy * wpitch + ox;
     }
-    const long HWout = (long)a.Hout * a.Wout;
+    const long HWout = oplane;
     float* out_b = a.out + (long)b * a.M * HWout;
 
     if (a.epi == LA_EPI_BWD) {

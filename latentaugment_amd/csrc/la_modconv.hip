@@ -5,6 +5,7 @@
 #include "la_modconv.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "la_conv.h"
@@ -54,8 +55,9 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
                              const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                              const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
                              float* scratch, float* y, float* y_pmax, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
-                             hipStream_t stream, const float* xscale) {
+                             hipStream_t stream, const float* xscale, int scratch_pitch) {
     LA_CHECK_ARG(x && wf && y && scratch && fir_host, "modconv_up2_fwd: null pointer");
+    LA_CHECK_ARG(scratch_pitch == 0 || scratch_pitch >= res + 1, "modconv_up2_fwd: scratch pitch smaller than a row");
     LA_CHECK_ARG(res >= 2 && res % 2 == 0, "modconv_up2_fwd: output resolution must be even");
     // transposed stride-2 conv as 4 output phases: row Y = 2*qy + py receives taps ky with (Y - ky) even
     const int hin = res / 2;
@@ -66,6 +68,7 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
     a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cout, cin, 9);
     a.B = B; a.C = cin; a.M = cout; a.Hin = a.Win = hin; a.Hout = a.Wout = res + 1;
     a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW;
+    if (scratch_pitch > 0) { a.out_pitch = scratch_pitch; a.out_plane = (long)scratch_pitch * (res + 1); }      // padded (2h+1)-wide rows
     if (precision == LA_PREC_F16X2) a.acc_scale_x = xscale;      // preset operand scale (bound-based): no absmax pass
     if (precision != LA_PREC_F32) {
         // split the (modulated) input once for the four phase launches
@@ -103,7 +106,8 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
     }
     // FIR with pad (1,1,1,1) and gain up^2 = 4 (conv2d_resample.py:119-126), then the layer epilogue
     return la_upfirdn2d_modconv_epilogue(scratch, y, B, cout, res + 1, res + 1, fir_host, 4, 4, 1, 1, 1, 1, 4.f, d, d_stride,
-                                         noise, noise_bstride, noise_strength, bias, act, alpha, gain, clamp, stream, y_pmax);
+                                         noise, noise_bstride, noise_strength, bias, act, alpha, gain, clamp, stream, y_pmax,
+                                         scratch_pitch, (long)scratch_pitch * (res + 1));
 }
 
 extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
@@ -112,7 +116,7 @@ extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const f
                                          float clamp, const float* fir_host, float* scratch, float* y, void* ws, size_t ws_bytes, int B, int cin,
                                          int cout, int res, hipStream_t stream) {
     return la_modconv3x3_up2_fwd_ex(x, x_bstride, wf, wq, precision, s, s_stride, d, d_stride, noise, noise_bstride, noise_strength, bias, act,
-                                    alpha, gain, clamp, fir_host, scratch, y, nullptr, ws, ws_bytes, B, cin, cout, res, stream);
+                                    alpha, gain, clamp, fir_host, scratch, y, nullptr, ws, ws_bytes, B, cin, cout, res, stream, nullptr, 0);
 }
 
 int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, const float* wb, const void* wq, int precision, const float* s, int s_stride,

@@ -87,8 +87,8 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
         L.y = c.take(mb * L.cout * hw);
         if (mb * L.cout * hw > gmax) gmax = mb * L.cout * hw;
         if (mb * L.cin * hw > gmax && !L.up) gmax = mb * L.cin * hw;
-        if (L.up) {
-            const size_t z = mb * L.cout * (size_t)(L.res + 1) * (L.res + 1);
+        if (L.up) {      // transposed-conv intermediate, rows padded to a multiple of 4 floats (zt_pitch)
+            const size_t z = mb * L.cout * (size_t)(L.res + 1) * (size_t)((L.res + 1 + 3) & ~3);
             if (z > ztmax) ztmax = z;
         }
         const int gin = L.up ? L.res / 2 : L.res;   // grid of the backward-data conv
@@ -326,7 +326,8 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
                 rc = la_modconv3x3_up2_fwd_ex(x, x_bstride, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                               L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f,
                                               sq2, h->clamp, h->fir, h->zT, L.y, (f16 && !bound_scale) ? h->pmax : nullptr, h->cws, h->cws_bytes, B, L.cin,
-                                              L.cout, res, stream, bound_scale ? h->xs_fwd + (long)ci * B : nullptr);
+                                              L.cout, res, stream, bound_scale ? h->xs_fwd + (long)ci * B : nullptr,
+                                              ((f16 && !bound_scale) || getenv("LA_NO_ZT_PITCH")) ? 0 : (res + 1 + 3) & ~3);      // (plane maxima come from the scalar FIR kernel only)
                 x_pmax = (f16 && !bound_scale) ? h->pmax : nullptr;
                 x_nseg = la_fir4x4_segments(res, res);
             }
