@@ -62,6 +62,16 @@ int la_style_backward_conv(float* ds_part, int ntiles, float* ddn_part, int nsla
                            float* ds_out, int ds_stride, hipStream_t);
 int la_style_backward_rgb(const float* dweff_part, int nslabs, const float* wrgb, int C, int imgc, int B,
                           float* ds_out, int ds_stride, hipStream_t);
+// Style-gradient finish of ALL layers of one backward pass in three launches (row sums of every partial buffer, conv layers,
+// ToRGB layers) instead of three small launches per layer: the per-layer partial buffers are kept until the end of the pass.
+#define LA_FIN_MAX_CONV 24
+#define LA_FIN_MAX_RGB 12
+struct LaStyleFinish {
+    int nconv, nrgb, imgc, d_stride, s_stride, ds_stride;
+    struct Conv { float* ds_part; float* ddn_part; const float* d; const float* s; const float* wsq; float* ds_out; int ntiles, nslabs, cin, cout, blk0; } conv[LA_FIN_MAX_CONV];
+    struct Rgb { float* dweff_part; const float* wrgb; float* ds_out; int nslabs, C, blk0; } rgb[LA_FIN_MAX_RGB];
+};
+int la_style_backward_all(const LaStyleFinish& f, int B, hipStream_t stream);
 int la_affine_bwd_chunks(const LaStyleTable& t);   // part scratch = chunks * B * wdim floats
 int la_affine_backward(const LaStyleTable& t, const float* ds_all, int B, int wdim, float* dws, int num_ws, float* part,
                        hipStream_t);

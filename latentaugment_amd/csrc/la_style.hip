@@ -493,6 +493,105 @@ int la_style_backward_conv(float* ds_part, int ntiles, float* ddn_part, int nsla
     return LA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// One-pass finish for all layers (LaStyleFinish): same arithmetic and summation order as the per-layer kernels above.
+struct LaRowSegs { int nseg; long row0[2 * LA_FIN_MAX_CONV + LA_FIN_MAX_RGB + 1]; float* ptr[2 * LA_FIN_MAX_CONV + LA_FIN_MAX_RGB]; int n[2 * LA_FIN_MAX_CONV + LA_FIN_MAX_RGB]; };
+
+__global__ __launch_bounds__(256) void la_rows_sum_all_kernel(LaRowSegs g) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= g.row0[g.nseg]) return;
+    int sg = 0;
+    while (sg + 1 < g.nseg && r >= g.row0[sg + 1]) ++sg;
+    const int n = g.n[sg];
+    float* row = g.ptr[sg] + (r - g.row0[sg]) * n;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int k = lane;
+    for (; k + 192 < n; k += 256) { v0 += row[k]; v1 += row[k + 64]; v2 += row[k + 128]; v3 += row[k + 192]; }
+    for (; k < n; k += 64) v0 += row[k];
+    float v = (v0 + v1) + (v2 + v3);
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft, 64);
+    if (lane == 0) row[0] = v;
+}
+
+__global__ __launch_bounds__(256) void la_style_bwd_conv_all_kernel(LaStyleFinish f) {
+    extern __shared__ float q[];   // [cout] + [16][16]
+    int l = 0;
+    while (l + 1 < f.nconv && (int)blockIdx.x >= f.conv[l + 1].blk0) ++l;
+    const LaStyleFinish::Conv& L = f.conv[l];
+    const int cin = L.cin, cout = L.cout;
+    float* comb = q + cout;
+    const int b = blockIdx.y;
+    for (int o = threadIdx.x; o < cout; o += blockDim.x) {
+        const float dv = L.d[(long)b * f.d_stride + o];
+        q[o] = L.ddn_part[((long)b * cout + o) * L.nslabs] * dv * dv;
+    }
+    __syncthreads();
+    const int il = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int i = ((int)blockIdx.x - L.blk0) * 16 + il;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < cin) {
+        const int per = (cout + 15) / 16;
+        const int o0 = part * per, o1 = o0 + per < cout ? o0 + per : cout;
+        int o = o0;
+        for (; o + 3 < o1; o += 4) {
+            a0 += q[o] * L.wsq[(long)o * cin + i];
+            a1 += q[o + 1] * L.wsq[(long)(o + 1) * cin + i];
+            a2 += q[o + 2] * L.wsq[(long)(o + 2) * cin + i];
+            a3 += q[o + 3] * L.wsq[(long)(o + 3) * cin + i];
+        }
+        for (; o < o1; ++o) a0 += q[o] * L.wsq[(long)o * cin + i];
+    }
+    comb[part * 16 + il] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (part == 0 && i < cin) {
+        float tot = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) tot += comb[p * 16 + il];
+        L.ds_out[(long)b * f.ds_stride + i] = L.ds_part[((long)b * cin + i) * L.ntiles] - L.s[(long)b * f.s_stride + i] * tot;
+    }
+}
+
+__global__ void la_style_bwd_rgb_all_kernel(LaStyleFinish f) {
+    int l = 0;
+    while (l + 1 < f.nrgb && (int)blockIdx.x >= f.rgb[l + 1].blk0) ++l;
+    const LaStyleFinish::Rgb& T = f.rgb[l];
+    const int b = blockIdx.y;
+    const int i = ((int)blockIdx.x - T.blk0) * blockDim.x + threadIdx.x;
+    if (i >= T.C) return;
+    float acc = 0.f;
+    for (int k = 0; k < f.imgc; ++k) acc += T.dweff_part[(((long)b * f.imgc + k) * T.C + i) * T.nslabs] * T.wrgb[k * T.C + i];
+    T.ds_out[(long)b * f.ds_stride + i] = acc;
+}
+
+int la_style_backward_all(const LaStyleFinish& fin, int B, hipStream_t stream) {
+    LA_CHECK_ARG(fin.nconv >= 0 && fin.nconv <= LA_FIN_MAX_CONV && fin.nrgb >= 0 && fin.nrgb <= LA_FIN_MAX_RGB, "style_backward_all: too many layers");
+    LaStyleFinish f = fin;
+    LaRowSegs g;
+    g.nseg = 0; g.row0[0] = 0;
+    auto seg = [&](float* p, long rows, int n) { g.ptr[g.nseg] = p; g.n[g.nseg] = n; g.row0[g.nseg + 1] = g.row0[g.nseg] + rows; ++g.nseg; };
+    int cblk = 0, rblk = 0, max_cout = 0;
+    for (int l = 0; l < f.nconv; ++l) {
+        LaStyleFinish::Conv& L = f.conv[l];
+        seg(L.ddn_part, (long)B * L.cout, L.nslabs);
+        seg(L.ds_part, (long)B * L.cin, L.ntiles);
+        L.blk0 = cblk; cblk += la_cdiv(L.cin, 16);
+        if (L.cout > max_cout) max_cout = L.cout;
+    }
+    for (int l = 0; l < f.nrgb; ++l) {
+        LaStyleFinish::Rgb& T = f.rgb[l];
+        seg(T.dweff_part, (long)B * f.imgc * T.C, T.nslabs);
+        T.blk0 = rblk; rblk += la_cdiv(T.C, 256);
+    }
+    if (g.nseg == 0) return LA_OK;
+    hipLaunchKernelGGL(la_rows_sum_all_kernel, dim3((unsigned)la_cdiv(g.row0[g.nseg], 4)), dim3(256), 0, stream, g);
+    if (f.nconv) hipLaunchKernelGGL(la_style_bwd_conv_all_kernel, dim3(cblk, B), dim3(256), (max_cout + 256) * sizeof(float), stream, f);
+    if (f.nrgb) hipLaunchKernelGGL(la_style_bwd_rgb_all_kernel, dim3(rblk, B), dim3(256), 0, stream, f);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
 // ToRGB style gradient: ds[b][i] = sum_k wrgb[k][i] * sum_slabs dweff_part[b][k][i][.]
 __global__ void la_style_bwd_rgb_kernel(const float* __restrict__ dweff_part, int nslabs, const float* __restrict__ wrgb,
                                         int C, int imgc, float* __restrict__ ds_out, int ds_stride) {

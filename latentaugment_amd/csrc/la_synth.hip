@@ -22,6 +22,7 @@ struct ConvLayer {
     float *wf, *wb, *wsq;   // packed (fp32)
     void *wqf, *wqb;        // packed split-bf16 (3 terms), forward / backward
     float* y;               // saved output [maxB][cout][res*res]
+    float *dsp, *ddnp;      // style-gradient partials of this layer (kept until the one-pass finish at the end of a backward pass)
     int s_off, d_off, style_idx;
     const float* noise_used;   // set by forward (null when the term vanishes)
     long noise_bstride;
@@ -32,6 +33,7 @@ struct RgbLayer {
     const float *affine_w, *affine_b, *weight, *bias;
     int s_off, style_idx;
     float *rgb_pre, *img, *g_img;
+    float* dwep;            // ToRGB weight-gradient partials [maxB][imgc][cin][slabs]
 };
 
 struct la_synth {
@@ -47,12 +49,12 @@ struct la_synth {
     LaDemodTable dt;
     int S, Dt;
     float *s_all, *d_all, *ds_all;
-    float *zT, *G0, *G1, *ds_part, *ddn_part, *dweff_part, *aff_part;
+    float *zT, *G0, *G1, *aff_part;
     void* cws;
     size_t cws_bytes;
     float* pmax;             // [maxB][max channels]: plane maxima handed from a producing kernel to the next contraction (fp16 mode)
-    float *ddn2, *pmax2;     // [maxB][cout][tiles]: demod-gradient partials / plane maxima of an up-sampling layer's seam when it is fused
-                             // into the epilogue of the conv1 backward contraction above it
+    float* pmax2;            // [maxB][cout][tiles]: plane maxima of an up-sampling layer's gz when its seam is fused into the epilogue of
+                             // the conv1 backward contraction above it
     float* xs_fwd;           // [nconv][B]: fp16 operand scales of the forward contractions (from the clamp bound, one launch per pass)
     float* xs_bound;         // [nconv]: bound on |input| of conv layer k: max|const| for the first, conv_clamp for the rest
     int lastB;
@@ -92,6 +94,11 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
             if (z > ztmax) ztmax = z;
         }
         const int gin = L.up ? L.res / 2 : L.res;   // grid of the backward-data conv
+        {
+            const size_t sl0 = (size_t)la_seam_slabs((long)hw), t1 = (size_t)la_conv_tiles_per_sample(L.res, L.res);
+            L.dsp = c.take(mb * L.cin * (size_t)la_conv_tiles_per_sample(gin, gin));
+            L.ddnp = c.take(mb * L.cout * (sl0 > t1 ? sl0 : t1));
+        }
         const size_t t = mb * L.cin * (size_t)la_conv_tiles_per_sample(gin, gin);
         if (t > dsp) dsp = t;
         const size_t sl = mb * L.cout * (size_t)la_seam_slabs((long)hw);
@@ -105,6 +112,7 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
         T.rgb_pre = c.take(mb * h->imgc * hw);
         T.img = c.take(mb * h->imgc * hw);
         T.g_img = c.take(mb * h->imgc * hw);
+        T.dwep = c.take(mb * h->imgc * T.cin * (size_t)la_seam_slabs((long)hw));
         const size_t sl = mb * h->imgc * T.cin * (size_t)la_seam_slabs((long)hw);
         if (sl > dwe) dwe = sl;
     }
@@ -114,9 +122,6 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
     h->zT = c.take(ztmax);
     h->G0 = c.take(gmax);
     h->G1 = c.take(gmax);
-    h->ds_part = c.take(dsp);
-    h->ddn_part = c.take(ddn);
-    h->dweff_part = c.take(dwe);
     h->aff_part = c.take((size_t)la_affine_bwd_chunks(h->st) * mb * h->wdim);
     h->cws = c.take((skf + 3) / 4);
     h->cws_bytes = skf;
@@ -137,7 +142,6 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
             const ConvLayer& L = h->conv[k];
             if (L.up) { const size_t n = mb * L.cout * (size_t)la_conv_tiles_per_sample(L.res, L.res); if (n > f2) f2 = n; }
         }
-        h->ddn2 = c.take(f2 ? f2 : 16);
         h->pmax2 = c.take(f2 ? f2 : 16);
     }
     h->xs_fwd = c.take((size_t)h->nconv * mb);
@@ -361,6 +365,15 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
     const float* gi = g_img;   // gradient w.r.t. the image at the current resolution
     int ci = h->nconv - 1;
     const float* gx_next = nullptr;   // gradient w.r.t. this block's conv1 output coming from the block above
+    // every layer leaves its style-gradient partials in buffers of its own; ONE finish (3 launches) at the end of the pass turns
+    // them into ds_all (la_style_backward_all), instead of 3 small launches per layer
+    LaStyleFinish fin; memset(&fin, 0, sizeof(fin));
+    fin.imgc = h->imgc; fin.d_stride = h->Dt; fin.s_stride = h->S; fin.ds_stride = h->S;
+    auto fin_conv = [&](const ConvLayer& L, int ntiles, int nslabs) {
+        LaStyleFinish::Conv& c = fin.conv[fin.nconv++];
+        c.ds_part = L.dsp; c.ddn_part = L.ddnp; c.d = h->d_all + L.d_off; c.s = h->s_all + L.s_off; c.wsq = L.wsq;
+        c.ds_out = h->ds_all + L.s_off; c.ntiles = ntiles; c.nslabs = nslabs; c.cin = L.cin; c.cout = L.cout;
+    };
     for (int k = h->nblocks - 1; k >= 0; --k) {
         const int res = 4 << k;
         const long HW = (long)res * res;
@@ -372,15 +385,17 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
         s.demod = h->d_all + L1.d_off; s.demod_stride = h->Dt; s.bias = L1.bias;
         s.noise = L1.noise_used; s.noise_bstride = L1.noise_bstride; s.noise_strength = L1.noise_strength;
         s.act = LA_ACT_LRELU; s.alpha = 0.2f; s.gain = sqrtf(2.f); s.clamp = h->clamp;
-        s.ddn_part = h->ddn_part;
+        s.ddn_part = L1.ddnp;
         s.g_img = gi; s.rgb_pre = T.rgb_pre; s.rgb_clamp = h->clamp; s.wrgb = T.weight;
-        s.s_rgb = h->s_all + T.s_off; s.s_stride = h->S; s.dweff_part = h->dweff_part;
+        s.s_rgb = h->s_all + T.s_off; s.s_stride = h->S; s.dweff_part = T.dwep;
         const bool f16 = h->precision == LA_PREC_F16X2;
         if (f16) s.pmax_out = h->pmax;      // the seam kernel leaves the plane maxima of gz for the contraction that follows
         if ((rc = la_seam_backward(s, B, h->imgc, stream))) return rc;
         const int slabs = la_seam_slabs(HW);
-        if ((rc = la_style_backward_rgb(h->dweff_part, slabs, T.weight, T.cin, h->imgc, B, h->ds_all + T.s_off, h->S, stream)))
-            return rc;
+        {
+            LaStyleFinish::Rgb& r = fin.rgb[fin.nrgb++];
+            r.dweff_part = T.dwep; r.wrgb = T.weight; r.ds_out = h->ds_all + T.s_off; r.nslabs = slabs; r.C = T.cin;
+        }
         // ---- conv1 backward-data (+ style-gradient partials).  16-bit modes, blocks above the first: the seam of the up-sampling
         // layer L0 (whose saved output is this contraction's xin) is applied in the same epilogue -- no separate pass over y0 and
         // the gradient; its demod-gradient partials and plane maxima come out per pixel tile.
@@ -396,15 +411,12 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
                 sf.demod = h->d_all + L0f.d_off; sf.demod_stride = h->Dt; sf.bias = L0f.bias;
                 sf.noise = L0f.noise_used; sf.noise_bstride = L0f.noise_bstride; sf.noise_strength = L0f.noise_strength;
                 sf.act = LA_ACT_LRELU; sf.alpha = 0.2f; sf.gain = sqrtf(2.f); sf.clamp = h->clamp;
-                sf.ddn_part = h->ddn2; sf.pmax = f16 ? h->pmax2 : nullptr;
+                sf.ddn_part = h->conv[ci - 1].ddnp; sf.pmax = f16 ? h->pmax2 : nullptr;
             }
             if ((rc = la_modconv3x3_bwd_ex(h->G0, f16 ? h->pmax : nullptr, slabs, L1.wb, L1.wqb, h->precision, h->s_all + L1.s_off, h->S, xin, xin_bs, h->G1,
-                                           h->ds_part, h->cws, h->cws_bytes, B, L1.cin, L1.cout, res, stream, fuse_seam ? &sf : nullptr)))
+                                           L1.dsp, h->cws, h->cws_bytes, B, L1.cin, L1.cout, res, stream, fuse_seam ? &sf : nullptr)))
                 return rc;
-            if ((rc = la_style_backward_conv(h->ds_part, tiles1, h->ddn_part, slabs, h->d_all + L1.d_off, h->Dt,
-                                             h->s_all + L1.s_off, h->S, L1.wsq, L1.cin, L1.cout, B,
-                                             h->ds_all + L1.s_off, h->S, stream)))
-                return rc;
+            fin_conv(L1, tiles1, slabs);
         }
         --ci;
         if (k == 0) break;
@@ -416,23 +428,19 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
             s.demod = h->d_all + L0.d_off; s.demod_stride = h->Dt; s.bias = L0.bias;
             s.noise = L0.noise_used; s.noise_bstride = L0.noise_bstride; s.noise_strength = L0.noise_strength;
             s.act = LA_ACT_LRELU; s.alpha = 0.2f; s.gain = sqrtf(2.f); s.clamp = h->clamp;
-            s.ddn_part = h->ddn_part;
+            s.ddn_part = L0.ddnp;
             if (f16) s.pmax_out = h->pmax;      // plane maxima of gz: bound for the operand scale of the fused FIR-adjoint + split pass
             if ((rc = la_seam_backward(s, B, 0, stream))) return rc;
         }
         {
             const int hin = res / 2;
             const int tiles = la_modconv_ds_tiles(hin);
-            float* ddn0 = fuse_seam ? h->ddn2 : h->ddn_part;
             const int nseg0 = fuse_seam ? tiles1 : slabs;
             if ((rc = la_modconv3x3_up2_bwd_ex(h->G1, f16 ? (fuse_seam ? h->pmax2 : h->pmax) : nullptr, nseg0, L0.wb, L0.wqb, h->precision, h->s_all + L0.s_off, h->S,
-                                               h->conv[ci - 1].y, (long)L0.cin * hin * hin, h->fir, h->zT, h->G0, h->ds_part, h->cws, h->cws_bytes, B,
+                                               h->conv[ci - 1].y, (long)L0.cin * hin * hin, h->fir, h->zT, h->G0, L0.dsp, h->cws, h->cws_bytes, B,
                                                L0.cin, L0.cout, res, stream)))
                 return rc;
-            if ((rc = la_style_backward_conv(h->ds_part, tiles, ddn0, nseg0, h->d_all + L0.d_off, h->Dt,
-                                             h->s_all + L0.s_off, h->S, L0.wsq, L0.cin, L0.cout, B,
-                                             h->ds_all + L0.s_off, h->S, stream)))
-                return rc;
+            fin_conv(L0, tiles, nseg0);
         }
         --ci;
         gx_next = h->G0;
@@ -443,5 +451,6 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
             return rc;
         gi = P.g_img;
     }
+    if ((rc = la_style_backward_all(fin, B, stream))) return rc;
     return la_affine_backward(h->st, h->ds_all, B, h->wdim, dws, h->num_ws, h->aff_part, stream);
 }

@@ -1,0 +1,57 @@
+"""Dev tool: HBM traffic per kernel class from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes, as
+MI355X_MICROARCH.md "HBM" prescribes) of `bench.py --steps 1 --warmup 0 --no-graph`.
+Usage: pmc_classes.py <fetch.db> <write.db> <precision> <out.json>
+
+Units / corrections (the guide's): both counters are in KB (x1024).  WRITE_SIZE is exact for 16 B/lane streaming stores.  On
+gfx950 FETCH_SIZE reports exactly half the bytes of wide coalesced (16 B/lane) streaming reads; other access widths are
+uncalibrated.  Reported per class: `fetch_raw`, `write`, and `bytes_per_launch` = 2 x fetch_raw + write (the guide's correction:
+an upper bound for the classes whose reads are not all 16 B/lane -- the contraction kernels read fp32 activations 4 B/lane)."""
+import collections
+import json
+import sqlite3
+import sys
+
+CLASS_OF = [
+    ('la_conv_bf16_halo_kernel', 'conv_halo'), ('la_conv_splitk_finish', 'conv_splitk'), ('la_conv_igemm', 'conv_f32'),
+    ('la_presplit', 'operand_prep'), ('la_plane_absmax', 'operand_prep'), ('la_xscale', 'operand_prep'),
+    ('la_fir4x4', 'fir'), ('la_upfirdn2d_kernel', 'fir'), ('la_seam_bwd', 'seam_bwd'), ('la_torgb_fwd', 'torgb_fwd'), ('la_bank', 'bank'),
+]
+LAUNCH_KERNEL = {'conv_splitk': 'la_conv_bf16_kernel'}      # launches of a split-K class = launches of the contraction, not the finish pass
+
+
+def cls(name):
+    if 'la_conv_bf16_kernel' in name:
+        return 'conv_splitk' if ', true,' in name else 'conv_flat'
+    for pat, c in CLASS_OF:
+        if pat in name:
+            return c
+    return None
+
+
+def totals(path, counter):
+    db = sqlite3.connect(path)
+    tot, n = collections.defaultdict(float), collections.defaultdict(int)
+    seen = set()
+    for name, cn, v, did in db.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
+        c = cls(name)
+        if c is None or cn != counter:
+            continue
+        tot[c] += v * 1024.0
+        if did not in seen and LAUNCH_KERNEL.get(c, '') in name:
+            seen.add(did)
+            n[c] += 1
+    return tot, n
+
+
+fetch, n1 = totals(sys.argv[1], 'FETCH_SIZE')
+write, n2 = totals(sys.argv[2], 'WRITE_SIZE')
+out = {'precision': sys.argv[3], 'classes': {},
+       'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of one batch (bench.py --steps 1 --warmup 0 --no-graph), KB units '
+               'x1024; bytes_per_launch = 2 x FETCH_SIZE (gfx950 under-count of 16 B/lane streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE: an upper '
+               'bound where reads are narrower than 16 B/lane (the contraction kernels read fp32 activations 4 B/lane); fetch_raw is the uncorrected counter'}
+for c in sorted(set(fetch) | set(write)):
+    n = max(n1.get(c, 0), n2.get(c, 0), 1)
+    out['classes'][c] = {'launches': n, 'fetch_raw_per_launch': fetch[c] / n, 'write_per_launch': write[c] / n,
+                         'bytes_per_launch': (2 * fetch[c] + write[c]) / n, 'bytes_per_batch': 2 * fetch[c] + write[c]}
+json.dump(out, open(sys.argv[4], 'w'), indent=1)
+print(json.dumps(out['classes'], indent=1)[:2000])
