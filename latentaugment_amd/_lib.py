@@ -116,6 +116,7 @@ SIGNATURES = {
 }
 
 _lib = None
+LOADED_PATH = None
 
 
 def load():
@@ -133,6 +134,8 @@ def load():
             f'{path} not found: build it with `make -C latentaugment_amd/csrc` (or __graft_entry__.build()). '
             'There is no CPU fallback for the latent-augmentation hot path.')
     lib = C.CDLL(path)
+    global LOADED_PATH
+    LOADED_PATH = os.path.realpath(path)      # what was actually dlopen'ed (tests check it is the in-tree build)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -501,8 +501,11 @@ __global__ __launch_bounds__(256) void la_rows_sum_all_kernel(LaRowSegs g) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= g.row0[g.nseg]) return;
-    int sg = 0;
-    while (sg + 1 < g.nseg && r >= g.row0[sg + 1]) ++sg;
+    int sg = 0, hi = g.nseg - 1;                 // binary search of the segment (a linear scan cost ~50 scalar loads per wave)
+    while (sg < hi) {
+        const int mid = (sg + hi + 1) >> 1;
+        if (r >= g.row0[mid]) sg = mid; else hi = mid - 1;
+    }
     const int n = g.n[sg];
     float* row = g.ptr[sg] + (r - g.row0[sg]) * n;
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;

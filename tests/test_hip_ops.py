@@ -38,6 +38,12 @@ def test_library_loaded_is_in_tree():
     lib = _lib.load()
     assert lib.la_abi_version() == 1
     assert os.path.dirname(_lib.LIB_PATH).endswith('latentaugment_amd')
+    # the path that was actually dlopen'ed is the in-tree build (LATENTAUG_HIP_LIB can redirect the load for kernel experiments:
+    # the parity suite must not run on such a redirect)
+    assert _lib.LOADED_PATH == os.path.realpath(_lib.LIB_PATH), _lib.LOADED_PATH
+    with open('/proc/self/maps') as f:
+        mapped = {line.split()[-1] for line in f if 'liblatentaug_hip' in line}
+    assert mapped == {os.path.realpath(_lib.LIB_PATH)}, mapped
 
 
 def test_bias_act_golden(dev, g):
