@@ -66,6 +66,13 @@ struct LaConvArgs {
     int seam_act; float seam_alpha, seam_gain, seam_clamp;
     float* seam_ddn_part;    // [B][M][tiles_per_sample]
     float* seam_pmax;        // [B][M][tiles_per_sample] or null
+    // ... and, with seam_imgc > 0, the ToRGB backward of the block whose conv1 output xin is (la_seam_bwd_kernel<imgc>):
+    //   g += sum_c seam_wrgb[c][m] * seam_srgb[b][m] * gr_c,  gr_c = seam_gimg[b][c][px] where |seam_rgbpre[b][c][px]| <= seam_rgb_clamp;
+    //   seam_dweff_part[b][c][m][tile] = sum_px gr_c * y
+    int seam_imgc;
+    const float* seam_gimg; const float* seam_rgbpre; float seam_rgb_clamp;
+    const float* seam_wrgb; const float* seam_srgb; int seam_srgb_stride;
+    float* seam_dweff_part;  // [B][imgc][M][tiles_per_sample]
     // optional caller-provided scratch (la_conv_workspace_bytes): [fp16 scale header | pre-split input | split-K slice partials]
     void* ws;
     size_t ws_bytes;

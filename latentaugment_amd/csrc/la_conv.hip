@@ -231,6 +231,9 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
     const float dm0 = (seam && a.seam_demod) ? a.seam_demod[(long)b * a.seam_demod_stride + m] : 1.f;
     const float b0 = (seam && a.seam_bias) ? a.seam_bias[m] : 0.f;
     float part = 0.f, dd = 0.f, mx = 0.f;
+    const int imgc = seam ? (a.seam_imgc < 4 ? a.seam_imgc : 4) : 0;
+    float we[4] = {0.f, 0.f, 0.f, 0.f}, dwe[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < imgc; ++c) we[c] = a.seam_wrgb[(long)c * a.M + m] * a.seam_srgb[(long)b * a.seam_srgb_stride + m];
     for (int g = tp; g < G; g += T) {
         float v = 0.f;
         for (int k = 0; k < a.ksplit; ++k) v += wsp[(long)k * slice + g];
@@ -247,6 +250,13 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
             const float y = xin_p ? xin_p[pos] : 0.f;
             part += v * y;
             v *= sc;
+            for (int c = 0; c < imgc; ++c) {
+                const long o = ((long)b * imgc + c) * HWout + pos;
+                float gv = a.seam_gimg[o];
+                if (a.seam_rgb_clamp >= 0.f && fabsf(a.seam_rgbpre[o]) > a.seam_rgb_clamp) gv = 0.f;
+                v += we[c] * gv;
+                dwe[c] += gv * y;
+            }
             if (seam) {
                 const float nz0 = a.seam_noise ? a.seam_noise[(long)b * a.seam_noise_bstride + pos] * a.seam_noise_strength : 0.f;
                 const float g1 = v * la_act_bwd_from_y(y, a.seam_act, a.seam_alpha, a.seam_gain, a.seam_clamp);
@@ -261,17 +271,28 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
         part = la_wave_sum(part);
         dd = la_wave_sum(dd);
 #pragma unroll
+        for (int c = 0; c < 4; ++c) dwe[c] = la_wave_sum(dwe[c]);
+#pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         if (PPB == 1) {
-            __shared__ float wdd[4], wmx[4];
-            if (lane == 0) { wpart[threadIdx.x >> 6] = part; wdd[threadIdx.x >> 6] = dd; wmx[threadIdx.x >> 6] = mx; }
+            __shared__ float wdd[4], wmx[4], wdw[4][4];
+            if (lane == 0) {
+                const int w = threadIdx.x >> 6;
+                wpart[w] = part; wdd[w] = dd; wmx[w] = mx;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) wdw[c][w] = dwe[c];
+            }
             __syncthreads();
             part = (wpart[0] + wpart[1]) + (wpart[2] + wpart[3]);
             dd = (wdd[0] + wdd[1]) + (wdd[2] + wdd[3]);
             mx = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dwe[c] = (wdw[c][0] + wdw[c][1]) + (wdw[c][2] + wdw[c][3]);
         }
         if (tp < a.tiles_per_sample) {
             const long slot = ((long)b * a.M + m) * a.tiles_per_sample + tp;
+            for (int c = 0; c < imgc; ++c)
+                a.seam_dweff_part[(((long)b * imgc + c) * a.M + m) * a.tiles_per_sample + tp] = tp == 0 ? dwe[c] : 0.f;
             if (a.ds_part) a.ds_part[slot] = tp == 0 ? part : 0.f;
             if (seam) {
                 a.seam_ddn_part[slot] = tp == 0 ? dd : 0.f;

@@ -86,15 +86,38 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
             float nz0[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) nz0[j] = 0.f;
+            // ToRGB part of the fused seam (seam_imgc image channels): per-pixel image gradients (masked by the ToRGB clamp) in
+            // registers, per-row effective ToRGB weights in LDS rows 16.., weight-gradient partials in rows 20..
+            constexpr int SEAM_MAXC = 4;
+            const int imgc = seam ? a.seam_imgc : 0;
+            float gr[SEAM_MAXC][NJ];
+#pragma unroll
+            for (int c = 0; c < SEAM_MAXC; ++c)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) gr[c][j] = 0.f;
             if (seam) {
                 if (tid < MT) {
                     red[6][tid] = a.seam_demod ? a.seam_demod[(long)b * a.seam_demod_stride + m0 + tid] : 1.f;
                     red[7][tid] = a.seam_bias ? a.seam_bias[m0 + tid] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < SEAM_MAXC; ++c)
+                        if (c < imgc) red[16 + c][tid] = a.seam_wrgb[(long)c * a.M + m0 + tid] * a.seam_srgb[(long)b * a.seam_srgb_stride + m0 + tid];
                 }
                 if (a.seam_noise) {
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) nz0[j] = a.seam_noise[(long)b * a.seam_noise_bstride + np[j]] * a.seam_noise_strength;
                 }
+#pragma unroll
+                for (int c = 0; c < SEAM_MAXC; ++c)
+                    if (c < imgc) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const long o = ((long)b * imgc + c) * HWo + np[j];
+                            float gv = a.seam_gimg[o];
+                            if (a.seam_rgb_clamp >= 0.f && fabsf(a.seam_rgbpre[o]) > a.seam_rgb_clamp) gv = 0.f;
+                            gr[c][j] = gv;
+                        }
+                    }
             }
             __syncthreads();
 #pragma unroll
@@ -111,14 +134,26 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                     const int mr = i * 32 + (r & 3) + 8 * (r >> 2);
                     const float sc = prm[mw + mr];
                     float part = 0.f, dd = 0.f, mx = 0.f;
+                    float dwe[SEAM_MAXC];
+#pragma unroll
+                    for (int c = 0; c < SEAM_MAXC; ++c) dwe[c] = 0.f;
                     if (seam) {
                         const float dm0 = red[6][mw + mr], b0 = red[7][mw + mr];
+                        float we[SEAM_MAXC];
+#pragma unroll
+                        for (int c = 0; c < SEAM_MAXC; ++c) we[c] = c < imgc ? red[16 + c][mw + mr] : 0.f;
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
                             const float v = acc[i][j][r], y = xv[r][j];
                             const bool pos = y > 0.f;
                             const float sl = fabsf(y) >= s_cl ? 0.f : (pos ? s_pos : s_neg);
-                            const float g1 = v * sc * sl;
+                            float g = v * sc;
+                            if (imgc > 0) {      // (block-uniform: the up layers' own seam carries no ToRGB part)
+#pragma unroll
+                                for (int c = 0; c < SEAM_MAXC; ++c)
+                                    if (c < imgc) { g += we[c] * gr[c][j]; dwe[c] += gr[c][j] * y; }
+                            }
+                            const float g1 = g * sl;
                             dd += g1 * (y * (pos ? i_gain : i_neg) - b0 - nz0[j]);
                             const float gz = g1 * dm0;
                             o0[(long)mr * HWo + np[j]] = gz;
@@ -142,6 +177,14 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
 #pragma unroll
                         for (int o = 16; o > 0; o >>= 1) { dd += __shfl_xor(dd, o, 64); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
                         if (l31 == 0) { red[8 + wn][mw + mr] = dd; red[12 + wn][mw + mr] = mx; }
+#pragma unroll
+                        for (int c = 0; c < SEAM_MAXC; ++c)
+                            if (c < imgc) {
+                                float t = dwe[c];
+#pragma unroll
+                                for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                                if (l31 == 0) red[20 + c * 4 + wn][mw + mr] = t;
+                            }
                     }
                 }
             }
@@ -149,6 +192,12 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                 __syncthreads();
                 if (tid < MT) {
                     const long slot = ((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile;
+                    for (int c = 0; c < imgc; ++c) {
+                        float t = red[20 + c * 4][tid];
+#pragma unroll
+                        for (int w = 1; w < WN_; ++w) t += red[20 + c * 4 + w][tid];
+                        a.seam_dweff_part[(((long)b * imgc + c) * a.M + m0 + tid) * a.tiles_per_sample + ntile] = t;
+                    }
                     if (a.ds_part) {
                         float t = red[0][tid];
 #pragma unroll
@@ -255,6 +304,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                 const float dm0 = (seam && mok && a.seam_demod) ? a.seam_demod[(long)b * a.seam_demod_stride + m] : 1.f;
                 const float b0 = (seam && mok && a.seam_bias) ? a.seam_bias[m] : 0.f;
                 float part = 0.f, dd = 0.f, mx = 0.f;
+                float dwe[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const float v = acc[i][j][r];
@@ -262,6 +312,13 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                         const float y = xin_b ? xin_b[(long)m * HWout + npos[j]] : 0.f;
                         float g = v * sc;
                         if (seam) {
+                            for (int c = 0; c < a.seam_imgc && c < 4; ++c) {
+                                const long o = ((long)b * a.seam_imgc + c) * HWout + npos[j];
+                                float gv = a.seam_gimg[o];
+                                if (a.seam_rgb_clamp >= 0.f && fabsf(a.seam_rgbpre[o]) > a.seam_rgb_clamp) gv = 0.f;
+                                g += a.seam_wrgb[(long)c * a.M + m] * a.seam_srgb[(long)b * a.seam_srgb_stride + m] * gv;
+                                dwe[c] += gv * y;
+                            }
                             const float nz0 = a.seam_noise ? a.seam_noise[(long)b * a.seam_noise_bstride + npos[j]] * a.seam_noise_strength : 0.f;
                             const float g1 = g * la_act_bwd_from_y(y, a.seam_act, a.seam_alpha, a.seam_gain, a.seam_clamp);
                             dd += g1 * (la_act_inv(y, a.seam_act, a.seam_alpha, a.seam_gain) - b0 - nz0);
@@ -282,6 +339,14 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
 #pragma unroll
                     for (int o = 16; o > 0; o >>= 1) { dd += __shfl_xor(dd, o, 64); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
                     if (l31 == 0) { red[8 + wn][ml] = dd; red[12 + wn][ml] = mx; }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < a.seam_imgc) {
+                            float t = dwe[c];
+#pragma unroll
+                            for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                            if (l31 == 0) red[20 + c * 4 + wn][ml] = t;
+                        }
                 }
             }
         }
@@ -289,6 +354,12 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
             __syncthreads();
             if (tid < MT && m0 + tid < a.M) {
                 const long slot = ((long)b * a.M + m0 + tid) * a.tiles_per_sample + ntile;
+                for (int c = 0; seam && c < a.seam_imgc && c < 4; ++c) {
+                    float t = red[20 + c * 4][tid];
+#pragma unroll
+                    for (int w = 1; w < WN_; ++w) t += red[20 + c * 4 + w][tid];
+                    a.seam_dweff_part[(((long)b * a.seam_imgc + c) * a.M + m0 + tid) * a.tiles_per_sample + ntile] = t;
+                }
                 if (a.ds_part) {
                     float t = red[0][tid];
 #pragma unroll

@@ -28,6 +28,11 @@ struct LaSeamFuse {
     int act; float alpha, gain, clamp;
     float* ddn_part;
     float* pmax;
+    // ToRGB backward of that block (imgc > 0): image gradient, ToRGB pre-clamp output, weights [imgc][C], styles, partial outputs
+    int imgc;
+    const float* g_img; const float* rgb_pre; float rgb_clamp;
+    const float* wrgb; const float* s_rgb; int s_rgb_stride;
+    float* dweff_part;       // [B][imgc][cin][la_modconv_ds_tiles(res)]
 };
 int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, const float* wb, const void* wq, int precision, const float* s, int s_stride,
                          const float* xin, long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
@@ -37,7 +42,8 @@ int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, con
 // operand in one fused pass (FIR adjoint + scale + split + interleave)
 int la_modconv3x3_up2_bwd_ex(const float* gz, const float* gz_pmax, int gz_nseg, const float* wb, const void* wq, int precision, const float* s,
                              int s_stride, const float* xin, long xin_bstride, const float* fir_host, float* scratch, float* gx,
-                             float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, hipStream_t stream);
+                             float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, hipStream_t stream,
+                             const LaSeamFuse* seam = nullptr);      // seam of the block BELOW (its conv1 output is xin), incl. its ToRGB backward
 
 extern "C" {
 int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps, hipStream_t);

@@ -119,6 +119,16 @@ extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const f
                                     alpha, gain, clamp, fir_host, scratch, y, nullptr, ws, ws_bytes, B, cin, cout, res, stream, nullptr, 0);
 }
 
+static void set_seam(LaConvArgs& a, const LaSeamFuse* seam) {
+    if (!seam) return;
+    a.seam_demod = seam->demod; a.seam_demod_stride = seam->demod_stride; a.seam_bias = seam->bias;
+    a.seam_noise = seam->noise; a.seam_noise_bstride = seam->noise_bstride; a.seam_noise_strength = seam->noise_strength;
+    a.seam_act = seam->act; a.seam_alpha = seam->alpha; a.seam_gain = seam->gain; a.seam_clamp = seam->clamp;
+    a.seam_ddn_part = seam->ddn_part; a.seam_pmax = seam->pmax;
+    a.seam_imgc = seam->imgc; a.seam_gimg = seam->g_img; a.seam_rgbpre = seam->rgb_pre; a.seam_rgb_clamp = seam->rgb_clamp;
+    a.seam_wrgb = seam->wrgb; a.seam_srgb = seam->s_rgb; a.seam_srgb_stride = seam->s_rgb_stride; a.seam_dweff_part = seam->dweff_part;
+}
+
 int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, const float* wb, const void* wq, int precision, const float* s, int s_stride,
                          const float* xin, long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
                          int res, hipStream_t stream, const LaSeamFuse* seam) {
@@ -135,12 +145,7 @@ int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, con
     a.out_scale = s; a.oscale_stride = s_stride;
     a.xin = xin; a.xin_bstride = xin_bstride;
     a.ds_part = ds_part; a.tiles_per_sample = la_conv_tiles_per_sample(res, res);
-    if (seam) {
-        a.seam_demod = seam->demod; a.seam_demod_stride = seam->demod_stride; a.seam_bias = seam->bias;
-        a.seam_noise = seam->noise; a.seam_noise_bstride = seam->noise_bstride; a.seam_noise_strength = seam->noise_strength;
-        a.seam_act = seam->act; a.seam_alpha = seam->alpha; a.seam_gain = seam->gain; a.seam_clamp = seam->clamp;
-        a.seam_ddn_part = seam->ddn_part; a.seam_pmax = seam->pmax;
-    }
+    set_seam(a, seam);
     return la_conv_launch(a, stream);
 }
 
@@ -152,10 +157,14 @@ extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const voi
 
 int la_modconv3x3_up2_bwd_ex(const float* gz, const float* gz_pmax, int gz_nseg, const float* wb, const void* wq, int precision, const float* s,
                              int s_stride, const float* xin, long xin_bstride, const float* fir_host, float* scratch, float* gx,
-                             float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, hipStream_t stream) {
+                             float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, hipStream_t stream,
+                             const LaSeamFuse* seam) {
     LA_CHECK_ARG(gz && wb && gx && scratch && fir_host, "modconv_up2_bwd: null pointer");
+    LA_CHECK_ARG(!seam || (precision != LA_PREC_F32 && xin && seam->ddn_part && (seam->imgc == 0 || (seam->g_img && seam->wrgb && seam->s_rgb && seam->dweff_part))),
+                 "modconv_up2_bwd: the fused seam needs a 16-bit contraction, xin and its output buffers");
     const int hin = res / 2;
     LaConvArgs a; base_args(a);
+    set_seam(a, seam);
     a.wgt = wb; a.out = gx;
     a.precision = precision; a.wgt_bf16 = wq; a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(cin, cout, 9);
     a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = res + 1; a.Hout = a.Wout = a.Gy = a.Gx = hin;

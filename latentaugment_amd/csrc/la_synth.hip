@@ -53,6 +53,8 @@ struct la_synth {
     void* cws;
     size_t cws_bytes;
     float* pmax;             // [maxB][max channels]: plane maxima handed from a producing kernel to the next contraction (fp16 mode)
+    float* pmax3;            // the same for a block's conv1 output when ITS seam (incl. ToRGB backward) is fused into the epilogue of the
+                             // up-sampling layer's backward contraction of the block above
     float* pmax2;            // [maxB][cout][tiles]: plane maxima of an up-sampling layer's gz when its seam is fused into the epilogue of
                              // the conv1 backward contraction above it
     float* xs_fwd;           // [nconv][B]: fp16 operand scales of the forward contractions (from the clamp bound, one launch per pass)
@@ -112,7 +114,10 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
         T.rgb_pre = c.take(mb * h->imgc * hw);
         T.img = c.take(mb * h->imgc * hw);
         T.g_img = c.take(mb * h->imgc * hw);
-        T.dwep = c.take(mb * h->imgc * T.cin * (size_t)la_seam_slabs((long)hw));
+        {
+            const size_t sl0 = (size_t)la_seam_slabs((long)hw), t1 = (size_t)la_conv_tiles_per_sample(T.res, T.res);
+            T.dwep = c.take(mb * h->imgc * T.cin * (sl0 > t1 ? sl0 : t1));
+        }
         const size_t sl = mb * h->imgc * T.cin * (size_t)la_seam_slabs((long)hw);
         if (sl > dwe) dwe = sl;
     }
@@ -143,6 +148,12 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
             if (L.up) { const size_t n = mb * L.cout * (size_t)la_conv_tiles_per_sample(L.res, L.res); if (n > f2) f2 = n; }
         }
         h->pmax2 = c.take(f2 ? f2 : 16);
+        size_t f3 = 0;
+        for (int k = 0; k < h->nconv; ++k) {
+            const ConvLayer& L = h->conv[k];
+            if (!L.up) { const size_t n = mb * L.cout * (size_t)la_conv_tiles_per_sample(L.res, L.res); if (n > f3) f3 = n; }
+        }
+        h->pmax3 = c.take(f3 ? f3 : 16);
     }
     h->xs_fwd = c.take((size_t)h->nconv * mb);
     h->xs_bound = c.take((size_t)h->nconv + 16);
@@ -374,34 +385,40 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
         c.ds_part = L.dsp; c.ddn_part = L.ddnp; c.d = h->d_all + L.d_off; c.s = h->s_all + L.s_off; c.wsq = L.wsq;
         c.ds_out = h->ds_all + L.s_off; c.ntiles = ntiles; c.nslabs = nslabs; c.cin = L.cin; c.cout = L.cout;
     };
+    static const bool no_fuse = getenv("LA_NO_SEAM_FUSE") != nullptr;      // dev knobs: A/B of the fused seams on one box
+    static const bool no_fuse2 = getenv("LA_NO_SEAM2_FUSE") != nullptr;
+    const bool f16 = h->precision == LA_PREC_F32 ? false : h->precision == LA_PREC_F16X2;
+    bool seam2_done = false;      // this block's conv1 seam was already applied by the epilogue of the up layer's backward above it
     for (int k = h->nblocks - 1; k >= 0; --k) {
         const int res = 4 << k;
         const long HW = (long)res * res;
         RgbLayer& T = h->rgb[k];
         ConvLayer& L1 = h->conv[ci];
-        // ---- seam at conv1 output: ToRGB backward + act backward
-        LaSeamArgs s; memset(&s, 0, sizeof(s));
-        s.y = L1.y; s.gx_next = gx_next; s.gz = h->G0; s.HW = HW; s.C = L1.cout;
-        s.demod = h->d_all + L1.d_off; s.demod_stride = h->Dt; s.bias = L1.bias;
-        s.noise = L1.noise_used; s.noise_bstride = L1.noise_bstride; s.noise_strength = L1.noise_strength;
-        s.act = LA_ACT_LRELU; s.alpha = 0.2f; s.gain = sqrtf(2.f); s.clamp = h->clamp;
-        s.ddn_part = L1.ddnp;
-        s.g_img = gi; s.rgb_pre = T.rgb_pre; s.rgb_clamp = h->clamp; s.wrgb = T.weight;
-        s.s_rgb = h->s_all + T.s_off; s.s_stride = h->S; s.dweff_part = T.dwep;
-        const bool f16 = h->precision == LA_PREC_F16X2;
-        if (f16) s.pmax_out = h->pmax;      // the seam kernel leaves the plane maxima of gz for the contraction that follows
-        if ((rc = la_seam_backward(s, B, h->imgc, stream))) return rc;
         const int slabs = la_seam_slabs(HW);
+        const int tiles1 = la_modconv_ds_tiles(res);
+        const int nseg1 = seam2_done ? tiles1 : slabs;      // granularity of this block's ddn / dweff / plane-maxima partials
+        // ---- seam at conv1 output: ToRGB backward + act backward (top block, or when it was not fused above)
+        LaSeamArgs s;
+        if (!seam2_done) {
+            memset(&s, 0, sizeof(s));
+            s.y = L1.y; s.gx_next = gx_next; s.gz = h->G0; s.HW = HW; s.C = L1.cout;
+            s.demod = h->d_all + L1.d_off; s.demod_stride = h->Dt; s.bias = L1.bias;
+            s.noise = L1.noise_used; s.noise_bstride = L1.noise_bstride; s.noise_strength = L1.noise_strength;
+            s.act = LA_ACT_LRELU; s.alpha = 0.2f; s.gain = sqrtf(2.f); s.clamp = h->clamp;
+            s.ddn_part = L1.ddnp;
+            s.g_img = gi; s.rgb_pre = T.rgb_pre; s.rgb_clamp = h->clamp; s.wrgb = T.weight;
+            s.s_rgb = h->s_all + T.s_off; s.s_stride = h->S; s.dweff_part = T.dwep;
+            if (f16) s.pmax_out = h->pmax;      // the seam kernel leaves the plane maxima of gz for the contraction that follows
+            if ((rc = la_seam_backward(s, B, h->imgc, stream))) return rc;
+        }
         {
             LaStyleFinish::Rgb& r = fin.rgb[fin.nrgb++];
-            r.dweff_part = T.dwep; r.wrgb = T.weight; r.ds_out = h->ds_all + T.s_off; r.nslabs = slabs; r.C = T.cin;
+            r.dweff_part = T.dwep; r.wrgb = T.weight; r.ds_out = h->ds_all + T.s_off; r.nslabs = nseg1; r.C = T.cin;
         }
         // ---- conv1 backward-data (+ style-gradient partials).  16-bit modes, blocks above the first: the seam of the up-sampling
         // layer L0 (whose saved output is this contraction's xin) is applied in the same epilogue -- no separate pass over y0 and
         // the gradient; its demod-gradient partials and plane maxima come out per pixel tile.
-        static const bool no_fuse = getenv("LA_NO_SEAM_FUSE") != nullptr;      // dev knob: A/B of the fused seam on one box
         const bool fuse_seam = k > 0 && h->precision != LA_PREC_F32 && !no_fuse;
-        const int tiles1 = la_modconv_ds_tiles(res);
         {
             const float* xin = (k == 0) ? h->cst : h->conv[ci - 1].y;
             const long xin_bs = (k == 0) ? 0 : (long)L1.cin * HW;
@@ -413,10 +430,11 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
                 sf.act = LA_ACT_LRELU; sf.alpha = 0.2f; sf.gain = sqrtf(2.f); sf.clamp = h->clamp;
                 sf.ddn_part = h->conv[ci - 1].ddnp; sf.pmax = f16 ? h->pmax2 : nullptr;
             }
-            if ((rc = la_modconv3x3_bwd_ex(h->G0, f16 ? h->pmax : nullptr, slabs, L1.wb, L1.wqb, h->precision, h->s_all + L1.s_off, h->S, xin, xin_bs, h->G1,
-                                           L1.dsp, h->cws, h->cws_bytes, B, L1.cin, L1.cout, res, stream, fuse_seam ? &sf : nullptr)))
+            if ((rc = la_modconv3x3_bwd_ex(h->G0, f16 ? (seam2_done ? h->pmax3 : h->pmax) : nullptr, nseg1, L1.wb, L1.wqb, h->precision, h->s_all + L1.s_off,
+                                           h->S, xin, xin_bs, h->G1, L1.dsp, h->cws, h->cws_bytes, B, L1.cin, L1.cout, res, stream,
+                                           fuse_seam ? &sf : nullptr)))
                 return rc;
-            fin_conv(L1, tiles1, slabs);
+            fin_conv(L1, tiles1, nseg1);
         }
         --ci;
         if (k == 0) break;
@@ -432,24 +450,38 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
             if (f16) s.pmax_out = h->pmax;      // plane maxima of gz: bound for the operand scale of the fused FIR-adjoint + split pass
             if ((rc = la_seam_backward(s, B, 0, stream))) return rc;
         }
+        // ---- image gradient one level down: adjoint of upsample2d = FIR (flipped) + decimate 2, pad (1,1,1,1), gain 4
+        // (before the up layer's backward contraction: its epilogue may apply the block below's ToRGB backward)
+        RgbLayer& P = h->rgb[k - 1];
+        if ((rc = la_upfirdn2d_ex(gi, P.g_img, B, h->imgc, res, res, h->fir, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1, 1, 4.f, nullptr,
+                                  stream)))
+            return rc;
+        const bool fuse_seam2 = h->precision != LA_PREC_F32 && !no_fuse2;
         {
             const int hin = res / 2;
             const int tiles = la_modconv_ds_tiles(hin);
             const int nseg0 = fuse_seam ? tiles1 : slabs;
+            LaSeamFuse sf2; memset(&sf2, 0, sizeof(sf2));
+            if (fuse_seam2) {
+                // the conv1 seam of the block BELOW (its saved output is this contraction's xin), incl. its ToRGB backward
+                const ConvLayer& Lb = h->conv[ci - 1];
+                sf2.demod = h->d_all + Lb.d_off; sf2.demod_stride = h->Dt; sf2.bias = Lb.bias;
+                sf2.noise = Lb.noise_used; sf2.noise_bstride = Lb.noise_bstride; sf2.noise_strength = Lb.noise_strength;
+                sf2.act = LA_ACT_LRELU; sf2.alpha = 0.2f; sf2.gain = sqrtf(2.f); sf2.clamp = h->clamp;
+                sf2.ddn_part = Lb.ddnp; sf2.pmax = f16 ? h->pmax3 : nullptr;
+                sf2.imgc = h->imgc; sf2.g_img = P.g_img; sf2.rgb_pre = P.rgb_pre; sf2.rgb_clamp = h->clamp;
+                sf2.wrgb = P.weight; sf2.s_rgb = h->s_all + P.s_off; sf2.s_rgb_stride = h->S; sf2.dweff_part = P.dwep;
+            }
             if ((rc = la_modconv3x3_up2_bwd_ex(h->G1, f16 ? (fuse_seam ? h->pmax2 : h->pmax) : nullptr, nseg0, L0.wb, L0.wqb, h->precision, h->s_all + L0.s_off, h->S,
                                                h->conv[ci - 1].y, (long)L0.cin * hin * hin, h->fir, h->zT, h->G0, L0.dsp, h->cws, h->cws_bytes, B,
-                                               L0.cin, L0.cout, res, stream)))
+                                               L0.cin, L0.cout, res, stream, fuse_seam2 ? &sf2 : nullptr)))
                 return rc;
             fin_conv(L0, tiles, nseg0);
         }
         --ci;
         gx_next = h->G0;
-        // ---- image gradient one level down: adjoint of upsample2d = FIR (flipped) + decimate 2, pad (1,1,1,1), gain 4
-        RgbLayer& P = h->rgb[k - 1];
-        if ((rc = la_upfirdn2d_ex(gi, P.g_img, B, h->imgc, res, res, h->fir, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1, 1, 4.f, nullptr,
-                                  stream)))
-            return rc;
         gi = P.g_img;
+        seam2_done = fuse_seam2;
     }
     if ((rc = la_style_backward_all(fin, B, stream))) return rc;
     return la_affine_backward(h->st, h->ds_all, B, h->wdim, dws, h->num_ws, h->aff_part, stream);
