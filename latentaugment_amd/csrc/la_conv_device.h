@@ -129,61 +129,84 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) xv[r][j] = x0[(long)(i * 32 + (r & 3) + 8 * (r >> 2)) * HWo + np[j]];
                 }
+                // four rows at a time (r = 4g .. 4g+3 are four CONSECUTIVE channels), so that the per-row reductions over the 32
+                // lanes of a half-wave run as one multi-value butterfly: 2 + 1 exchanges halve the values per lane from 4 to 1
+                // (lane bits 4, 3 pick the row), 3 more finish it -- 6 shuffles per 4 rows and quantity instead of 20
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int mr = i * 32 + (r & 3) + 8 * (r >> 2);
-                    const float sc = prm[mw + mr];
-                    float part = 0.f, dd = 0.f, mx = 0.f;
-                    float dwe[SEAM_MAXC];
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float part[4], dd[4], mx[4], dwe[SEAM_MAXC][4];
 #pragma unroll
-                    for (int c = 0; c < SEAM_MAXC; ++c) dwe[c] = 0.f;
-                    if (seam) {
-                        const float dm0 = red[6][mw + mr], b0 = red[7][mw + mr];
-                        float we[SEAM_MAXC];
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = g4 * 4 + q;
+                        const int mr = i * 32 + q + 8 * g4;
+                        const float sc = prm[mw + mr];
+                        part[q] = dd[q] = mx[q] = 0.f;
 #pragma unroll
-                        for (int c = 0; c < SEAM_MAXC; ++c) we[c] = c < imgc ? red[16 + c][mw + mr] : 0.f;
+                        for (int c = 0; c < SEAM_MAXC; ++c) dwe[c][q] = 0.f;
+                        if (seam) {
+                            const float dm0 = red[6][mw + mr], b0 = red[7][mw + mr];
+                            float we[SEAM_MAXC];
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) {
-                            const float v = acc[i][j][r], y = xv[r][j];
-                            const bool pos = y > 0.f;
-                            const float sl = fabsf(y) >= s_cl ? 0.f : (pos ? s_pos : s_neg);
-                            float g = v * sc;
-                            if (imgc > 0) {      // (block-uniform: the up layers' own seam carries no ToRGB part)
+                            for (int c = 0; c < SEAM_MAXC; ++c) we[c] = c < imgc ? red[16 + c][mw + mr] : 0.f;
 #pragma unroll
-                                for (int c = 0; c < SEAM_MAXC; ++c)
-                                    if (c < imgc) { g += we[c] * gr[c][j]; dwe[c] += gr[c][j] * y; }
+                            for (int j = 0; j < NJ; ++j) {
+                                const float v = acc[i][j][r], y = xv[r][j];
+                                const bool pos = y > 0.f;
+                                const float sl = fabsf(y) >= s_cl ? 0.f : (pos ? s_pos : s_neg);
+                                float g = v * sc;
+                                if (imgc > 0) {      // (block-uniform: the up layers' own seam carries no ToRGB part)
+#pragma unroll
+                                    for (int c = 0; c < SEAM_MAXC; ++c)
+                                        if (c < imgc) { g += we[c] * gr[c][j]; dwe[c][q] += gr[c][j] * y; }
+                                }
+                                const float g1 = g * sl;
+                                dd[q] += g1 * (y * (pos ? i_gain : i_neg) - b0 - nz0[j]);
+                                const float gz = g1 * dm0;
+                                o0[(long)mr * HWo + np[j]] = gz;
+                                mx[q] = fmaxf(mx[q], fabsf(gz));
+                                part[q] += v * y;
                             }
-                            const float g1 = g * sl;
-                            dd += g1 * (y * (pos ? i_gain : i_neg) - b0 - nz0[j]);
-                            const float gz = g1 * dm0;
-                            o0[(long)mr * HWo + np[j]] = gz;
-                            mx = fmaxf(mx, fabsf(gz));
-                            part += v * y;
-                        }
-                    } else {
+                        } else {
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) {
-                            const float v = acc[i][j][r];
-                            o0[(long)mr * HWo + np[j]] = v * sc;
-                            if (x0) part += v * xv[r][j];
+                            for (int j = 0; j < NJ; ++j) {
+                                const float v = acc[i][j][r];
+                                o0[(long)mr * HWo + np[j]] = v * sc;
+                                if (x0) part[q] += v * xv[r][j];
+                            }
                         }
                     }
+                    // lane (bit4, bit3) ends up with row 2*bit4 + bit3 of the group
+                    const bool up16 = (l31 & 16) != 0, up8 = (l31 & 8) != 0;
+                    const int mrow = mw + i * 32 + 8 * g4 + (up16 ? 2 : 0) + (up8 ? 1 : 0);
+                    const bool writer = (l31 & 7) == 0;
+                    auto bfly_sum = [&](float (&v)[4]) {
+                        const float k0 = up16 ? v[2] : v[0], s0 = up16 ? v[0] : v[2];
+                        const float k1 = up16 ? v[3] : v[1], s1 = up16 ? v[1] : v[3];
+                        const float a0 = k0 + __shfl_xor(s0, 16, 64), a1 = k1 + __shfl_xor(s1, 16, 64);
+                        float t = (up8 ? a1 : a0) + __shfl_xor(up8 ? a0 : a1, 8, 64);
+                        t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 1, 64);
+                        return t;
+                    };
+                    auto bfly_max = [&](float (&v)[4]) {
+                        const float k0 = up16 ? v[2] : v[0], s0 = up16 ? v[0] : v[2];
+                        const float k1 = up16 ? v[3] : v[1], s1 = up16 ? v[1] : v[3];
+                        const float a0 = fmaxf(k0, __shfl_xor(s0, 16, 64)), a1 = fmaxf(k1, __shfl_xor(s1, 16, 64));
+                        float t = fmaxf(up8 ? a1 : a0, __shfl_xor(up8 ? a0 : a1, 8, 64));
+                        t = fmaxf(t, __shfl_xor(t, 4, 64)); t = fmaxf(t, __shfl_xor(t, 2, 64)); t = fmaxf(t, __shfl_xor(t, 1, 64));
+                        return t;
+                    };
                     if (a.ds_part) {
-#pragma unroll
-                        for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-                        if (l31 == 0) red[wn][mw + mr] = part;
+                        const float t = bfly_sum(part);
+                        if (writer) red[wn][mrow] = t;
                     }
                     if (seam) {
-#pragma unroll
-                        for (int o = 16; o > 0; o >>= 1) { dd += __shfl_xor(dd, o, 64); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
-                        if (l31 == 0) { red[8 + wn][mw + mr] = dd; red[12 + wn][mw + mr] = mx; }
+                        const float t = bfly_sum(dd), m = bfly_max(mx);
+                        if (writer) { red[8 + wn][mrow] = t; red[12 + wn][mrow] = m; }
 #pragma unroll
                         for (int c = 0; c < SEAM_MAXC; ++c)
                             if (c < imgc) {
-                                float t = dwe[c];
-#pragma unroll
-                                for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-                                if (l31 == 0) red[20 + c * 4 + wn][mw + mr] = t;
+                                const float u = bfly_sum(dwe[c]);
+                                if (writer) red[20 + c * 4 + wn][mrow] = u;
                             }
                     }
                 }
