@@ -573,7 +573,8 @@ int la_style_backward_all(const LaStyleFinish& fin, int B, hipStream_t stream) {
     LaStyleFinish f = fin;
     LaRowSegs g;
     g.nseg = 0; g.row0[0] = 0;
-    auto seg = [&](float* p, long rows, int n) { g.ptr[g.nseg] = p; g.n[g.nseg] = n; g.row0[g.nseg + 1] = g.row0[g.nseg] + rows; ++g.nseg; };
+    // (rows of a single partial are already their own sum: nothing to do)
+    auto seg = [&](float* p, long rows, int n) { if (n <= 1) return; g.ptr[g.nseg] = p; g.n[g.nseg] = n; g.row0[g.nseg + 1] = g.row0[g.nseg] + rows; ++g.nseg; };
     int cblk = 0, rblk = 0, max_cout = 0;
     for (int l = 0; l < f.nconv; ++l) {
         LaStyleFinish::Conv& L = f.conv[l];
@@ -587,8 +588,8 @@ int la_style_backward_all(const LaStyleFinish& fin, int B, hipStream_t stream) {
         seg(T.dweff_part, (long)B * f.imgc * T.C, T.nslabs);
         T.blk0 = rblk; rblk += la_cdiv(T.C, 256);
     }
-    if (g.nseg == 0) return LA_OK;
-    hipLaunchKernelGGL(la_rows_sum_all_kernel, dim3((unsigned)la_cdiv(g.row0[g.nseg], 4)), dim3(256), 0, stream, g);
+    if (g.nseg > 0)
+        hipLaunchKernelGGL(la_rows_sum_all_kernel, dim3((unsigned)la_cdiv(g.row0[g.nseg], 4)), dim3(256), 0, stream, g);
     if (f.nconv) hipLaunchKernelGGL(la_style_bwd_conv_all_kernel, dim3(cblk, B), dim3(256), (max_cout + 256) * sizeof(float), stream, f);
     if (f.nrgb) hipLaunchKernelGGL(la_style_bwd_rgb_all_kernel, dim3(rblk, B), dim3(256), 0, stream, f);
     LA_CHECK_LAUNCH();
