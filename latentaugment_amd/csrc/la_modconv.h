@@ -15,9 +15,11 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
                              const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                              const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
                              float* scratch, float* y, float* y_pmax, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
-                             hipStream_t stream, const float* xscale = nullptr, int scratch_pitch = 0);
-// scratch_pitch (floats, 0 = dense (res+1)): row pitch of the transposed-conv intermediate; a multiple of 4 lets the FIR run its
-// 16-byte vector kernel (the scratch then holds B * cout * (res+1) * scratch_pitch floats)
+                             hipStream_t stream, const float* xscale = nullptr, int scratch_pitch = 0, int scratch_xhalf = 0);
+// scratch_pitch / scratch_xhalf (floats; both 0 = dense (res+1)-wide rows, or both set): COLUMN-PLANAR rows of the transposed-conv
+// intermediate -- the even output columns of a row at [0, res/2 + 1), the odd ones from scratch_xhalf on (a multiple of 4,
+// scratch_pitch >= scratch_xhalf + res/2) -- so that every output phase of the transposed conv stores contiguous runs and the FIR
+// runs its vector kernel (the scratch then holds B * cout * (res+1) * scratch_pitch floats)
 // xscale (optional, [B]): preset power-of-two fp16 operand scale of the input (e.g. from the clamp bound of the producing layer)
 // Backward seam of the layer that produced `xin`, applied inside the backward contraction's epilogue (LaConvArgs::seam_*):
 // its demod / bias / noise / activation, and where its demod-gradient partials and plane maxima go ([B][cin][la_modconv_ds_tiles(res)]).

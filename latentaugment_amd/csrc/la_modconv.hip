@@ -55,9 +55,11 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
                              const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                              const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
                              float* scratch, float* y, float* y_pmax, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
-                             hipStream_t stream, const float* xscale, int scratch_pitch) {
+                             hipStream_t stream, const float* xscale, int scratch_pitch, int scratch_xhalf) {
     LA_CHECK_ARG(x && wf && y && scratch && fir_host, "modconv_up2_fwd: null pointer");
     LA_CHECK_ARG(scratch_pitch == 0 || scratch_pitch >= res + 1, "modconv_up2_fwd: scratch pitch smaller than a row");
+    LA_CHECK_ARG((scratch_xhalf == 0 && scratch_pitch == 0) || (scratch_xhalf >= res / 2 + 1 && scratch_pitch >= scratch_xhalf + res / 2),
+                 "modconv_up2_fwd: bad column-planar scratch layout");
     LA_CHECK_ARG(res >= 2 && res % 2 == 0, "modconv_up2_fwd: output resolution must be even");
     // transposed stride-2 conv as 4 output phases: row Y = 2*qy + py receives taps ky with (Y - ky) even
     const int hin = res / 2;
@@ -69,6 +71,7 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
     a.B = B; a.C = cin; a.M = cout; a.Hin = a.Win = hin; a.Hout = a.Wout = res + 1;
     a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW;
     if (scratch_pitch > 0) { a.out_pitch = scratch_pitch; a.out_plane = (long)scratch_pitch * (res + 1); }      // padded (2h+1)-wide rows
+    if (scratch_xhalf > 0) { a.out_sx = 1; a.Wout = scratch_pitch; }      // column-planar rows: phase px writes the contiguous run from px * xhalf
     if (precision == LA_PREC_F16X2) a.acc_scale_x = xscale;      // preset operand scale (bound-based): no absmax pass
     if (precision != LA_PREC_F32) {
         // split the (modulated) input once for the four phase launches
@@ -81,7 +84,7 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
     int np = 0;
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
-            a.out_oy = py; a.out_ox = px;
+            a.out_oy = py; a.out_ox = scratch_xhalf > 0 ? px * scratch_xhalf : px;
             a.Gy = py ? hin : hin + 1; a.Gx = px ? hin : hin + 1;
             int nt = 0;
             for (int ky = py; ky < 3; ky += 2)
@@ -91,7 +94,7 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
             a.ntaps = nt;
             if (merged) {
                 LaConvArgs::Phase& P = a.ph[np++];
-                P.Gy = a.Gy; P.Gx = a.Gx; P.out_oy = py; P.out_ox = px; P.ntaps = nt;
+                P.Gy = a.Gy; P.Gx = a.Gx; P.out_oy = py; P.out_ox = a.out_ox; P.ntaps = nt;
                 for (int t = 0; t < nt; ++t) { P.tap_dy[t] = a.tap_dy[t]; P.tap_dx[t] = a.tap_dx[t]; P.tap_w[t] = a.tap_w[t]; }
                 continue;
             }
@@ -107,7 +110,7 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
     // FIR with pad (1,1,1,1) and gain up^2 = 4 (conv2d_resample.py:119-126), then the layer epilogue
     return la_upfirdn2d_modconv_epilogue(scratch, y, B, cout, res + 1, res + 1, fir_host, 4, 4, 1, 1, 1, 1, 4.f, d, d_stride,
                                          noise, noise_bstride, noise_strength, bias, act, alpha, gain, clamp, stream, y_pmax,
-                                         scratch_pitch, (long)scratch_pitch * (res + 1));
+                                         scratch_pitch, (long)scratch_pitch * (res + 1), scratch_xhalf);
 }
 
 extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,

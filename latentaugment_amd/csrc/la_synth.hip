@@ -76,6 +76,8 @@ struct Carver {
     }
 };
 
+// column-planar intermediate of an up layer (la_modconv3x3_up2_fwd_ex): floats from the start of a row to its odd-column run
+static inline int zt_xhalf(int res) { return (res / 2 + 1 + 3) & ~3; }
 static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
     Carver c{(char*)workspace, 0, cap};
     const size_t mb = h->maxB;
@@ -91,8 +93,8 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
         L.y = c.take(mb * L.cout * hw);
         if (mb * L.cout * hw > gmax) gmax = mb * L.cout * hw;
         if (mb * L.cin * hw > gmax && !L.up) gmax = mb * L.cin * hw;
-        if (L.up) {      // transposed-conv intermediate, rows padded to a multiple of 4 floats (zt_pitch)
-            const size_t z = mb * L.cout * (size_t)(L.res + 1) * (size_t)((L.res + 1 + 3) & ~3);
+        if (L.up) {      // transposed-conv intermediate, column-planar rows (zt_xhalf)
+            const size_t z = mb * L.cout * (size_t)(L.res + 1) * (size_t)(2 * zt_xhalf(L.res));
             if (z > ztmax) ztmax = z;
         }
         const int gin = L.up ? L.res / 2 : L.res;   // grid of the backward-data conv
@@ -315,6 +317,9 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
     h->lastB = B;
     const bool f16 = h->precision == LA_PREC_F16X2;
     const bool bound_scale = f16 && h->clamp > 0.f;
+    // scratch layout of the up layers: dense interleaved rows (plane maxima wanted: scalar FIR; dev knob LA_NO_ZT_PITCH) or column-planar
+    static const bool zt_knob_dense = getenv("LA_NO_ZT_PITCH") != nullptr;
+    const bool zt_dense = (f16 && !bound_scale) || zt_knob_dense;
     if (bound_scale && (rc = la_xscale_from_bounds(h->dt, h->s_all, h->S, h->xs_bound, h->xs_fwd, B, stream))) return rc;
     int ci = 0;
     const float* x = h->cst;
@@ -342,7 +347,7 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
                                               L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f,
                                               sq2, h->clamp, h->fir, h->zT, L.y, (f16 && !bound_scale) ? h->pmax : nullptr, h->cws, h->cws_bytes, B, L.cin,
                                               L.cout, res, stream, bound_scale ? h->xs_fwd + (long)ci * B : nullptr,
-                                              ((f16 && !bound_scale) || getenv("LA_NO_ZT_PITCH")) ? 0 : (res + 1 + 3) & ~3);      // (plane maxima come from the scalar FIR kernel only)
+                                              zt_dense ? 0 : 2 * zt_xhalf(res), zt_dense ? 0 : zt_xhalf(res));      // (plane maxima come from the scalar FIR kernel only)
                 x_pmax = (f16 && !bound_scale) ? h->pmax : nullptr;
                 x_nseg = la_fir4x4_segments(res, res);
             }

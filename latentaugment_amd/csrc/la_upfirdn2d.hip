@@ -21,6 +21,7 @@ struct FirArgs {
     const float* addend;         // optional same-shape tensor added to the result (skip connection), epi 0 only
     float* pmax;                 // optional [P][la_fir4x4_segments(Hout, Wout)]: partial max |out| per plane, 4x4 stride-1 kernel only
     int in_pitch; long in_plane; // 0 = dense; row pitch / plane stride of `in` in floats (vector kernel: multiples of 4)
+    int in_xhalf;                // > 0: COLUMN-PLANAR rows -- the even columns of a row at [0, ceil(Win/2)), the odd ones from in_xhalf on
 };
 
 __global__ __launch_bounds__(256) void la_upfirdn2d_kernel(FirArgs a) {
@@ -154,7 +155,7 @@ static int fir_fill(FirArgs& a, const float* in, float* out, int B, int C, int H
     *Wout = (upW - fw + dnx) / dnx;   // upfirdn2d.cpp:35-36
     *Hout = (upH - fh + dny) / dny;
     a.in = in; a.out = out; a.P = B * C; a.C = C; a.pmax = nullptr;
-    a.in_pitch = Win; a.in_plane = (long)Hin * Win;
+    a.in_pitch = Win; a.in_plane = (long)Hin * Win; a.in_xhalf = 0;
     a.Hin = Hin; a.Win = Win; a.Hout = *Hout; a.Wout = *Wout;
     a.upx = upx; a.upy = upy; a.dnx = dnx; a.dny = dny; a.padx0 = padx0; a.pady0 = pady0;
     a.fw = fw; a.fh = fh;
@@ -168,88 +169,95 @@ static int fir_fill(FirArgs& a, const float* in, float* out, int B, int C, int H
     return LA_OK;
 }
 
-// Vector form of the 4x4 stride-1 FIR (+ layer epilogue) for a SEPARABLE filter f = fy (x) fx (setup_filter's outer product),
-// outputs with W % 4 == 0 and a 16-byte aligned, padded input (in_pitch % 4 == 0).  Thread = 4 columns walking FIRV_ROWS rows with
-// a rolling window: per input row 3 aligned 16-byte loads (next row prefetched), a horizontal 4-tap pass (4 values), a vertical
-// 4-tap pass over the last four horizontal rows -> one 16-byte store.  8 MACs and 0.9 load instructions per output at ~50
-// registers (full occupancy); the scalar kernel above: 16 MACs and 5.5 dword loads per output, bound by load issue.
-// out[y][x] = sum_{a,b} fy[a] fx[b] * in[y + a - 1][x + b - 1]  (pad 1: the FIR after a transposed stride-2 conv).
-#define FIRV_ROWS 16
-template <int EPI>
-__global__ __launch_bounds__(256) void la_fir4x4_s1v_kernel(FirArgs a, float4 fx, float4 fy) {
-    const int w4 = a.Wout >> 2;                                   // 4-column groups per row
-    const int tw = w4 < 64 ? w4 : 64;                             // groups per wave row (power of two: W is)
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int xg = blockIdx.x * 64 + (lane % tw);
-    const int strip = (blockIdx.y * 4 + wid) * (64 / tw) + lane / tw;
-    const int x0 = xg * 4, y0 = strip * FIRV_ROWS;
-    if (xg >= w4 || y0 >= a.Hout) return;
+// Vector form of the 4x4 stride-1 pad-1 FIR (+ layer epilogue) for a SEPARABLE filter f = fy (x) fx (setup_filter's outer product)
+// on COLUMN-PLANAR input rows (FirArgs::in_xhalf): the transposed stride-2 conv that produces the (2h+1)-wide intermediate writes
+// each output phase as contiguous runs (even columns | odd columns) instead of 4-byte stores at stride 8 (128 -> 313 us on the
+// 8x128x257^2 launch), and this kernel re-interleaves on the fly.
+//     out[y][x] = sum_{a,b} fy[a] fx[b] * in[y + a - 1][x + b - 1]
+// Work item = (plane, ROWS-row strip, 4-column group), groups fastest, so that small planes share a workgroup; per input row two
+// 8-byte loads (even / odd plane) + three neighbour dwords (L1 hits), 7 columns -> 4 horizontal results, then a vertical 4-tap
+// pass over a rolling window of the last four horizontal rows with two input rows in flight: 8 MACs per output (the scalar kernel
+// above: 16 MACs and 5.5 dword loads per output).  Measured at 8x128x256^2: 133 us; an 8-column form with 16-byte loads (113
+// registers) 147 us; the same kernel on column-interleaved rows with three 16-byte loads per row 127 us.
+template <int EPI, int ROWS>
+__global__ __launch_bounds__(256) void la_fir4x4_s1p_kernel(FirArgs a, float4 fx, float4 fy) {
+    const int w4 = a.Wout >> 2;
+    const int strips = (a.Hout + ROWS - 1) / ROWS;
+    const int per_plane = w4 * strips;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int p = (int)(gid / per_plane);
+    if (p >= a.P) return;
+    const int within = (int)(gid - (long)p * per_plane);
+    const int strip = within / w4, xg = within - strip * w4;
+    const int x0 = xg * 4, q2 = xg * 2, y0 = strip * ROWS;
     const long HWout = (long)a.Hout * a.Wout;
-    const bool lo = x0 >= 4;
-    // columns x0 - 1 .. x0 + 5 of an input row -> the horizontal pass of the 4 output columns; columns >= Win are pad
-    const bool ok4 = x0 + 4 < a.Win, ok5 = x0 + 5 < a.Win, ok3 = x0 + 3 < a.Win, ok2 = x0 + 2 < a.Win, ok1 = x0 + 1 < a.Win;
-    struct Row { float4 l, m, h; };
-    auto load_row = [&](const float* ip, int iy) {
+    const int ne = (a.Win + 1) >> 1, no = a.Win >> 1;
+    const bool okm = q2 > 0, oke = q2 + 2 < ne, oko = q2 + 2 < no;
+    struct Row { float2 e, o; float om1, e2, o2; };
+    const float* ip = a.in + (long)p * a.in_plane + q2;
+    auto load_row = [&](int iy) {
         Row r;
-        r.l = r.m = r.h = make_float4(0.f, 0.f, 0.f, 0.f);
+        r.e = r.o = make_float2(0.f, 0.f);
+        r.om1 = r.e2 = r.o2 = 0.f;
         if (iy >= 0 && iy < a.Hin) {
-            const float* rp = ip + (long)iy * a.in_pitch + x0;
-            if (lo) r.l = *reinterpret_cast<const float4*>(rp - 4);
-            r.m = *reinterpret_cast<const float4*>(rp);
-            r.h = *reinterpret_cast<const float4*>(rp + 4);       // (x0 + 7 < in_pitch always: in_pitch >= Wout + 4)
+            const float* rp = ip + (long)iy * a.in_pitch;
+            r.e = *reinterpret_cast<const float2*>(rp);
+            r.o = *reinterpret_cast<const float2*>(rp + a.in_xhalf);
+            if (okm) r.om1 = rp[a.in_xhalf - 1];
+            if (oke) r.e2 = rp[2];
+            if (oko) r.o2 = rp[a.in_xhalf + 2];
         }
         return r;
     };
     auto hpass = [&](const Row& r) {
-        const float c_1 = r.l.w, c0 = r.m.x, c1 = ok1 ? r.m.y : 0.f, c2 = ok2 ? r.m.z : 0.f, c3 = ok3 ? r.m.w : 0.f,
-                    c4 = ok4 ? r.h.x : 0.f, c5 = ok5 ? r.h.y : 0.f;
+        // image columns x0 - 1 .. x0 + 5
+        const float c[7] = {r.om1, r.e.x, r.o.x, r.e.y, r.o.y, r.e2, r.o2};
         float4 h;
-        h.x = fx.x * c_1 + fx.y * c0 + fx.z * c1 + fx.w * c2;
-        h.y = fx.x * c0 + fx.y * c1 + fx.z * c2 + fx.w * c3;
-        h.z = fx.x * c1 + fx.y * c2 + fx.z * c3 + fx.w * c4;
-        h.w = fx.x * c2 + fx.y * c3 + fx.z * c4 + fx.w * c5;
+        h.x = fx.x * c[0] + fx.y * c[1] + fx.z * c[2] + fx.w * c[3];
+        h.y = fx.x * c[1] + fx.y * c[2] + fx.z * c[3] + fx.w * c[4];
+        h.z = fx.x * c[2] + fx.y * c[3] + fx.z * c[4] + fx.w * c[5];
+        h.w = fx.x * c[3] + fx.y * c[4] + fx.z * c[5] + fx.w * c[6];
         return h;
     };
-    for (int p = blockIdx.z; p < a.P; p += gridDim.z) {
-        const float* ip = a.in + (long)p * a.in_plane;
-        float dm = 1.f, bv = 0.f;
-        if (EPI == 1) {
-            const int b = p / a.C, c = p - b * a.C;
-            if (a.demod) dm = a.demod[(long)b * a.demod_stride + c];
-            if (a.bias) bv = a.bias[c];
-        }
-        const float* nzp = (EPI == 1 && a.noise) ? a.noise + (long)(p / a.C) * a.noise_bstride : nullptr;
-        // window: h0..h2 = horizontal passes of input rows y - 1, y, y + 1; each step adds row y + 2 and emits output row y
-        float4 h0 = hpass(load_row(ip, y0 - 1)), h1 = hpass(load_row(ip, y0)), h2 = hpass(load_row(ip, y0 + 1));
-        Row nxt = load_row(ip, y0 + 2);
-        const int y1 = y0 + FIRV_ROWS < a.Hout ? y0 + FIRV_ROWS : a.Hout;
+    float dm = 1.f, bv = 0.f;
+    const int b = p / a.C;
+    if (EPI == 1) {
+        const int c = p - b * a.C;
+        if (a.demod) dm = a.demod[(long)b * a.demod_stride + c];
+        if (a.bias) bv = a.bias[c];
+    }
+    const float* nzp = (EPI == 1 && a.noise) ? a.noise + (long)b * a.noise_bstride : nullptr;
+    const Row r0 = load_row(y0 - 1), r1 = load_row(y0), r2 = load_row(y0 + 1);
+    Row n0 = load_row(y0 + 2), n1 = load_row(y0 + 3);
+    float4 h0 = hpass(r0), h1 = hpass(r1), h2 = hpass(r2);
+    const int y1 = y0 + ROWS < a.Hout ? y0 + ROWS : a.Hout;
 #pragma unroll 4
-        for (int y = y0; y < y1; ++y) {
-            const float4 h3 = hpass(nxt);
-            nxt = load_row(ip, y + 3);                            // prefetch the row of the next step
-            float4 o;
-            o.x = fy.x * h0.x + fy.y * h1.x + fy.z * h2.x + fy.w * h3.x;
-            o.y = fy.x * h0.y + fy.y * h1.y + fy.z * h2.y + fy.w * h3.y;
-            o.z = fy.x * h0.z + fy.y * h1.z + fy.z * h2.z + fy.w * h3.z;
-            o.w = fy.x * h0.w + fy.y * h1.w + fy.z * h2.w + fy.w * h3.w;
-            h0 = h1; h1 = h2; h2 = h3;
-            const long pos = (long)y * a.Wout + x0;
-            if (EPI == 1) {
-                float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (nzp) {
-                    nz = *reinterpret_cast<const float4*>(nzp + pos);
-                    nz.x *= a.noise_strength; nz.y *= a.noise_strength; nz.z *= a.noise_strength; nz.w *= a.noise_strength;
-                }
-                o.x = la_act_fwd(o.x * dm + bv + nz.x, a.act, a.alpha, a.gain, a.clamp);
-                o.y = la_act_fwd(o.y * dm + bv + nz.y, a.act, a.alpha, a.gain, a.clamp);
-                o.z = la_act_fwd(o.z * dm + bv + nz.z, a.act, a.alpha, a.gain, a.clamp);
-                o.w = la_act_fwd(o.w * dm + bv + nz.w, a.act, a.alpha, a.gain, a.clamp);
-            } else if (a.addend) {
-                const float4 ad = *reinterpret_cast<const float4*>(a.addend + (long)p * HWout + pos);
-                o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+    for (int y = y0; y < y1; ++y) {
+        const float4 h3 = hpass(n0);
+        n0 = n1;
+        n1 = load_row(y + 4);
+        float4 o;
+        o.x = fy.x * h0.x + fy.y * h1.x + fy.z * h2.x + fy.w * h3.x;
+        o.y = fy.x * h0.y + fy.y * h1.y + fy.z * h2.y + fy.w * h3.y;
+        o.z = fy.x * h0.z + fy.y * h1.z + fy.z * h2.z + fy.w * h3.z;
+        o.w = fy.x * h0.w + fy.y * h1.w + fy.z * h2.w + fy.w * h3.w;
+        h0 = h1; h1 = h2; h2 = h3;
+        const long pos = (long)y * a.Wout + x0;
+        if (EPI == 1) {
+            float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nzp) {
+                nz = *reinterpret_cast<const float4*>(nzp + pos);
+                nz.x *= a.noise_strength; nz.y *= a.noise_strength; nz.z *= a.noise_strength; nz.w *= a.noise_strength;
             }
-            *reinterpret_cast<float4*>(a.out + (long)p * HWout + pos) = o;
+            o.x = la_act_fwd(o.x * dm + bv + nz.x, a.act, a.alpha, a.gain, a.clamp);
+            o.y = la_act_fwd(o.y * dm + bv + nz.y, a.act, a.alpha, a.gain, a.clamp);
+            o.z = la_act_fwd(o.z * dm + bv + nz.z, a.act, a.alpha, a.gain, a.clamp);
+            o.w = la_act_fwd(o.w * dm + bv + nz.w, a.act, a.alpha, a.gain, a.clamp);
+        } else if (a.addend) {
+            const float4 ad = *reinterpret_cast<const float4*>(a.addend + (long)p * HWout + pos);
+            o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
         }
+        *reinterpret_cast<float4*>(a.out + (long)p * HWout + pos) = o;
     }
 }
 
@@ -279,20 +287,24 @@ static int fir_launch(const FirArgs& a, hipStream_t stream) {
 static int fir_launch_inner(const FirArgs& a, hipStream_t stream) {
     const bool s1 = a.upx == 1 && a.upy == 1 && a.dnx == 1 && a.dny == 1 && a.fw == 4 && a.fh == 4;
     float fx[4], fy[4];
-    if (s1 && !a.pmax && a.padx0 == 1 && a.pady0 == 1 && a.Wout % 4 == 0 && (a.Wout & (a.Wout - 1)) == 0 && a.in_pitch % 4 == 0 && a.in_plane % 4 == 0 &&
-        a.in_pitch >= a.Wout + 4 && a.Win <= a.Wout + 1 && (((size_t)a.in | (size_t)a.out | (size_t)a.noise | (size_t)a.addend) & 15) == 0 &&
-        (a.noise_bstride % 4) == 0 && fir_separable(a.f, fx, fy)) {
-        const int w4 = a.Wout / 4, tw = w4 < 64 ? w4 : 64;
-        const int strips = la_cdiv(a.Hout, FIRV_ROWS), per_wg = 4 * (64 / tw);
-        dim3 g(la_cdiv(w4, 64), la_cdiv(strips, per_wg), a.P < 8192 ? a.P : 8192);
-        LA_CHECK_ARG(g.y <= 65535, "upfirdn2d: output too tall");
+    if (a.in_xhalf > 0) {      // column-planar rows: only the planar vector kernel reads them
+        LA_CHECK_ARG(s1 && !a.pmax && a.padx0 == 1 && a.pady0 == 1 && a.Wout % 4 == 0 && a.Win == a.Wout + 1 &&
+                         a.in_pitch % 4 == 0 && a.in_plane % 4 == 0 && a.in_xhalf % 4 == 0 && a.in_xhalf >= (a.Win + 1) / 2 &&
+                         a.in_pitch >= a.in_xhalf + a.Win / 2 && (a.noise_bstride % 4) == 0 &&
+                         (((size_t)a.in | (size_t)a.out | (size_t)a.noise | (size_t)a.addend) & 15) == 0 && fir_separable(a.f, fx, fy),
+                     "upfirdn2d: column-planar input needs the 4x4 pad-1 separable FIR on aligned planes (W % 4 == 0, no plane maxima)");
+        // rows per thread: 16 where that still leaves every SIMD >= 4 waves' worth of threads, else 4 (short serial chains on small planes)
+        const int rows = (long)a.P * (a.Wout / 4) * la_cdiv(a.Hout, 16) >= 256l * 4 * 4 * 64 ? 16 : 4;
+        const long items = (long)a.P * (a.Wout / 4) * la_cdiv(a.Hout, rows);
+        LA_CHECK_ARG(items < (1l << 38), "upfirdn2d: too many planes");
+        dim3 g((unsigned)((items + 255) / 256));
         const float4 vx = make_float4(fx[0], fx[1], fx[2], fx[3]), vy = make_float4(fy[0], fy[1], fy[2], fy[3]);
-        if (a.epi == 1) hipLaunchKernelGGL(la_fir4x4_s1v_kernel<1>, g, dim3(256), 0, stream, a, vx, vy);
-        else hipLaunchKernelGGL(la_fir4x4_s1v_kernel<0>, g, dim3(256), 0, stream, a, vx, vy);
+        if (a.epi == 1) { if (rows == 4) hipLaunchKernelGGL((la_fir4x4_s1p_kernel<1, 4>), g, dim3(256), 0, stream, a, vx, vy); else hipLaunchKernelGGL((la_fir4x4_s1p_kernel<1, 16>), g, dim3(256), 0, stream, a, vx, vy); }
+        else { if (rows == 4) hipLaunchKernelGGL((la_fir4x4_s1p_kernel<0, 4>), g, dim3(256), 0, stream, a, vx, vy); else hipLaunchKernelGGL((la_fir4x4_s1p_kernel<0, 16>), g, dim3(256), 0, stream, a, vx, vy); }
         LA_CHECK_LAUNCH();
         return LA_OK;
     }
-    LA_CHECK_ARG(a.in_pitch == a.Win && a.in_plane == (long)a.Hin * a.Win, "upfirdn2d: a padded input layout needs the vector 4x4 kernel (W % 4 == 0, no plane maxima)");
+    LA_CHECK_ARG(a.in_pitch == a.Win && a.in_plane == (long)a.Hin * a.Win, "upfirdn2d: a padded input layout needs the column-planar vector 4x4 kernel");
     if (a.upx == 1 && a.upy == 1 && a.dnx == 1 && a.dny == 1 && a.fw == 4 && a.fh == 4) {
         dim3 g(la_cdiv(a.Wout, 64), la_cdiv(a.Hout, 4 * FIR_ROWS), a.P < 4096 ? a.P : 4096);
         LA_CHECK_ARG(g.y <= 65535, "upfirdn2d: output too tall");
@@ -325,7 +337,7 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
                                   int fh, int fw, int padx0, int padx1, int pady0, int pady1, float fir_gain,
                                   const float* demod, int demod_stride, const float* noise, long noise_bstride,
                                   float noise_strength, const float* bias, int act, float alpha, float gain,
-                                  float clamp, hipStream_t stream, float* pmax, int in_pitch, long in_plane) {
+                                  float clamp, hipStream_t stream, float* pmax, int in_pitch, long in_plane, int in_xhalf) {
     FirArgs a; int ho, wo;
     int rc = fir_fill(a, in, out, B, C, Hin, Win, f_host, fh, fw, 1, 1, 1, 1, padx0, padx1, pady0, pady1, 0, fir_gain,
                       &ho, &wo);
@@ -334,7 +346,7 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
     a.noise_strength = noise_strength; a.bias = bias; a.act = act; a.alpha = alpha; a.gain = gain; a.clamp = clamp;
     if (fw == 4 && fh == 4) a.pmax = pmax;
     else LA_CHECK_ARG(!pmax, "upfirdn2d: plane maxima are produced by the 4x4 stride-1 kernel only");
-    if (in_pitch > 0) { a.in_pitch = in_pitch; a.in_plane = in_plane; }
+    if (in_pitch > 0) { a.in_pitch = in_pitch; a.in_plane = in_plane; a.in_xhalf = in_xhalf; }
     return fir_launch(a, stream);
 }
 
