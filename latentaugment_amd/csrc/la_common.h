@@ -74,6 +74,21 @@ __device__ __forceinline__ float la_pow2_scale(float amax) {
     return ldexpf(1.f, s);
 }
 
+// Running per-sample fp16 operand scale handed from a producing kernel to the contraction that consumes its output: the slot
+// starts a pass at LA_XS_INIT (2^100, the largest scale la_pow2_scale returns); every producing workgroup lowers it to
+// la_pow2_scale(mult * its own max) -- positive floats order like unsigned ints, so an atomicMin on the bit pattern does it, the
+// result is the scale of the overall maximum whatever the arrival order, and the consumer just reads a float.  `seen` is an
+// earlier (possibly stale, i.e. larger) read of the slot: workgroups that cannot lower it skip the atomic.
+#define LA_XS_INIT 0x71800000u
+__device__ __forceinline__ float la_xs_peek(const float* slot) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void la_xs_lower(float* slot, float seen, float mult, float wg_max) {
+    if (!(wg_max > 0.f)) return;
+    const float s = la_pow2_scale(mult * wg_max);
+    if (s < seen) atomicMin(reinterpret_cast<unsigned*>(slot), __float_as_uint(s));
+}
+
 // activation ids follow the reference's cuda_idx (bias_act.py:20-30): 1 linear, 2 relu, 3 lrelu
 #define LA_ACT_LINEAR 1
 #define LA_ACT_RELU 2

@@ -66,6 +66,9 @@ struct LaConvArgs {
     int seam_act; float seam_alpha, seam_gain, seam_clamp;
     float* seam_ddn_part;    // [B][M][tiles_per_sample]
     float* seam_pmax;        // [B][M][tiles_per_sample] or null
+    float* seam_xs_out;      // [B] or null: fp16 operand scale of `out` for its consumer = pow2 scale of seam_xs_mult * max|out| over the
+    float seam_xs_mult;      //   sample, final when the launch has run: direct kernels lower the slot themselves (la_xs_lower, la_common.h; it must
+                             //   hold LA_XS_INIT before), the split-K form reduces seam_pmax (required as scratch) with one small launch
     // ... and, with seam_imgc > 0, the ToRGB backward of the block whose conv1 output xin is (la_seam_bwd_kernel<imgc>):
     //   g += sum_c seam_wrgb[c][m] * seam_srgb[b][m] * gr_c,  gr_c = seam_gimg[b][c][px] where |seam_rgbpre[b][c][px]| <= seam_rgb_clamp;
     //   seam_dweff_part[b][c][m][tile] = sum_px gr_c * y

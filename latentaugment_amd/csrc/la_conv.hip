@@ -9,6 +9,7 @@
 #include "la_conv.h"
 #include <stdlib.h>
 #include "la_conv_device.h"
+#include <type_traits>
 
 #define KC 16
 
@@ -234,38 +235,79 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
     const int imgc = seam ? (a.seam_imgc < 4 ? a.seam_imgc : 4) : 0;
     float we[4] = {0.f, 0.f, 0.f, 0.f}, dwe[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < imgc; ++c) we[c] = a.seam_wrgb[(long)c * a.M + m] * a.seam_srgb[(long)b * a.seam_srgb_stride + m];
-    for (int g = tp; g < G; g += T) {
-        float v = 0.f;
-        for (int k = 0; k < a.ksplit; ++k) v += wsp[(long)k * slice + g];
-        const int gy = g / a.Gx, gx = g - gy * a.Gx;
-        const long pos = (long)(gy * a.out_sy + a.out_oy) * wpitch + gx * a.out_sx + a.out_ox;
-        if (a.epi == LA_EPI_FWD) {
-            const float nz = a.noise ? a.noise[(long)b * a.noise_bstride + pos] * a.noise_strength : 0.f;
-            v = la_conv_epi_fwd(a, v, dmv, nz, bv);
-            if (a.out2) {
-                const long o2 = ((long)b * a.M + m) * HWout + pos;
-                a.out2[o2] = v + (a.addend ? a.addend[o2] : 0.f);
+    // VEC consecutive grid positions per thread and step (4: 16-byte loads / stores when the rows allow it, else 1)
+    auto run = [&](auto vec_tag) {
+        constexpr int VEC = decltype(vec_tag)::value;
+        typedef float vf __attribute__((ext_vector_type(VEC)));
+        auto ld = [](const float* p) { return *reinterpret_cast<const vf*>(p); };
+        for (int g = tp * VEC; g < G; g += T * VEC) {
+            vf acc = ld(wsp + g);
+            for (int k = 1; k < a.ksplit; ++k) acc += ld(wsp + (long)k * slice + g);
+            const int gy = g / a.Gx, gx = g - gy * a.Gx;
+            const long pos = (long)(gy * a.out_sy + a.out_oy) * wpitch + gx * a.out_sx + a.out_ox;
+            float v[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = VEC == 1 ? acc[0] : acc[e];
+            if (a.epi == LA_EPI_FWD) {
+                vf nz = 0.f;
+                if (a.noise) nz = ld(a.noise + (long)b * a.noise_bstride + pos) * a.noise_strength;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = la_conv_epi_fwd(a, v[e], dmv, nz[e], bv);
+                if (a.out2) {
+                    const long o2 = ((long)b * a.M + m) * HWout + pos;
+                    vf ad = 0.f;
+                    if (a.addend) ad = ld(a.addend + o2);
+                    vf w;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) w[e] = v[e] + ad[e];
+                    *reinterpret_cast<vf*>(a.out2 + o2) = w;
+                }
+            } else if (a.epi == LA_EPI_BWD) {
+                vf y = 0.f;
+                if (xin_p) y = ld(xin_p + pos);
+                vf gv[4], nz0 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    gv[c] = 0.f;
+                    if (c < imgc) {
+                        const long o = ((long)b * imgc + c) * HWout + pos;
+                        gv[c] = ld(a.seam_gimg + o);
+                        if (a.seam_rgb_clamp >= 0.f) {
+                            const vf pre = ld(a.seam_rgbpre + o);
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) if (fabsf(pre[e]) > a.seam_rgb_clamp) gv[c][e] = 0.f;
+                        }
+                    }
+                }
+                if (seam && a.seam_noise) nz0 = ld(a.seam_noise + (long)b * a.seam_noise_bstride + pos) * a.seam_noise_strength;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    part += v[e] * y[e];
+                    v[e] *= sc;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < imgc) { v[e] += we[c] * gv[c][e]; dwe[c] += gv[c][e] * y[e]; }
+                    if (seam) {
+                        const float g1 = v[e] * la_act_bwd_from_y(y[e], a.seam_act, a.seam_alpha, a.seam_gain, a.seam_clamp);
+                        dd += g1 * (la_act_inv(y[e], a.seam_act, a.seam_alpha, a.seam_gain) - b0 - nz0[e]);
+                        v[e] = g1 * dm0;
+                        mx = fmaxf(mx, fabsf(v[e]));
+                    }
+                }
             }
-        } else if (a.epi == LA_EPI_BWD) {
-            const float y = xin_p ? xin_p[pos] : 0.f;
-            part += v * y;
-            v *= sc;
-            for (int c = 0; c < imgc; ++c) {
-                const long o = ((long)b * imgc + c) * HWout + pos;
-                float gv = a.seam_gimg[o];
-                if (a.seam_rgb_clamp >= 0.f && fabsf(a.seam_rgbpre[o]) > a.seam_rgb_clamp) gv = 0.f;
-                v += we[c] * gv;
-                dwe[c] += gv * y;
-            }
-            if (seam) {
-                const float nz0 = a.seam_noise ? a.seam_noise[(long)b * a.seam_noise_bstride + pos] * a.seam_noise_strength : 0.f;
-                const float g1 = v * la_act_bwd_from_y(y, a.seam_act, a.seam_alpha, a.seam_gain, a.seam_clamp);
-                dd += g1 * (la_act_inv(y, a.seam_act, a.seam_alpha, a.seam_gain) - b0 - nz0);
-                v = g1 * dm0;
-                mx = fmaxf(mx, fabsf(v));
-            }
+            vf w;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) w[e] = v[e];
+            *reinterpret_cast<vf*>(out_p + pos) = w;
         }
-        out_p[pos] = v;
+    };
+    {
+        size_t al = (size_t)a.splitk_ws | (size_t)a.out | (size_t)a.out2 | (size_t)a.addend | (size_t)a.noise | (size_t)a.xin;
+        if (seam) al |= (size_t)a.seam_noise | (size_t)(imgc ? a.seam_gimg : nullptr) | (size_t)(imgc ? a.seam_rgbpre : nullptr);
+        const bool vec4 = a.out_sx == 1 && ((a.Gx | wpitch | a.out_ox) & 3) == 0 && ((HWout | a.noise_bstride | a.seam_noise_bstride | a.xin_bstride) & 3) == 0 &&
+                          (al & 15) == 0 && (a_in.nphase == 0 || (a_in.ph[blockIdx.z].ws_off & 3) == 0);
+        if (vec4) run(std::integral_constant<int, 4>{});
+        else run(std::integral_constant<int, 1>{});
     }
     if (a.epi == LA_EPI_BWD && (a.ds_part || seam)) {
         part = la_wave_sum(part);
@@ -318,6 +360,7 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
         LA_CHECK_ARG(a.tiles_per_sample == la_conv_tiles_per_sample(a.Gy, a.Gx), "conv: tiles_per_sample mismatch");
         LA_CHECK_ARG(a.out_sy == 1 && a.out_sx == 1 && a.out_oy == 0 && a.out_ox == 0, "conv: bwd epilogue needs dense output");
     }
+    LA_CHECK_ARG(!a.seam_xs_out || a.seam_pmax, "conv: seam_xs_out needs seam_pmax as scratch for the split-K form");
     int tiles = la_conv_tiles_per_sample(a.Gy, a.Gx);
     const int nphase = a.nphase;
     LA_CHECK_ARG(nphase >= 0 && nphase <= LA_CONV_MAX_PHASES, "conv: bad phase count");
@@ -398,10 +441,17 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
                 const unsigned nz = nphase > 0 ? nphase : 1;
                 if (Gmax >= 256) hipLaunchKernelGGL(la_conv_splitk_finish_kernel<1>, dim3(a.M, a.B, nz), dim3(256), 0, stream, as);
                 else hipLaunchKernelGGL(la_conv_splitk_finish_kernel<4>, dim3(la_cdiv(a.M, 4), a.B, nz), dim3(256), 0, stream, as);
+                // the consumer's operand scale (LaConvArgs::seam_xs_out): thousands of short finish workgroups lowering one slot per
+                // sample at the same moment serialise on it (measured 21 -> 65 us), so this form reduces the plane maxima instead
+                if (as.seam_xs_out && as.seam_ddn_part && as.epi == LA_EPI_BWD) {
+                    int rc = la_conv_xscale_from_pmax(as.seam_pmax, as.tiles_per_sample, nullptr, 0, as.seam_xs_mult, as.seam_xs_out, a.B, a.M, stream);
+                    if (rc) return rc;
+                }
             }
         }
     }
     if (as.ksplit == 1) {
+        if (as.seam_xs_out) as.seam_pmax = nullptr;      // direct kernels lower the consumer's scale slot themselves: no plane maxima
         dim3 grid(tiles, mtiles, a.B * (nphase > 0 ? nphase : 1));
         if (bf) pcls = la_conv_bf16_uses_halo(as) ? LA_PC_CONV_HALO : LA_PC_CONV_FLAT;
         pslot = la_prof_open(pcls, pflops, pbytes, stream);

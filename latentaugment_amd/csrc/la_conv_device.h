@@ -82,6 +82,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
             // fused seam of the layer that produced xin (see LaConvArgs): LDS rows 6, 7 = its demod / bias, 8.. = ddn partials,
             // 12.. = maxima (the 16-bit kernels' LDS is large enough; the fp32 kernel never sets seam_ddn_part)
             const bool seam = a.seam_ddn_part != nullptr && x0 != nullptr;
+            const float xs_seen = (seam && a.seam_xs_out) ? la_xs_peek(a.seam_xs_out + b) : 0.f;      // (early: its latency hides under the epilogue)
             // (activation backward from the saved output as straight-line selects with reciprocals: same values as
             //  la_act_bwd_from_y / la_act_inv up to the rounding of 1/gain, 1/alpha)
             const float s_pos = a.seam_gain, s_neg = a.seam_act == LA_ACT_LRELU ? a.seam_gain * a.seam_alpha : (a.seam_act == LA_ACT_RELU ? 0.f : a.seam_gain);
@@ -237,6 +238,18 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                         for (int w = 1; w < WN_; ++w) { t += red[8 + w][tid]; m = fmaxf(m, red[12 + w][tid]); }
                         a.seam_ddn_part[slot] = t;
                         if (a.seam_pmax) a.seam_pmax[slot] = m;
+                        red[12][tid] = m;
+                    }
+                }
+                if (seam && a.seam_xs_out) {      // this workgroup's maximum lowers the running operand scale of the sample (wave 0)
+                    __syncthreads();
+                    if (tid < 64) {
+                        float m = 0.f;
+#pragma unroll
+                        for (int k = tid; k < MT; k += 64) m = fmaxf(m, red[12][k]);
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                        if (tid == 0) la_xs_lower(a.seam_xs_out + b, xs_seen, a.seam_xs_mult, m);
                     }
                 }
             }
@@ -320,6 +333,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
         const float* xin_b = a.xin ? a.xin + (long)b * a.xin_bstride : nullptr;
         const float* os_b = a.out_scale ? a.out_scale + (long)b * a.oscale_stride : nullptr;
         const bool seam = a.seam_ddn_part != nullptr && xin_b != nullptr;      // fused seam of the layer that produced xin (LaConvArgs)
+        const float xs_seen = (seam && a.seam_xs_out) ? la_xs_peek(a.seam_xs_out + b) : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -399,6 +413,18 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                     for (int w = 1; w < WN_; ++w) { t += red[8 + w][tid]; mm = fmaxf(mm, red[12 + w][tid]); }
                     a.seam_ddn_part[slot] = t;
                     if (a.seam_pmax) a.seam_pmax[slot] = mm;
+                    red[12][tid] = mm;
+                }
+            }
+            if (seam && a.seam_xs_out) {
+                __syncthreads();
+                if (tid < 64) {
+                    float m = 0.f;
+                    for (int k = tid; k < MT; k += 64)
+                        if (m0 + k < a.M) m = fmaxf(m, red[12][k]);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                    if (tid == 0) la_xs_lower(a.seam_xs_out + b, xs_seen, a.seam_xs_mult, m);
                 }
             }
         }

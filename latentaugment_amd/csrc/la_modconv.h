@@ -30,6 +30,7 @@ struct LaSeamFuse {
     int act; float alpha, gain, clamp;
     float* ddn_part;
     float* pmax;
+    float* xs_out; float xs_mult;      // optional [B]: running operand scale of the epilogue's output for its consumer (la_xs_lower)
     // ToRGB backward of that block (imgc > 0): image gradient, ToRGB pre-clamp output, weights [imgc][C], styles, partial outputs
     int imgc;
     const float* g_img; const float* rgb_pre; float rgb_clamp;
@@ -38,14 +39,18 @@ struct LaSeamFuse {
 };
 int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, const float* wb, const void* wq, int precision, const float* s, int s_stride,
                          const float* xin, long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
-                         int res, hipStream_t stream, const LaSeamFuse* seam = nullptr);
+                         int res, hipStream_t stream, const LaSeamFuse* seam = nullptr, const float* xscale = nullptr);
+// xscale (optional, [B]): the fp16 operand scale of gz, already final when this launch starts (left by the producer of gz through
+// LaSeamFuse::xs_out / LaSeamArgs::xs_out) -- no plane-maxima reduction launch
 
 // gz_pmax [B][cout][gz_nseg]: partial max |gz| per plane (left by the seam kernel); with it the fp16 mode builds the contraction's
 // operand in one fused pass (FIR adjoint + scale + split + interleave)
 int la_modconv3x3_up2_bwd_ex(const float* gz, const float* gz_pmax, int gz_nseg, const float* wb, const void* wq, int precision, const float* s,
                              int s_stride, const float* xin, long xin_bstride, const float* fir_host, float* scratch, float* gx,
                              float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, hipStream_t stream,
-                             const LaSeamFuse* seam = nullptr);      // seam of the block BELOW (its conv1 output is xin), incl. its ToRGB backward
+                             const LaSeamFuse* seam = nullptr, const float* xscale = nullptr);      // seam of the block BELOW (its conv1 output is xin), incl. its ToRGB backward
+
+float la_modconv_up2_bwd_xs_mult(const float* fir_host);      // the `mult` of the operand scale an up layer's backward expects (LaSeamFuse::xs_mult)
 
 extern "C" {
 int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps, hipStream_t);

@@ -127,14 +127,14 @@ static void set_seam(LaConvArgs& a, const LaSeamFuse* seam) {
     a.seam_demod = seam->demod; a.seam_demod_stride = seam->demod_stride; a.seam_bias = seam->bias;
     a.seam_noise = seam->noise; a.seam_noise_bstride = seam->noise_bstride; a.seam_noise_strength = seam->noise_strength;
     a.seam_act = seam->act; a.seam_alpha = seam->alpha; a.seam_gain = seam->gain; a.seam_clamp = seam->clamp;
-    a.seam_ddn_part = seam->ddn_part; a.seam_pmax = seam->pmax;
+    a.seam_ddn_part = seam->ddn_part; a.seam_pmax = seam->pmax; a.seam_xs_out = seam->xs_out; a.seam_xs_mult = seam->xs_mult;
     a.seam_imgc = seam->imgc; a.seam_gimg = seam->g_img; a.seam_rgbpre = seam->rgb_pre; a.seam_rgb_clamp = seam->rgb_clamp;
     a.seam_wrgb = seam->wrgb; a.seam_srgb = seam->s_rgb; a.seam_srgb_stride = seam->s_rgb_stride; a.seam_dweff_part = seam->dweff_part;
 }
 
 int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, const float* wb, const void* wq, int precision, const float* s, int s_stride,
                          const float* xin, long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
-                         int res, hipStream_t stream, const LaSeamFuse* seam) {
+                         int res, hipStream_t stream, const LaSeamFuse* seam, const float* xscale) {
     LA_CHECK_ARG(gz && wb && gx, "modconv_bwd: null pointer");
     LA_CHECK_ARG(!seam || (precision != LA_PREC_F32 && xin && seam->ddn_part), "modconv_bwd: the fused seam needs a 16-bit contraction and xin");
     LaConvArgs a; base_args(a);
@@ -144,6 +144,7 @@ int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, con
     a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = a.Hout = a.Wout = a.Gy = a.Gx = res;
     a.ntaps = 9;
     for (int t = 0; t < 9; ++t) { a.tap_dy[t] = 1 - t / 3; a.tap_dx[t] = 1 - t % 3; a.tap_w[t] = t; }
+    if (precision == LA_PREC_F16X2 && xscale) { a.acc_scale_x = xscale; a.in_pmax = nullptr; }      // preset operand scale
     a.epi = LA_EPI_BWD;
     a.out_scale = s; a.oscale_stride = s_stride;
     a.xin = xin; a.xin_bstride = xin_bstride;
@@ -161,7 +162,7 @@ extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const voi
 int la_modconv3x3_up2_bwd_ex(const float* gz, const float* gz_pmax, int gz_nseg, const float* wb, const void* wq, int precision, const float* s,
                              int s_stride, const float* xin, long xin_bstride, const float* fir_host, float* scratch, float* gx,
                              float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, hipStream_t stream,
-                             const LaSeamFuse* seam) {
+                             const LaSeamFuse* seam, const float* xscale_in) {
     LA_CHECK_ARG(gz && wb && gx && scratch && fir_host, "modconv_up2_bwd: null pointer");
     LA_CHECK_ARG(!seam || (precision != LA_PREC_F32 && xin && seam->ddn_part && (seam->imgc == 0 || (seam->g_img && seam->wrgb && seam->s_rgb && seam->dweff_part))),
                  "modconv_up2_bwd: the fused seam needs a 16-bit contraction, xin and its output buffers");
@@ -180,16 +181,18 @@ int la_modconv3x3_up2_bwd_ex(const float* gz, const float* gz_pmax, int gz_nseg,
     a.in_bstride = (long)cout * (res + 1) * (res + 1);
     const size_t qbytes = (size_t)B * la_cdiv(cout, 32) * 32 * (res + 1) * (res + 1) * 4;
     const size_t fused_need = 512 + ((qbytes + 255) & ~(size_t)255);
-    if (precision == LA_PREC_F16X2 && gz_pmax && gz_nseg >= 1 && res % 4 == 0 && ws && ws_bytes > fused_need && (((size_t)ws | (size_t)gz) & 15) == 0) {
+    if (precision == LA_PREC_F16X2 && (xscale_in || (gz_pmax && gz_nseg >= 1)) && res % 4 == 0 && ws && ws_bytes > fused_need && (((size_t)ws | (size_t)gz) & 15) == 0) {
         // fp16 mode with the plane maxima of gz at hand (left by the seam kernel): ONE pass turns gz into the contraction's
         // operand -- FIR adjoint (pad 2, flipped taps, gain 4; upfirdn2d.py:255-266) + operand scale + fp16 split + channel
         // interleave.  The scale comes from the bound |adjoint(gz)| <= 4 * sum(f) * max|gz| = 4 * max|gz| (see la_upfirdn2d.hip).
-        float* xscale = static_cast<float*>(ws);
+        const float* xscale = xscale_in;      // (already final: the producer of gz lowered it with the same bound, la_modconv_up2_bwd_xs_mult)
         unsigned* q = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + 512);
-        float fsum = 0.f;
-        for (int i = 0; i < 16; ++i) fsum += fabsf(fir_host[i]);
-        int rc = la_conv_xscale_from_pmax(gz_pmax, gz_nseg, nullptr, 0, 4.f * fsum, xscale, B, cout, stream);
-        if (rc) return rc;
+        int rc;
+        if (!xscale) {
+            float* xs = static_cast<float*>(ws);
+            if ((rc = la_conv_xscale_from_pmax(gz_pmax, gz_nseg, nullptr, 0, la_modconv_up2_bwd_xs_mult(fir_host), xs, B, cout, stream))) return rc;
+            xscale = xs;
+        }
         if ((rc = la_fir4x4_adjoint_pack_f16(gz, q, xscale, B, cout, res, res, fir_host, 4.f, stream))) return rc;
         a.in = gz;                       // (not read: the launch takes its operand from in_q)
         a.in_q = q; a.acc_scale_x = xscale;
@@ -212,6 +215,13 @@ int la_modconv3x3_up2_bwd_ex(const float* gz, const float* gz_pmax, int gz_nseg,
     a.in = scratch; a.in_pmax = pmax; a.in_pmax_nseg = nseg;
     a.ws = ws; a.ws_bytes = ws_bytes;
     return la_conv_launch(a, stream);
+}
+
+// bound factor of the fused FIR-adjoint operand: |adjoint(gz)| <= 4 * sum|f| * max|gz|
+float la_modconv_up2_bwd_xs_mult(const float* fir_host) {
+    float fsum = 0.f;
+    for (int i = 0; i < 16; ++i) fsum += fabsf(fir_host[i]);
+    return 4.f * fsum;
 }
 
 extern "C" int la_modconv3x3_up2_bwd_f32(const float* gz, const float* wb, const void* wq, int precision, const float* s, int s_stride, const float* xin,

@@ -43,6 +43,7 @@ struct LaSeamArgs {
     const float* s_rgb; int s_stride;   // styles of the ToRGB layer (already * weight_gain)
     float* dweff_part;       // [B][imgc][C][slabs]
     float* pmax_out;         // optional [B][C][slabs]: partial max |gz| per plane (one per workgroup)
+    float* xs_out; float xs_mult;      // optional [B] (needs pmax_out): fp16 operand scale of gz for its consumer, pow2 scale of xs_mult * max|gz|
 };
 
 int la_pack_conv_weights(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps, hipStream_t,
@@ -50,7 +51,8 @@ int la_pack_conv_weights(const float* w, float* wf, float* wb, float* wsq, int c
 int la_affine_forward(const LaStyleTable& t, const float* ws, long ws_bstride, long ws_lstride, int B, int wdim,
                       float* s_all, hipStream_t);
 // xs[l][b] = power-of-two fp16 operand scale of conv layer l's forward contraction from the bound  bound[l] * max_i |s[b][i]|
-int la_xscale_from_bounds(const LaDemodTable& t, const float* s_all, int s_stride, const float* bound, float* xs, int B, hipStream_t);
+int la_xscale_from_bounds(const LaDemodTable& t, const float* s_all, int s_stride, const float* bound, float* xs, int B, hipStream_t,
+                          float* xs_bwd = nullptr);      // xs_bwd [nlayers][B] (optional): reset to LA_XS_INIT for the backward pass (la_common.h)
 int la_demod_forward(const LaDemodTable& t, const float* s_all, int s_stride, int B, float* d_all, hipStream_t);
 int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_stride, const float* bias,
                      const float* skip, float* rgb_pre, float* img, int B, int C, int imgc, int H, int W, float clamp,

@@ -4,6 +4,7 @@
 //   ToRGB-backward + bias_act-backward + demod-gradient reductions, and the style-gradient finish.
 // All are HBM- or latency-bound; the contraction work lives in la_conv.hip.
 #include "la_style.h"
+#include "la_conv.h"
 
 // ------------------------------------------------------------------------------------------------------------
 // weight packing:  W[o][i][ky][kx]  ->  wf[t][i][o], wb[t][o][i], wsq[o][i] = sum_t W^2      (t = ky*3+kx)
@@ -151,7 +152,8 @@ int la_demod_forward(const LaDemodTable& t, const float* s_all, int s_stride, in
 // is known as soon as the styles are -- no pass over the activations (plane maxima / absmax kernels) is needed.  A bound
 // instead of the exact maximum only moves the absolute floor of the 2-term fp16 split (see la_upfirdn2d.hip).
 __global__ __launch_bounds__(256) void la_xscale_bound_kernel(LaDemodTable t, const float* __restrict__ s_all, int s_stride,
-                                                             const float* __restrict__ bound, float* __restrict__ xs, int B) {
+                                                             const float* __restrict__ bound, float* __restrict__ xs, int B,
+                                                             unsigned* __restrict__ xs_bwd) {
     __shared__ float red[4];
     const int l = blockIdx.x, b = blockIdx.y;
     const float* sp = s_all + (long)b * s_stride + t.s_off[l];
@@ -161,11 +163,14 @@ __global__ __launch_bounds__(256) void la_xscale_bound_kernel(LaDemodTable t, co
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) xs[(long)l * B + b] = la_pow2_scale(bound[l] * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (threadIdx.x == 0) {
+        xs[(long)l * B + b] = la_pow2_scale(bound[l] * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        if (xs_bwd) xs_bwd[(long)l * B + b] = LA_XS_INIT;      // the backward pass's running operand scales start over (la_xs_lower)
+    }
 }
 
-int la_xscale_from_bounds(const LaDemodTable& t, const float* s_all, int s_stride, const float* bound, float* xs, int B, hipStream_t stream) {
-    hipLaunchKernelGGL(la_xscale_bound_kernel, dim3(t.nlayers, B), dim3(256), 0, stream, t, s_all, s_stride, bound, xs, B);
+int la_xscale_from_bounds(const LaDemodTable& t, const float* s_all, int s_stride, const float* bound, float* xs, int B, hipStream_t stream, float* xs_bwd) {
+    hipLaunchKernelGGL(la_xscale_bound_kernel, dim3(t.nlayers, B), dim3(256), 0, stream, t, s_all, s_stride, bound, xs, B, reinterpret_cast<unsigned*>(xs_bwd));
     LA_CHECK_LAUNCH();
     return LA_OK;
 }
@@ -382,7 +387,9 @@ __global__ __launch_bounds__(256) void la_seam_bwd_kernel(LaSeamArgs a) {
         __syncthreads();
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gmax;
         __syncthreads();
-        if (threadIdx.x == 0) a.pmax_out[((long)b * a.C + c) * gridDim.x + slab] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (threadIdx.x == 0) {
+            a.pmax_out[((long)b * a.C + c) * gridDim.x + slab] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        }
         __syncthreads();
     }
     const float ddn_t = la_block_sum_256(ddn, red);
@@ -412,6 +419,11 @@ int la_seam_backward(const LaSeamArgs& a, int B, int imgc, hipStream_t stream) {
 #undef LAUNCH
     la_prof_close(pslot, stream);
     LA_CHECK_LAUNCH();
+    // the consumer's fp16 operand scale (thousands of short workgroups: a reduction launch, not la_xs_lower -- see la_conv_launch)
+    if (a.xs_out) {
+        LA_CHECK_ARG(a.pmax_out, "seam: xs_out needs pmax_out as scratch");
+        return la_conv_xscale_from_pmax(a.pmax_out, (int)grid.x, nullptr, 0, a.xs_mult, a.xs_out, B, a.C, stream);
+    }
     return LA_OK;
 }
 

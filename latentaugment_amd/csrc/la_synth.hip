@@ -58,6 +58,7 @@ struct la_synth {
     float* pmax2;            // [maxB][cout][tiles]: plane maxima of an up-sampling layer's gz when its seam is fused into the epilogue of
                              // the conv1 backward contraction above it
     float* xs_fwd;           // [nconv][B]: fp16 operand scales of the forward contractions (from the clamp bound, one launch per pass)
+    float* xs_bwd;           // [nconv][B]: running fp16 operand scales of the backward contractions' inputs, lowered by the producing kernels
     float* xs_bound;         // [nconv]: bound on |input| of conv layer k: max|const| for the first, conv_clamp for the rest
     int lastB;
     int precision;
@@ -158,6 +159,7 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
         h->pmax3 = c.take(f3 ? f3 : 16);
     }
     h->xs_fwd = c.take((size_t)h->nconv * mb);
+    h->xs_bwd = c.take((size_t)h->nconv * mb);
     h->xs_bound = c.take((size_t)h->nconv + 16);
     *need = c.off;
     return LA_OK;
@@ -320,7 +322,7 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
     // scratch layout of the up layers: dense interleaved rows (plane maxima wanted: scalar FIR; dev knob LA_NO_ZT_PITCH) or column-planar
     static const bool zt_knob_dense = getenv("LA_NO_ZT_PITCH") != nullptr;
     const bool zt_dense = (f16 && !bound_scale) || zt_knob_dense;
-    if (bound_scale && (rc = la_xscale_from_bounds(h->dt, h->s_all, h->S, h->xs_bound, h->xs_fwd, B, stream))) return rc;
+    if (bound_scale && (rc = la_xscale_from_bounds(h->dt, h->s_all, h->S, h->xs_bound, h->xs_fwd, B, stream, h->xs_bwd))) return rc;
     int ci = 0;
     const float* x = h->cst;
     long x_bstride = 0;
@@ -393,6 +395,15 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
     static const bool no_fuse = getenv("LA_NO_SEAM_FUSE") != nullptr;      // dev knobs: A/B of the fused seams on one box
     static const bool no_fuse2 = getenv("LA_NO_SEAM2_FUSE") != nullptr;
     const bool f16 = h->precision == LA_PREC_F32 ? false : h->precision == LA_PREC_F16X2;
+    // fp16 operand scales of the backward contractions: with a clamp (the forward pass then ran la_xscale_from_bounds, which also reset
+    // xs_bwd) the direct contraction kernels, whose epilogues produce the next contraction's input, lower the consumer's slot
+    // themselves (la_xs_lower): no plane maxima, no reduction launch between producer and consumer.  The split-K finish and the
+    // seam kernel still reduce plane maxima with one small launch (inside la_conv_launch / la_seam_backward), into the same slot.
+    // Without a clamp: plane maxima + la_xscale_pmax at the consumer as before.
+    static const bool no_xs = getenv("LA_NO_XS_HANDOFF") != nullptr;      // dev knob
+    const bool xs_hand = f16 && h->clamp > 0.f && !no_xs;
+    const float up_mult = la_modconv_up2_bwd_xs_mult(h->fir);
+    auto xs_slot = [&](int conv_index) { return xs_hand ? h->xs_bwd + (long)conv_index * B : nullptr; };
     bool seam2_done = false;      // this block's conv1 seam was already applied by the epilogue of the up layer's backward above it
     for (int k = h->nblocks - 1; k >= 0; --k) {
         const int res = 4 << k;
@@ -414,6 +425,7 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
             s.g_img = gi; s.rgb_pre = T.rgb_pre; s.rgb_clamp = h->clamp; s.wrgb = T.weight;
             s.s_rgb = h->s_all + T.s_off; s.s_stride = h->S; s.dweff_part = T.dwep;
             if (f16) s.pmax_out = h->pmax;      // the seam kernel leaves the plane maxima of gz for the contraction that follows
+            if (xs_hand) { s.xs_out = xs_slot(ci); s.xs_mult = 1.f; }
             if ((rc = la_seam_backward(s, B, h->imgc, stream))) return rc;
         }
         {
@@ -433,11 +445,13 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
                 sf.demod = h->d_all + L0f.d_off; sf.demod_stride = h->Dt; sf.bias = L0f.bias;
                 sf.noise = L0f.noise_used; sf.noise_bstride = L0f.noise_bstride; sf.noise_strength = L0f.noise_strength;
                 sf.act = LA_ACT_LRELU; sf.alpha = 0.2f; sf.gain = sqrtf(2.f); sf.clamp = h->clamp;
-                sf.ddn_part = h->conv[ci - 1].ddnp; sf.pmax = f16 ? h->pmax2 : nullptr;
+                sf.ddn_part = h->conv[ci - 1].ddnp;
+                sf.pmax = f16 ? h->pmax2 : nullptr;
+                if (xs_hand) { sf.xs_out = xs_slot(ci - 1); sf.xs_mult = up_mult; }
             }
             if ((rc = la_modconv3x3_bwd_ex(h->G0, f16 ? (seam2_done ? h->pmax3 : h->pmax) : nullptr, nseg1, L1.wb, L1.wqb, h->precision, h->s_all + L1.s_off,
                                            h->S, xin, xin_bs, h->G1, L1.dsp, h->cws, h->cws_bytes, B, L1.cin, L1.cout, res, stream,
-                                           fuse_seam ? &sf : nullptr)))
+                                           fuse_seam ? &sf : nullptr, xs_slot(ci))))
                 return rc;
             fin_conv(L1, tiles1, nseg1);
         }
@@ -453,6 +467,7 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
             s.act = LA_ACT_LRELU; s.alpha = 0.2f; s.gain = sqrtf(2.f); s.clamp = h->clamp;
             s.ddn_part = L0.ddnp;
             if (f16) s.pmax_out = h->pmax;      // plane maxima of gz: bound for the operand scale of the fused FIR-adjoint + split pass
+            if (xs_hand) { s.xs_out = xs_slot(ci); s.xs_mult = up_mult; }
             if ((rc = la_seam_backward(s, B, 0, stream))) return rc;
         }
         // ---- image gradient one level down: adjoint of upsample2d = FIR (flipped) + decimate 2, pad (1,1,1,1), gain 4
@@ -473,13 +488,15 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
                 sf2.demod = h->d_all + Lb.d_off; sf2.demod_stride = h->Dt; sf2.bias = Lb.bias;
                 sf2.noise = Lb.noise_used; sf2.noise_bstride = Lb.noise_bstride; sf2.noise_strength = Lb.noise_strength;
                 sf2.act = LA_ACT_LRELU; sf2.alpha = 0.2f; sf2.gain = sqrtf(2.f); sf2.clamp = h->clamp;
-                sf2.ddn_part = Lb.ddnp; sf2.pmax = f16 ? h->pmax3 : nullptr;
+                sf2.ddn_part = Lb.ddnp;
+                sf2.pmax = f16 ? h->pmax3 : nullptr;
+                if (xs_hand) { sf2.xs_out = xs_slot(ci - 1); sf2.xs_mult = 1.f; }
                 sf2.imgc = h->imgc; sf2.g_img = P.g_img; sf2.rgb_pre = P.rgb_pre; sf2.rgb_clamp = h->clamp;
                 sf2.wrgb = P.weight; sf2.s_rgb = h->s_all + P.s_off; sf2.s_rgb_stride = h->S; sf2.dweff_part = P.dwep;
             }
             if ((rc = la_modconv3x3_up2_bwd_ex(h->G1, f16 ? (fuse_seam ? h->pmax2 : h->pmax) : nullptr, nseg0, L0.wb, L0.wqb, h->precision, h->s_all + L0.s_off, h->S,
                                                h->conv[ci - 1].y, (long)L0.cin * hin * hin, h->fir, h->zT, h->G0, L0.dsp, h->cws, h->cws_bytes, B,
-                                               L0.cin, L0.cout, res, stream, fuse_seam2 ? &sf2 : nullptr)))
+                                               L0.cin, L0.cout, res, stream, fuse_seam2 ? &sf2 : nullptr, xs_slot(ci))))
                 return rc;
             fin_conv(L0, tiles, nseg0);
         }
