@@ -32,6 +32,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef LA_STAMP
 #define LA_STAMP 0
 #endif
+#ifndef LA_GATHER
+#define LA_GATHER 1      // fp16 flat kernel: 1 = lane-contiguous 16-byte pieces (8 lanes per pixel record), 0 = one pixel half-record per lane
+#endif
 // issue-order fences of the halo tap loop (dev builds can override LA_FENCES: bit 0 = A, bit 1 = B, bit 2 = C)
 #ifndef LA_FENCES
 #define LA_FENCES 2
@@ -481,6 +484,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     const int gx_l = nvalid ? g_l - gy_l * a.Gx : 0;
     const int iy0 = gy_l * a.in_sy, ix0 = gx_l * a.in_sx;
     const unsigned HWin = (unsigned)(a.Hin * a.Win);
+    // fp16 pieces (LA_GATHER): load k of a thread is the 16-byte piece (4 channels) tid & 7 of pixel k * 32 + (tid >> 3), so that the
+    // 8 lanes of a pixel read its whole 128-byte record and a wave instruction touches 8 lines instead of 64
+    constexpr bool PIECES = (FMT == FMT_F16X2) && (LA_GATHER == 1);
+    int piy0[4], pix0[4]; unsigned pbase[4]; bool pvalid[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n_k = k * 32 + (tid >> 3);
+        const int nidx = ntile * NT + n_k;
+        pvalid[k] = nidx < Ntot;
+        const int bb = SPLIT ? (pvalid[k] ? nidx / G : 0) : bz;
+        const int g = SPLIT ? nidx - bb * G : nidx;
+        const int gy = pvalid[k] ? g / a.Gx : 0, gx = pvalid[k] ? g - gy * a.Gx : 0;
+        piy0[k] = gy * a.in_sy; pix0[k] = gx * a.in_sx;
+        pbase[k] = (SPLIT ? (unsigned)bb * ((unsigned)((a.C + KCB - 1) / KCB) * KCB * HWin * 4u) : 0u) + (unsigned)(tid & 7) * 16u;
+    }
+    bool pok[4] = {false, false, false, false};
 
     const int nck = (a.C + KCB - 1) / KCB;
     int ck_beg = 0, ck_end = nck;
@@ -516,6 +535,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     unsigned ex[16], ey[NTERM == 3 ? 16 : 1];
     bool ok_r = false;
     auto load_b = [&](int cc, int t) {
+        if constexpr (PIECES) {
+            const int dy = (int)((dypack >> (4 * t)) & 15u) - 8, dx = (int)((dxpack >> (4 * t)) & 15u) - 8;
+            const unsigned so = (unsigned)cc * HWin * (KCB * EB);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int iy = piy0[k] + dy, ix = pix0[k] + dx;
+                pok[k] = pvalid[k] && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+                const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, pbase[k] + (unsigned)(iyc * a.Win + ixc) * (KCB * EB), so, 0);
+                ex[4 * k] = v.x; ex[4 * k + 1] = v.y; ex[4 * k + 2] = v.z; ex[4 * k + 3] = v.w;
+            }
+            return;
+        }
         const int iy = iy0 + (int)((dypack >> (4 * t)) & 15u) - 8, ix = ix0 + (int)((dxpack >> (4 * t)) & 15u) - 8;
         ok_r = nvalid && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
         const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
@@ -543,6 +575,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     };
     const int wrow = n_l * BPITCH, wsw = (n_l >> 2) & 3;
     auto write_b = [&](unsigned char* buf) {
+        if constexpr (PIECES) {
+            const int s = tid & 7;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int n_k = k * 32 + (tid >> 3);
+                unsigned char* p = buf + n_k * BPITCH + (((((s >> 1) ^ (n_k >> 2)) & 3) << 4) | ((s & 1) << 3));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const unsigned sel = q == 1 ? 0x07060302u : 0x05040100u;
+                    const unsigned w0 = __builtin_amdgcn_perm(ex[4 * k + 1], ex[4 * k], sel), w1 = __builtin_amdgcn_perm(ex[4 * k + 3], ex[4 * k + 2], sel);
+                    *reinterpret_cast<uint2*>(p + q * BPLANE) = pok[k] ? make_uint2(w0, w1) : make_uint2(0u, 0u);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NTERM; ++q) {
             const unsigned sel = q == 1 ? 0x07060302u : 0x05040100u;
