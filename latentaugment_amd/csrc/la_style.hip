@@ -341,14 +341,31 @@ __global__ __launch_bounds__(256) void la_seam_bwd_kernel(LaSeamArgs a) {
 #pragma unroll
     for (int k = 0; k < IMGC; ++k) weff[k] = a.wrgb[k * a.C + c] * a.s_rgb[(long)b * a.s_stride + c];
     float ddn = 0.f, gmax = 0.f;
+    // activation backward from the saved output as straight-line selects with reciprocals (the same arithmetic as the seam fused into
+    // the contraction epilogues, la_conv_device.h): la_act_bwd_from_y / la_act_inv up to the rounding of 1/gain, 1/alpha
+    const float s_pos = a.gain, s_neg = a.act == LA_ACT_LRELU ? a.gain * a.alpha : (a.act == LA_ACT_RELU ? 0.f : a.gain);
+    const float i_gain = 1.f / a.gain, i_neg = a.act == LA_ACT_LRELU ? 1.f / (a.gain * a.alpha) : 1.f / a.gain;
+    const float s_cl = a.clamp >= 0.f ? a.clamp : __builtin_huge_valf();
     float dwe[IMGC > 0 ? IMGC : 1];
 #pragma unroll
     for (int k = 0; k < IMGC; ++k) dwe[k] = 0.f;
 
-    for (long q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
+    // the HBM streams (y, the incoming gradient) of the next step are requested before this step's arithmetic: the kernel is a plain
+    // stream, what limits it is the number of bytes in flight (the image-sized operands are L2 hits)
+    const long qf = q0 + threadIdx.x;
+    float4 y_n = make_float4(0.f, 0.f, 0.f, 0.f), g_n = y_n;
+    if (qf < q1) {
+        y_n = *reinterpret_cast<const float4*>(a.y + plane + qf * 4);
+        if (a.gx_next) g_n = *reinterpret_cast<const float4*>(a.gx_next + plane + qf * 4);
+    }
+    for (long q = qf; q < q1; q += blockDim.x) {
         const long p = q * 4;
-        const float4 yv = *reinterpret_cast<const float4*>(a.y + plane + p);
-        float4 g = a.gx_next ? *reinterpret_cast<const float4*>(a.gx_next + plane + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 yv = y_n;
+        float4 g = g_n;
+        if (q + blockDim.x < q1) {
+            y_n = *reinterpret_cast<const float4*>(a.y + plane + p + 4 * (long)blockDim.x);
+            if (a.gx_next) g_n = *reinterpret_cast<const float4*>(a.gx_next + plane + p + 4 * (long)blockDim.x);
+        }
 #pragma unroll
         for (int k = 0; k < IMGC; ++k) {
             const long o = ((long)b * IMGC + k) * HW + p;
@@ -370,11 +387,12 @@ __global__ __launch_bounds__(256) void la_seam_bwd_kernel(LaSeamArgs a) {
             nz.x *= a.noise_strength; nz.y *= a.noise_strength; nz.z *= a.noise_strength; nz.w *= a.noise_strength;
         }
         float4 gz;
-#define ONE(f)                                                                               \
-        {                                                                                    \
-            const float g1 = g.f * la_act_bwd_from_y(yv.f, a.act, a.alpha, a.gain, a.clamp); \
-            ddn += g1 * (la_act_inv(yv.f, a.act, a.alpha, a.gain) - bv - nz.f);              \
-            gz.f = g1 * dm;                                                                  \
+#define ONE(f)                                                                                \
+        {                                                                                     \
+            const bool pos = yv.f > 0.f;                                                      \
+            const float g1 = g.f * (fabsf(yv.f) >= s_cl ? 0.f : (pos ? s_pos : s_neg));       \
+            ddn += g1 * (yv.f * (pos ? i_gain : i_neg) - bv - nz.f);                          \
+            gz.f = g1 * dm;                                                                   \
         }
         ONE(x) ONE(y) ONE(z) ONE(w)
 #undef ONE

@@ -360,8 +360,8 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
 // nothing measurable: the 2-term split keeps 22 significand bits of every element whatever the scale; only the absolute floor
 // (fp16 subnormals, 2^-24 in scaled units) moves, from <= 2^-39 to <= 2^-36 of the sample maximum for a bound 8x too large.
 // Workgroup = 8 rows x 64 columns x 32 channels; thread = 4 rows x 4 columns x 4 channels from 16-byte row loads (1.3 loads per
-// output; the plain FIR kernel issues 5.5), results transposed through LDS (16-byte slots XOR-swizzled by the pixel quad) so
-// that every store is a full 128-byte [pixel][32 channels] line.
+// output; the plain FIR kernel issues 5.5), results transposed through LDS (16-byte slots XOR-swizzled by the pixel quad; two rounds
+// of 4 rows, 32 KB) so that every store is a full 128-byte [pixel][32 channels] line.
 struct FirPackArgs {
     const float* in;       // [B][C][H][W], W % 4 == 0, 16-byte aligned planes
     unsigned* out;         // [B][nck][Hz*Wz][32]
@@ -370,8 +370,8 @@ struct FirPackArgs {
     float f[16];           // effective correlation taps (flip and gain folded in)
 };
 
-__global__ __launch_bounds__(256) void la_fir4x4_adj_pack_kernel(FirPackArgs a) {
-    __shared__ uint4 tile[512 * 8];                       // [8 rows x 64 cols][8 slots of 4 channels]
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void la_fir4x4_adj_pack_kernel(FirPackArgs a) {
+    __shared__ uint4 tile[256 * 8];                       // [4 rows x 64 cols][8 slots of 4 channels]: half the rows per round (32 KB)
     const int tid = threadIdx.x;
     const int xg = tid & 15, rs = (tid >> 4) & 1, cg = tid >> 5;
     const int b = blockIdx.z / a.nck, ck = blockIdx.z - b * a.nck;
@@ -424,22 +424,29 @@ __global__ __launch_bounds__(256) void la_fir4x4_adj_pack_kernel(FirPackArgs a) 
                 pk[r][k][j] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
             }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int pl = (rs * 4 + r) * 64 + xg * 4 + k;
-            tile[pl * 8 + (cg ^ ((pl >> 2) & 7))] = make_uint4(pk[r][k][0], pk[r][k][1], pk[r][k][2], pk[r][k][3]);
-        }
-    __syncthreads();
+    // two rounds through LDS (rows 0-1 then rows 2-3 of every thread): 32 KB per workgroup instead of 64, twice the waves per CU
     const long plane = (long)a.Hz * a.Wz;
     uint4* op = reinterpret_cast<uint4*>(a.out) + ((long)b * a.nck + ck) * plane * 8;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int idx = it * 256 + tid;
-        const int pl = idx >> 3, slot = idx & 7;
-        const int Y = Yb + (pl >> 6), X = Xb + (pl & 63);
-        if (Y < a.Hz && X < a.Wz) op[((long)Y * a.Wz + X) * 8 + (slot ^ ((pl >> 2) & 7))] = tile[idx];
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = half * 2 + r2;
+                const int pl = (rs * 2 + r2) * 64 + xg * 4 + k;
+                tile[pl * 8 + (cg ^ ((pl >> 2) & 7))] = make_uint4(pk[r][k][0], pk[r][k][1], pk[r][k][2], pk[r][k][3]);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int pl = idx >> 3, slot = idx & 7;
+            const int lr = pl >> 6;
+            const int Y = Yb + (lr >> 1) * 4 + half * 2 + (lr & 1), X = Xb + (pl & 63);
+            if (Y < a.Hz && X < a.Wz) op[((long)Y * a.Wz + X) * 8 + (slot ^ ((pl >> 2) & 7))] = tile[idx];
+        }
     }
 }
 
