@@ -276,6 +276,10 @@ int la_latent_opt_set_crop_pos(la_latent_opt* h, int x, int y);
  * after its first eager execution and replayed for every further step and batch of the same size -- the loop is ~230 short
  * launches per step and otherwise host-launch-bound at small batches.  0: every launch eager.  Results are identical. */
 int la_latent_opt_set_graph(la_latent_opt* h, int enable);
+/* Per-step snapshots for the reference's verbose_log (util_latent_aug.py:292-295 snap_w / snap_img): device buffers (or NULL)
+ * w_trace [steps][B][w_dim] = the optimised latent after every step, img_trace [steps][B][C][R][R] = the image synthesised in
+ * every step.  While either is set the loop launches eagerly. */
+int la_latent_opt_set_trace(la_latent_opt* h, float* w_trace, float* img_trace);
 /* w0 [B][w_dim] -> img_out [B][C][R][R], w_aug_out [B][num_ws][w_dim]; losses_out (may be NULL) [steps][4] =
  * weighted {latent, pix, disc, lpips} per step. */
 int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const float* const* final_noises, float* img_out,

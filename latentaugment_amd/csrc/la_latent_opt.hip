@@ -39,6 +39,8 @@ struct la_latent_opt {
     hipGraph_t graph;
     hipGraphExec_t graph_exec;
     hipStream_t cap_stream; // capture needs a non-default stream; the replay goes to the caller's stream
+    float* trace_w;         // optional [steps][B][w_dim]: the latent after every step (verbose_log snapshots); forces eager launches
+    float* trace_img;       // optional [steps][B][C][R][R]: the image synthesised in every step
 };
 
 static size_t al(size_t n) { return ((n * sizeof(float)) + 63) & ~(size_t)63; }
@@ -112,6 +114,12 @@ extern "C" void la_latent_opt_destroy(la_latent_opt* h) {
 }
 
 // 1 (default): steps 2..N of the first batch and every step of later batches replay ONE captured step; 0: every launch eager
+extern "C" int la_latent_opt_set_trace(la_latent_opt* h, float* w_trace, float* img_trace) {
+    LA_CHECK_ARG(h, "latent_opt_set_trace: null handle");
+    h->trace_w = w_trace; h->trace_img = img_trace;
+    return LA_OK;
+}
+
 extern "C" int la_latent_opt_set_graph(la_latent_opt* h, int enable) {
     LA_CHECK_ARG(h, "latent_opt_set_graph: null handle");
     h->graph_mode = enable ? 1 : 0;
@@ -291,7 +299,8 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     // Replay of a captured step.  The step is captured AFTER one eager execution with the same batch size (module loading,
     // per-device attribute opt-ins and every other first-use effect happen outside the capture).  While the launch profiler
     // (la_prof_begin .. la_prof_end) is on, launches stay eager so that its event brackets see them.  If capture is refused the handle falls back to eager launches of the same kernels.
-    const bool replay = h->graph_mode == 1 && !want_losses && c.steps > 0 && !la_prof_enabled();
+    const bool tracing = h->trace_w || h->trace_img;
+    const bool replay = h->graph_mode == 1 && !want_losses && !tracing && c.steps > 0 && !la_prof_enabled();
     int first_graph_step = 1;
     if (replay && (!h->graph_exec || h->graph_B != B)) {
         drop_graph(h);
@@ -313,7 +322,14 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     }
     for (int step = first_graph_step; step <= c.steps; ++step) {
         if (replay && h->graph_exec && h->graph_B == B) LA_HIP(hipGraphLaunch(h->graph_exec, stream));
-        else if ((rc = run_step(want_losses ? h->losses + (size_t)(step - 1) * 4 : nullptr, stream))) return rc;
+        else {
+            if ((rc = run_step(want_losses ? h->losses + (size_t)(step - 1) * 4 : nullptr, stream))) return rc;
+            // verbose_log snapshots (util_latent_aug.py:292-295): the image synthesised in this step, the latent after its update
+            if (h->trace_img)
+                LA_HIP(hipMemcpyAsync(h->trace_img + (size_t)(step - 1) * B * h->imgc * h->R * h->R, la_synth_image(h->g),
+                                      sizeof(float) * (size_t)B * h->imgc * h->R * h->R, hipMemcpyDeviceToDevice, stream));
+            if (h->trace_w) LA_HIP(hipMemcpyAsync(h->trace_w + (size_t)(step - 1) * nw, h->w_opt, sizeof(float) * nw, hipMemcpyDeviceToDevice, stream));
+        }
     }
     if ((rc = la_broadcast_mix(h->w_opt, w0, w_aug_out, B, h->num_ws, wd, c.alpha, c.soft_aug, stream))) return rc;
     if ((rc = la_synth_forward(h->g, w_aug_out, (long)h->num_ws * wd, wd, B, c.final_noise_mode, final_noises, img_out, stream)))

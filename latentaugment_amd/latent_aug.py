@@ -40,6 +40,21 @@ def get_params(load_size, crop_size, preprocess='center_random_crop'):
     return {'crop_pos': (x, y)}
 
 
+def write_png_gray(path, a):
+    """8-bit greyscale PNG of a 2-D uint8 array (the reference writes its snapshots with cv2.imwrite, :655)."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    h, w = a.shape
+    raw = b''.join(b'\x00' + a[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        return struct.pack('>I', len(data)) + tag + data + struct.pack('>I', zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, 'wb') as f:
+        f.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, 0, 0, 0, 0)) + chunk(b'IDAT', zlib.compress(raw, 6)) +
+                chunk(b'IEND', b''))
+
+
 def shard_bounds(batch, world_size, rank):
     """Contiguous sample range of a rank: [rank*b, (rank+1)*b) with b = ceil(batch / world_size)."""
     per = (batch + world_size - 1) // world_size
@@ -151,6 +166,8 @@ class LatentAug:
         self._mapping = None
         self.stats_dataset_w = latent_codes
         self.stats_loss = {}
+        self.stats_time = {}
+        self._verbose_flag = bool(opt.verbose_log)      # the reference logs the FIRST batch only (:189-191, :297-300)
 
         if banks is None and getattr(opt, 'interim_dir', None) and getattr(opt, 'dataset_aug', None):
             # real-data banks from the interim zips (reference :137-158), cached as DatasetStats pickles
@@ -292,8 +309,9 @@ class LatentAug:
         off = self.center_off if self.preprocess in ('center_crop', 'center_random_crop') else 0
         return off + int(x1), off + int(y1)
 
-    def run_local(self, w, final_noises=None, want_losses=False, crop_pos=None):
-        """w [b,1,w_dim] on this device -> (img [b,C,R,R], w_aug [b,num_ws,w_dim], losses or None)."""
+    def run_local(self, w, final_noises=None, want_losses=False, crop_pos=None, trace=None):
+        """w [b,1,w_dim] on this device -> (img [b,C,R,R], w_aug [b,num_ws,w_dim], losses or None).
+        trace (optional): dict that receives 'w' [steps,b,w_dim] and 'img' [steps,b,C,R,R], the per-step snapshots."""
         if self.feat is not None:
             if crop_pos is None:
                 crop_pos = getattr(self, 'crop_params', None)
@@ -311,11 +329,56 @@ class LatentAug:
             if final_noises is None:
                 final_noises = self.engine.make_noises(b)
             fn = self.engine.noise_pointer_array(final_noises)
+        tw = ti = None
+        if trace is not None and self.num_epochs > 0:
+            tw = torch.empty([self.num_epochs, b, self.w_dim], device=self.device, dtype=torch.float32)
+            ti = torch.empty([self.num_epochs, b, self.engine.img_channels, self.res, self.res], device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.la_latent_opt_run(self._h, _lib.ptr(w), b, fn, _lib.ptr(img), _lib.ptr(w_aug),
-                                                   _lib.ptr(losses), _lib.stream_ptr()), 'la_latent_opt_run')
+            if tw is not None:
+                _lib.check(self._lib.la_latent_opt_set_trace(self._h, _lib.ptr(tw), _lib.ptr(ti)), 'la_latent_opt_set_trace')
+            try:
+                _lib.check(self._lib.la_latent_opt_run(self._h, _lib.ptr(w), b, fn, _lib.ptr(img), _lib.ptr(w_aug),
+                                                       _lib.ptr(losses), _lib.stream_ptr()), 'la_latent_opt_run')
+            finally:
+                if tw is not None:
+                    _lib.check(self._lib.la_latent_opt_set_trace(self._h, None, None), 'la_latent_opt_set_trace')
+        if tw is not None:
+            trace['w'], trace['img'] = tw, ti
         self._keep = final_noises
         return img, w_aug, losses
+
+    # ---- verbose_log artefacts of the first batch (reference :278-300, :620-655)
+    def _log_first_batch(self, losses, elapsed, trace, fname):
+        import json
+        import pickle
+        L = losses.cpu().numpy()
+        active = [('loss_latent', 0, self._cfg.w_latent), ('loss_disc', 2, self._cfg.w_disc), ('loss_pix', 1, self._cfg.w_pix),
+                  ('loss_lpips', 3, self._cfg.w_lpips)]
+        for e in range(self.num_epochs):
+            st = {name: float(L[e, col]) for name, col, wgt in active if wgt > 0}      # only the active criteria are logged (:233-268)
+            st['loss'] = float(-L[e, 0] - L[e, 1] - L[e, 3] + L[e, 2])
+            self.stats_loss[f'epoch_{e}'] = st
+            # the loop runs on the device without a host round trip per epoch: the batch time is spread evenly over the epochs
+            self.stats_time[f'epoch_{e}'] = {'time_epoch': elapsed / max(self.num_epochs, 1)}
+            desc = ''.join(f'{k} {v:<4.2f} ' for k, v in st.items()) + '||| ' + f"time_epoch {self.stats_time[f'epoch_{e}']['time_epoch']:<4.3f} "
+            print(f'epoch {e + 1:>4d}/{self.num_epochs}, {desc}')
+        if self.save_dir and self.num_epochs > 0:
+            os.makedirs(self.save_dir, exist_ok=True)
+            for stats, title in ((self.stats_loss, 'losses'), (self.stats_time, 'times [s]')):
+                with open(os.path.join(self.save_dir, f'{title}.jsonl'), 'w') as f:      # (the reference's per-key PNG plots need matplotlib)
+                    f.write(json.dumps(stats, indent=2) + '\n')
+            if trace and 'w' in trace and fname:      # snapshots only with a batch of one (:292-295)
+                base = os.path.splitext(os.path.basename(str(fname[0])))[0]
+                tw, ti = trace['w'].cpu().numpy(), trace['img'].cpu().numpy()
+                for e in range(self.num_epochs):
+                    with open(os.path.join(self.save_dir, f'w_{base}_{e}.pkl'), 'wb') as f:
+                        pickle.dump(tw[e].squeeze(), f, pickle.HIGHEST_PROTOCOL)
+                    if ti.shape[2] >= 2:
+                        row = np.concatenate([ti[e, 0, 0], ti[e, 0, 1]], axis=1)      # modality A | modality B
+                    else:
+                        row = ti[e, 0, 0]
+                    row = ((np.clip(row, -1.0, 1.0) + 1) / 2 * 255.0).astype(np.uint8)
+                    write_png_gray(os.path.join(self.save_dir, f'{base}_{e}.png'), row)
 
     def forward(self, w, fname=None, final_noises=None):
         """LatentAug.forward(w, fname) (reference :207-310): returns (imgAB_aug, w_aug) for the FULL batch.
@@ -357,12 +420,17 @@ class LatentAug:
             img = full[:, :n_img].reshape(B, self.engine.img_channels, self.res, self.res)
             w_aug = full[:, n_img:].reshape(B, self.num_ws, self.w_dim)
             return img, w_aug
-        img, w_aug, losses = self.run_local(w, final_noises, want_losses=bool(self.verbose_log))
-        if self.verbose_log and losses is not None:
-            L = losses.cpu().numpy()
-            for e in range(self.num_epochs):
-                self.stats_loss[f'epoch_{e}'] = dict(loss_latent=float(L[e, 0]), loss_pix=float(L[e, 1]), loss_disc=float(L[e, 2]),
-                                                     loss_lpips=float(L[e, 3]), loss=float(-L[e, 0] - L[e, 1] - L[e, 3] + L[e, 2]))
+        if self._verbose_flag:
+            import time
+            trace = {} if w.shape[0] == 1 else None
+            torch.cuda.synchronize(self.device)
+            t0 = time.time()
+            img, w_aug, losses = self.run_local(w, final_noises, want_losses=True, trace=trace)
+            torch.cuda.synchronize(self.device)
+            self._log_first_batch(losses, time.time() - t0, trace, fname)
+            self._verbose_flag = False
+            return img, w_aug
+        img, w_aug, _ = self.run_local(w, final_noises)
         return img, w_aug
 
     __call__ = forward
