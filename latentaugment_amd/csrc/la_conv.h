@@ -76,6 +76,13 @@ struct LaConvArgs {
     const float* seam_gimg; const float* seam_rgbpre; float seam_rgb_clamp;
     const float* seam_wrgb; const float* seam_srgb; int seam_srgb_stride;
     float* seam_dweff_part;  // [B][imgc][M][tiles_per_sample]
+    // Fused ToRGB of the block (LA_EPI_FWD, 16-bit halo launches whose ONE row tile holds every output channel, M == tile rows):
+    //   rgb_pre[b][c][px] = sum_m rgb_w[c][m] * rgb_s[b][m] * out[b][m][px] + rgb_bias[c];  rgb_img = clamp(rgb_pre) + rgb_skip
+    // (la_torgb_fwd_kernel's arithmetic on the epilogue's registers: the block's conv1 output is not streamed a second time)
+    int rgb_imgc;            // 0: none
+    const float* rgb_w; const float* rgb_s; int rgb_s_stride; const float* rgb_bias;
+    const float* rgb_skip;   // [B][imgc][Hout*Wout] or null
+    float* rgb_pre; float* rgb_img; float rgb_clamp;
     // optional caller-provided scratch (la_conv_workspace_bytes): [fp16 scale header | pre-split input | split-K slice partials]
     void* ws;
     size_t ws_bytes;

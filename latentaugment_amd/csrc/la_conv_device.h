@@ -274,6 +274,24 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
         // activation as straight-line selects (same arithmetic as la_act_fwd)
         const float slope = a.act == LA_ACT_LRELU ? a.alpha : (a.act == LA_ACT_RELU ? 0.f : 1.f);
         const float cl = a.clamp >= 0.f ? a.clamp : __builtin_huge_valf();
+        // fused ToRGB (LaConvArgs::rgb_*): effective weights of this tile's rows in LDS rows 16.., per-lane partial sums over the
+        // lane's 16 rows, then over the two half-waves and the waves along M (LDS, floats [wm][c][128 pixels] behind the row tables)
+        constexpr int RGB_MAXC = 4;
+        const int rgbc = (fwd && TILE2D && a.rgb_imgc > 0 && MT == a.M) ? a.rgb_imgc : 0;
+        float* rgbp = &red[0][0] + 40 * MT;
+        float pr[RGB_MAXC][NJ];
+#pragma unroll
+        for (int c = 0; c < RGB_MAXC; ++c)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) pr[c][j] = 0.f;
+        if (rgbc > 0) {
+            if (tid < MT) {
+#pragma unroll
+                for (int c = 0; c < RGB_MAXC; ++c)
+                    if (c < rgbc) red[16 + c][tid] = a.rgb_w[(long)c * a.M + tid] * a.rgb_s[(long)b * a.rgb_s_stride + tid];
+            }
+            __syncthreads();
+        }
         float* o2 = (fwd && a.out2) ? a.out2 + ((long)b * a.M + m0 + mw) * HWo : nullptr;
         const float* ad = (o2 && a.addend) ? a.addend + ((long)b * a.M + m0 + mw) * HWo : nullptr;
 #pragma unroll
@@ -300,7 +318,37 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                     }
                     if (!LA_NOSTORE || v == 1.2345e30f) o0[(long)mr * HWo + np[j]] = v;
                     if (o2) o2[(long)mr * HWo + np[j]] = v + (ad ? av[r][j] : 0.f);
+                    if (rgbc > 0) {
+#pragma unroll
+                        for (int c = 0; c < RGB_MAXC; ++c)
+                            if (c < rgbc) pr[c][j] += red[16 + c][mw + mr] * v;
+                    }
                 }
+            }
+        }
+        if (rgbc > 0) {
+#pragma unroll
+            for (int c = 0; c < RGB_MAXC; ++c)
+                if (c < rgbc) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const float t = pr[c][j] + __shfl_xor(pr[c][j], 32, 64);      // rows of the other half-wave
+                        if (lh == 0) rgbp[(wm * RGB_MAXC + c) * NT + (wn * NJ + j) * 32 + l31] = t;
+                    }
+                }
+            __syncthreads();
+            for (int k = tid; k < rgbc * NT; k += 256) {
+                const int c = k / NT, tp = k - c * NT;
+                float t = rgbp[c * NT + tp];
+#pragma unroll
+                for (int w = 1; w < WM_; ++w) t += rgbp[(w * RGB_MAXC + c) * NT + tp];
+                t += a.rgb_bias ? a.rgb_bias[c] : 0.f;
+                const int tpr = a.Gx >> 5;
+                const int tyb = ntile / tpr, txb = ntile - tyb * tpr;
+                const long pos = ((long)b * rgbc + c) * HWo + (long)(tyb * 4 + (tp >> 5)) * a.Wout + txb * 32 + (tp & 31);
+                a.rgb_pre[pos] = t;
+                if (a.rgb_clamp >= 0.f) t = fminf(fmaxf(t, -a.rgb_clamp), a.rgb_clamp);
+                a.rgb_img[pos] = t + (a.rgb_skip ? a.rgb_skip[pos] : 0.f);
             }
         }
         return;

@@ -7,10 +7,19 @@
 // Internal variants with plane maxima passed between producer and consumer (fp16 operand scale without an absmax pass):
 //   in_pmax  [B][C][in_nseg]: partial max |input| per plane, written by the kernel that produced the input
 //   y_pmax   [B][cout][la_fir4x4_segments(res, res)]: partial max |y| per plane, written by the FIR epilogue of the up-sampling layer
+// ToRGB of the block fused into the epilogue of its conv1 (LaConvArgs::rgb_*): possible where one row tile of the halo kernel holds
+// every output channel (la_modconv3x3_fwd_fuses_rgb); weights [imgc][cout], styles [B][s_stride] (already * weight_gain), bias [imgc],
+// skip [B][imgc][res^2] or null, outputs rgb_pre / img [B][imgc][res^2]
+struct LaRgbFuse {
+    int imgc;
+    const float* w; const float* s; int s_stride; const float* bias; const float* skip;
+    float* rgb_pre; float* img; float clamp;
+};
+bool la_modconv3x3_fwd_fuses_rgb(int precision, int B, int cin, int cout, int res);
 int la_modconv3x3_fwd_ex(const float* x, long x_bstride, const float* in_pmax, int in_nseg, const float* wf, const void* wq, int precision, const float* s,
                          int s_stride, const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                          const float* bias, int act, float alpha, float gain, float clamp, float* y, void* ws, size_t ws_bytes, int B,
-                         int cin, int cout, int res, hipStream_t stream, const float* xscale = nullptr);
+                         int cin, int cout, int res, hipStream_t stream, const float* xscale = nullptr, const LaRgbFuse* rgb = nullptr);
 int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
                              const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                              const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,

@@ -22,12 +22,34 @@ extern "C" int la_pack_conv_weights_f32(const float* w, float* wf, float* wb, fl
     return la_pack_conv_weights(w, wf, wb, wsq, cout, cin, ktaps, stream);
 }
 
+static void fwd_shape(LaConvArgs& a, int precision, int B, int cin, int cout, int res) {
+    a.precision = precision;
+    a.B = B; a.C = cin; a.M = cout; a.Hin = a.Win = a.Hout = a.Wout = a.Gy = a.Gx = res;
+    a.ntaps = 9;
+    for (int t = 0; t < 9; ++t) { a.tap_dy[t] = t / 3 - 1; a.tap_dx[t] = t % 3 - 1; a.tap_w[t] = t; }
+}
+
+// one row tile of the halo kernel = all output channels (tiles of 128, 64 or -- for <= 32 channels -- 32 rows, la_conv_launch)
+bool la_modconv3x3_fwd_fuses_rgb(int precision, int B, int cin, int cout, int res) {
+    static const bool off = getenv("LA_NO_RGB_FUSE") != nullptr;      // dev knob
+    if (off || precision == LA_PREC_F32 || (cout != 128 && cout != 64 && cout != 32)) return false;
+    LaConvArgs a; base_args(a);
+    fwd_shape(a, precision, B, cin, cout, res);
+    return la_conv_bf16_uses_halo(a);
+}
+
 int la_modconv3x3_fwd_ex(const float* x, long x_bstride, const float* in_pmax, int in_nseg, const float* wf, const void* wq, int precision, const float* s,
                          int s_stride, const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                          const float* bias, int act, float alpha, float gain, float clamp, float* y, void* ws, size_t ws_bytes, int B,
-                         int cin, int cout, int res, hipStream_t stream, const float* xscale) {
+                         int cin, int cout, int res, hipStream_t stream, const float* xscale, const LaRgbFuse* rgb) {
     LA_CHECK_ARG(x && wf && y, "modconv_fwd: null pointer");
     LaConvArgs a; base_args(a);
+    if (rgb) {
+        LA_CHECK_ARG(rgb->imgc >= 1 && rgb->imgc <= 4 && rgb->w && rgb->s && rgb->rgb_pre && rgb->img && la_modconv3x3_fwd_fuses_rgb(precision, B, cin, cout, res),
+                     "modconv_fwd: this launch cannot carry the fused ToRGB (la_modconv3x3_fwd_fuses_rgb)");
+        a.rgb_imgc = rgb->imgc; a.rgb_w = rgb->w; a.rgb_s = rgb->s; a.rgb_s_stride = rgb->s_stride; a.rgb_bias = rgb->bias;
+        a.rgb_skip = rgb->skip; a.rgb_pre = rgb->rgb_pre; a.rgb_img = rgb->img; a.rgb_clamp = rgb->clamp;
+    }
     if (precision == LA_PREC_F16X2) a.acc_scale_x = xscale;      // preset operand scale (bound-based): no absmax / plane-maxima pass
     a.in = x; a.in_bstride = x_bstride; a.wgt = wf; a.out = y; a.in_pmax = in_pmax; a.in_pmax_nseg = in_nseg;
     a.in_scale = s; a.scale_stride = s_stride;

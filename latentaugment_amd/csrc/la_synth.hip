@@ -331,6 +331,18 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
     for (int k = 0; k < h->nblocks; ++k) {
         const int res = 4 << k;
         const int nl = (k == 0) ? 1 : 2;
+        RgbLayer& T = h->rgb[k];
+        float* const rgb_dst = (k == h->nblocks - 1 && img_out) ? img_out : T.img;
+        // ToRGB inside the epilogue of the block's conv1 where one row tile of the halo kernel holds all its channels (the top blocks:
+        // <= 128 channels at >= 64^2) -- conv1's output is then not streamed a second time
+        const bool fuse_rgb = la_modconv3x3_fwd_fuses_rgb(h->precision, B, h->conv[ci + nl - 1].cin, h->conv[ci + nl - 1].cout, res);
+        const float* skip = nullptr;
+        if (k > 0 && fuse_rgb) {      // (the skip image has to exist before conv1 runs)
+            RgbLayer& P = h->rgb[k - 1];
+            if ((rc = la_upfirdn2d_ex(P.img, T.g_img, B, h->imgc, res / 2, res / 2, h->fir, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1, 0, 4.f, nullptr, stream)))
+                return rc;
+            skip = T.g_img;
+        }
         for (int q = 0; q < nl; ++q, ++ci) {
             ConvLayer& L = h->conv[ci];
             L.noise_used = nullptr; L.noise_bstride = 0;
@@ -339,10 +351,14 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
                 else if (noise_mode == 2) { L.noise_used = noises[ci]; L.noise_bstride = (long)res * res; LA_CHECK_ARG(L.noise_used, "synth_forward: missing noise tensor"); }
             }
             const float sq2 = sqrtf(2.f);
+            LaRgbFuse rf;
+            rf.imgc = h->imgc; rf.w = T.weight; rf.s = h->s_all + T.s_off; rf.s_stride = h->S; rf.bias = T.bias; rf.skip = skip;
+            rf.rgb_pre = T.rgb_pre; rf.img = rgb_dst; rf.clamp = h->clamp;
             if (!L.up) {
                 rc = la_modconv3x3_fwd_ex(x, x_bstride, x_pmax, x_nseg, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                           L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f, sq2,
-                                          h->clamp, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream, bound_scale ? h->xs_fwd + (long)ci * B : nullptr);
+                                          h->clamp, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream, bound_scale ? h->xs_fwd + (long)ci * B : nullptr,
+                                          (fuse_rgb && q == nl - 1) ? &rf : nullptr);
                 x_pmax = nullptr;
             } else {
                 rc = la_modconv3x3_up2_fwd_ex(x, x_bstride, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
@@ -356,21 +372,20 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
             if (rc) return rc;
             x = L.y; x_bstride = (long)L.cout * res * res;
         }
-        RgbLayer& T = h->rgb[k];
-        const float* skip = nullptr;
-        if (k > 0) {
-            // img = upsample2d(img_prev, f): up 2, pad (2,1,2,1), gain 4 (upfirdn2d.py:342-348); result parked in g_img scratch
-            RgbLayer& P = h->rgb[k - 1];
-            if ((rc = la_upfirdn2d_ex(P.img, T.g_img, B, h->imgc, res / 2, res / 2, h->fir, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1, 0,
-                                      4.f, nullptr, stream)))
+        if (!fuse_rgb) {
+            if (k > 0) {
+                // img = upsample2d(img_prev, f): up 2, pad (2,1,2,1), gain 4 (upfirdn2d.py:342-348); result parked in g_img scratch
+                RgbLayer& P = h->rgb[k - 1];
+                if ((rc = la_upfirdn2d_ex(P.img, T.g_img, B, h->imgc, res / 2, res / 2, h->fir, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1, 0,
+                                          4.f, nullptr, stream)))
+                    return rc;
+                skip = T.g_img;
+            }
+            if ((rc = la_torgb_forward(x, T.weight, h->s_all + T.s_off, h->S, T.bias, skip, T.rgb_pre, rgb_dst, B, T.cin, h->imgc,
+                                       res, res, h->clamp, stream)))
                 return rc;
-            skip = T.g_img;
         }
-        float* dst = (k == h->nblocks - 1 && img_out) ? img_out : T.img;
-        if ((rc = la_torgb_forward(x, T.weight, h->s_all + T.s_off, h->S, T.bias, skip, T.rgb_pre, dst, B, T.cin, h->imgc,
-                                   res, res, h->clamp, stream)))
-            return rc;
-        if (k == h->nblocks - 1) h->final_img = dst;
+        if (k == h->nblocks - 1) h->final_img = rgb_dst;
     }
     return LA_OK;
 }
