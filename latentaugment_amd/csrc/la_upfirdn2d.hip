@@ -275,6 +275,103 @@ static bool fir_separable(const float* f, float* fx, float* fy) {
 
 int la_fir4x4_segments(int Hout, int Wout) { return la_cdiv(Wout, 64) * la_cdiv(Hout, 4 * FIR_ROWS); }
 
+// 4x4 FIR around a factor-2 resampling of few, possibly large planes (the image pyramid of the skip architecture: upsample2d
+// forward, upfirdn2d.py:342-348, and its adjoint-by-decimation in the backward pass).  Same taps, same accumulation order (rows,
+// then columns, ascending) as the generic kernel above, without its per-output tap search; work item = 2 x 4 (up) / 1 x 2 (down)
+// outputs, flat over all planes.
+__global__ __launch_bounds__(256) void la_fir4x4_up2_kernel(FirArgs a) {      // up 2, pad0 2: out [2H][2W]
+    const int wq = a.Wout >> 2;                                  // 4-column groups per output row
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_plane = (long)a.Hin * wq;
+    const int p = (int)(gid / per_plane);
+    if (p >= a.P) return;
+    const int within = (int)(gid - (long)p * per_plane);
+    const int i = within / wq, q = within - i * wq;
+    const int j0 = 2 * q;
+    const float* ip = a.in + (long)p * a.Hin * a.Win;
+    float v[3][4];                                               // in[i-1 .. i+1][j0-1 .. j0+2], zero outside
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int iy = i - 1 + r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ix = j0 - 1 + c;
+            v[r][c] = (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) ? ip[(long)iy * a.Win + ix] : 0.f;
+        }
+    }
+    const long HWout = (long)a.Hout * a.Wout;
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                            // output column 4q + k = 2 (j0 + k/2) + (k & 1)
+            const int px = k & 1, jj = k >> 1;
+            float s = 0.f;
+#pragma unroll
+            for (int ua = 0; ua < 2; ++ua) {                     // taps ta = py + 2 ua at input row i + py + ua - 1
+                const int ta = py + 2 * ua, r = py + ua;
+#pragma unroll
+                for (int ub = 0; ub < 2; ++ub) {
+                    const int tb = px + 2 * ub, c = jj + px + ub;
+                    s += v[r][c] * a.f[ta * 4 + tb];
+                }
+            }
+            o[k] = s;
+        }
+        const long pos = (long)(2 * i + py) * a.Wout + 4 * q;
+        if (a.addend) {
+            const float4 ad = *reinterpret_cast<const float4*>(a.addend + (long)p * HWout + pos);
+            o[0] += ad.x; o[1] += ad.y; o[2] += ad.z; o[3] += ad.w;
+        }
+        *reinterpret_cast<float4*>(a.out + (long)p * HWout + pos) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void la_fir4x4_down2_kernel(FirArgs a) {    // down 2, pad0 1: out [H/2][W/2]
+    const int wq = a.Wout >> 1;                                  // 2-column groups per output row
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_plane = (long)a.Hout * wq;
+    const int p = (int)(gid / per_plane);
+    if (p >= a.P) return;
+    const int within = (int)(gid - (long)p * per_plane);
+    const int y = within / wq, q = within - y * wq;
+    const float* ip = a.in + (long)p * a.Hin * a.Win;
+    float v[4][6];                                               // in[2y-1 .. 2y+2][4q-1 .. 4q+4]
+    const bool vec = (a.Win & 3) == 0 && (((size_t)a.in) & 15) == 0;      // (Win = 2 Wout is even; rows 16-byte aligned when Win % 4 == 0)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int iy = 2 * y - 1 + r;
+        const bool rok = iy >= 0 && iy < a.Hin;
+        const float* rp = ip + (long)(rok ? iy : 0) * a.Win + 4 * q;
+        if (vec) {      // columns 4q .. 4q+3 as one 16-byte load, the two neighbours as dwords
+            const float4 m = rok ? *reinterpret_cast<const float4*>(rp) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[r][1] = m.x; v[r][2] = m.y; v[r][3] = m.z; v[r][4] = m.w;
+            v[r][0] = (rok && q > 0) ? rp[-1] : 0.f;
+            v[r][5] = (rok && 4 * q + 4 < a.Win) ? rp[4] : 0.f;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int ix = 4 * q - 1 + c;
+                v[r][c] = (rok && ix >= 0 && ix < a.Win) ? rp[c - 1] : 0.f;
+            }
+        }
+    }
+    float o[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) s += v[ta][2 * k + tb] * a.f[ta * 4 + tb];
+        o[k] = s;
+    }
+    const long HWout = (long)a.Hout * a.Wout;
+    const long pos = (long)y * a.Wout + 2 * q;
+    if (a.addend) { o[0] += a.addend[(long)p * HWout + pos]; o[1] += a.addend[(long)p * HWout + pos + 1]; }
+    *reinterpret_cast<float2*>(a.out + (long)p * HWout + pos) = make_float2(o[0], o[1]);
+}
+
 static int fir_launch_inner(const FirArgs& a, hipStream_t stream);
 static int fir_launch(const FirArgs& a, hipStream_t stream) {
     // launch profiler: one read of the input planes + one write of the output planes
@@ -310,6 +407,22 @@ static int fir_launch_inner(const FirArgs& a, hipStream_t stream) {
         LA_CHECK_ARG(g.y <= 65535, "upfirdn2d: output too tall");
         if (a.epi == 1) hipLaunchKernelGGL(la_fir4x4_s1_kernel<1>, g, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(la_fir4x4_s1_kernel<0>, g, dim3(256), 0, stream, a);
+        LA_CHECK_LAUNCH();
+        return LA_OK;
+    }
+    // the image pyramid's factor-2 resamplers (dense input, 4x4 taps, aligned outputs)
+    const bool plain = a.fw == 4 && a.fh == 4 && a.epi == 0 && !a.pmax && a.in_pitch == a.Win && a.in_plane == (long)a.Hin * a.Win;
+    if (plain && a.upx == 2 && a.upy == 2 && a.dnx == 1 && a.dny == 1 && a.padx0 == 2 && a.pady0 == 2 && a.Wout == 2 * a.Win && a.Hout == 2 * a.Hin &&
+        a.Wout % 4 == 0 && (((size_t)a.out | (size_t)a.addend) & 15) == 0) {
+        const long items = (long)a.P * a.Hin * (a.Wout / 4);
+        hipLaunchKernelGGL(la_fir4x4_up2_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, a);
+        LA_CHECK_LAUNCH();
+        return LA_OK;
+    }
+    if (plain && a.upx == 1 && a.upy == 1 && a.dnx == 2 && a.dny == 2 && a.padx0 == 1 && a.pady0 == 1 && 2 * a.Wout == a.Win && 2 * a.Hout == a.Hin &&
+        a.Wout % 2 == 0 && (((size_t)a.out) & 7) == 0) {
+        const long items = (long)a.P * a.Hout * (a.Wout / 2);
+        hipLaunchKernelGGL(la_fir4x4_down2_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, a);
         LA_CHECK_LAUNCH();
         return LA_OK;
     }
