@@ -155,13 +155,16 @@ __global__ __launch_bounds__(256) void la_bank_colsum_kernel(const float* __rest
     __shared__ float comb[4][64];
     const int kl = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long k = (long)blockIdx.x * 64 + kl;
-    float a0 = 0.f, a1 = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four rows in flight per thread (the scan is a plain HBM stream)
     if (k < K) {
         long r = w;
-        for (; r + 4 < m; r += 8) { a0 += Y[r * K + k]; a1 += Y[(r + 4) * K + k]; }
-        if (r < m) a0 += Y[r * K + k];
+        for (; r + 12 < m; r += 16) {
+            const float v0 = Y[r * K + k], v1 = Y[(r + 4) * K + k], v2 = Y[(r + 8) * K + k], v3 = Y[(r + 12) * K + k];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; r < m; r += 4) a0 += Y[r * K + k];
     }
-    comb[w][kl] = a0 + a1;
+    comb[w][kl] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (w == 0 && k < K) colsum[k] = (comb[0][kl] + comb[1][kl]) + (comb[2][kl] + comb[3][kl]);
 }
