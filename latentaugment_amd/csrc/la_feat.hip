@@ -176,40 +176,66 @@ __global__ void la_pool2_bwd_kernel(const float* __restrict__ x, const float* __
     gx[base] = am == 0 ? g : 0.f; gx[base + 1] = am == 1 ? g : 0.f; gx[base + R] = am == 2 ? g : 0.f; gx[base + R + 1] = am == 3 ? g : 0.f;
 }
 
-// tap forward: feat[n][off + c*HW + p] = f * rsqrt(sum_c f^2 + 1e-10) * sqrt(lin[c]) / sqrt(HW);  one thread per (n, p)
-__global__ void la_tap_fwd_kernel(const float* __restrict__ f, const float* __restrict__ lin, float* __restrict__ feat, int C,
-                                  int HW, long F, long off, long total) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const long n = i / HW; const int p = (int)(i - n * HW);
+// tap forward: feat[n][off + c*HW + p] = f * rsqrt(sum_c f^2 + 1e-10) * sqrt(lin[c]) / sqrt(HW)
+// Workgroup = PL pixel lanes (consecutive pixels: coalesced) x 256 / PL channel groups of one image; every thread walks C / groups
+// channels, the channel sums are combined through LDS in a fixed order.  (Round 1 ran one thread per pixel over all C channels:
+// 16 threads walking 512 channels three times at the 4x4 tap of VGG16, 555 us.)
+__global__ __launch_bounds__(256) void la_tap_fwd_kernel(const float* __restrict__ f, const float* __restrict__ lin, float* __restrict__ feat, int C,
+                                                          int HW, long F, long off, int PL) {
+    __shared__ float red[256];
+    const int pl = threadIdx.x % PL, cg = threadIdx.x / PL, CG = 256 / PL;
+    const int p = blockIdx.x * PL + pl;
+    const long n = blockIdx.y;
+    const bool ok = p < HW;
     const float* fp = f + n * C * HW + p;
     float s = 0.f;
-    for (int c = 0; c < C; ++c) { const float v = fp[(long)c * HW]; s += v * v; }
-    const float r = rsqrtf(s + 1e-10f) * rsqrtf((float)HW);
+    if (ok)
+        for (int c = cg; c < C; c += CG) { const float v = fp[(long)c * HW]; s += v * v; }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    float tot = 0.f;
+    for (int g = 0; g < CG; ++g) tot += red[g * PL + pl];
+    const float r = rsqrtf(tot + 1e-10f) * rsqrtf((float)HW);
+    if (!ok) return;
     float* o = feat + n * F + off + p;
-    for (int c = 0; c < C; ++c) o[(long)c * HW] = fp[(long)c * HW] * r * sqrtf(lin[c]);
+    for (int c = cg; c < C; c += CG) o[(long)c * HW] = fp[(long)c * HW] * r * sqrtf(lin[c]);
 }
 
-// tap backward: gf[k] (+)= r * (u_k - y_k * sum_c u_c y_c),  u_c = g_c * sqrt(lin_c)/sqrt(HW),  y_c = f_c * r
-__global__ void la_tap_bwd_kernel(const float* __restrict__ f, const float* __restrict__ lin, const float* __restrict__ gfeat,
-                                  float* __restrict__ gf, int C, int HW, long F, long off, long total, int accumulate) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const long n = i / HW; const int p = (int)(i - n * HW);
+// tap backward: gf[k] (+)= r * (u_k - y_k * sum_c u_c y_c),  u_c = g_c * sqrt(lin_c)/sqrt(HW),  y_c = f_c * r   (same thread layout)
+__global__ __launch_bounds__(256) void la_tap_bwd_kernel(const float* __restrict__ f, const float* __restrict__ lin, const float* __restrict__ gfeat,
+                                                          float* __restrict__ gf, int C, int HW, long F, long off, int PL, int accumulate) {
+    __shared__ float red[2][256];
+    const int pl = threadIdx.x % PL, cg = threadIdx.x / PL, CG = 256 / PL;
+    const int p = blockIdx.x * PL + pl;
+    const long n = blockIdx.y;
+    const bool ok = p < HW;
     const float* fp = f + n * C * HW + p;
     const float* gp = gfeat + n * F + off + p;
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) { const float v = fp[(long)c * HW]; s += v * v; }
-    const float r = rsqrtf(s + 1e-10f), a = rsqrtf((float)HW);
-    float dot = 0.f;
-    for (int c = 0; c < C; ++c) dot += gp[(long)c * HW] * sqrtf(lin[c]) * a * fp[(long)c * HW] * r;
+    const float a = rsqrtf((float)HW);
+    float s = 0.f, d = 0.f;                       // sum f^2 and sum u_c f_c of this thread's channels
+    if (ok)
+        for (int c = cg; c < C; c += CG) {
+            const float v = fp[(long)c * HW];
+            s += v * v;
+            d += gp[(long)c * HW] * sqrtf(lin[c]) * a * v;
+        }
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = d;
+    __syncthreads();
+    float st = 0.f, dt = 0.f;
+    for (int g = 0; g < CG; ++g) { st += red[0][g * PL + pl]; dt += red[1][g * PL + pl]; }
+    const float r = rsqrtf(st + 1e-10f);
+    const float dot = dt * r;                      // sum_c u_c y_c
+    if (!ok) return;
     float* op = gf + n * C * HW + p;
-    for (int c = 0; c < C; ++c) {
+    for (int c = cg; c < C; c += CG) {
         const float u = gp[(long)c * HW] * sqrtf(lin[c]) * a, y = fp[(long)c * HW] * r;
         const float v = r * (u - y * dot);
         op[(long)c * HW] = accumulate ? op[(long)c * HW] + v : v;
     }
 }
+
+// pixel lanes of a tap workgroup: the largest power of two <= min(64, HW)
+static inline int tap_lanes(int HW) { int pl = 1; while (pl * 2 <= HW && pl < 64) pl *= 2; return pl; }
 
 static void fbase(LaConvArgs& a) {
     memset(&a, 0, sizeof(a));
@@ -248,9 +274,9 @@ extern "C" int la_feat_forward(la_feat* h, const float* x, int N, float* feat_ou
             if ((rc = f_conv(h, o, false, cur, o.y, N, stream))) return rc;
             cur = o.y;
         } else if (o.kind == LA_FEAT_TAP) {
-            const long total = (long)N * HWo;
-            hipLaunchKernelGGL(la_tap_fwd_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, stream, cur, o.lin, feat_out, o.cout, HWo,
-                               (long)h->F, o.feat_off, total);
+            const int pl = tap_lanes(HWo);
+            hipLaunchKernelGGL(la_tap_fwd_kernel, dim3(la_cdiv(HWo, pl), N), dim3(256), 0, stream, cur, o.lin, feat_out, o.cout, HWo,
+                               (long)h->F, o.feat_off, pl);
         } else {
             const long planes = (long)N * o.cout;
             hipLaunchKernelGGL(la_pool2_fwd_kernel, dim3(la_cdiv(planes * HWo, 256)), dim3(256), 0, stream, cur, o.y, o.res_in, planes,
@@ -278,9 +304,9 @@ extern "C" int la_feat_backward(la_feat* h, const float* gfeat, float* gx, hipSt
         for (int q = k - 1; q >= 0; --q) if (h->op[q].kind != LA_FEAT_TAP) { act_in = h->op[q].y; break; }
         const int HWo = o.res_out * o.res_out;
         if (o.kind == LA_FEAT_TAP) {
-            const long total = (long)N * HWo;
-            hipLaunchKernelGGL(la_tap_bwd_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, stream, act_in, o.lin, gfeat, g, o.cout, HWo,
-                               (long)h->F, o.feat_off, total, have ? 1 : 0);
+            const int pl = tap_lanes(HWo);
+            hipLaunchKernelGGL(la_tap_bwd_kernel, dim3(la_cdiv(HWo, pl), N), dim3(256), 0, stream, act_in, o.lin, gfeat, g, o.cout, HWo,
+                               (long)h->F, o.feat_off, pl, have ? 1 : 0);
             have = true;
         } else if (o.kind == LA_FEAT_CONV_RELU) {
             LA_CHECK_ARG(have, "feat_backward: the op list must end with a tap");

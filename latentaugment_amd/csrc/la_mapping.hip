@@ -27,10 +27,26 @@ __global__ __launch_bounds__(256) void la_fc_kernel(const float* __restrict__ x,
     if (o >= out) return;
     const float* wrow = W + (long)o * in;
     const float bv = bias ? bias[o] * bgain : 0.f;
+    const bool vec = (in & 3) == 0 && ((((size_t)W) | ((size_t)x)) & 15) == 0;      // rows of 16-byte aligned float4s
     for (int b0 = 0; b0 < B; b0 += MB) {
         float acc[MB];
 #pragma unroll
         for (int q = 0; q < MB; ++q) acc[q] = 0.f;
+        if (vec) {      // (the discriminator's 8192-wide epilogue row: 16-byte loads, two weight groups in flight)
+            const float4* w4 = reinterpret_cast<const float4*>(wrow);
+            const int n4 = in >> 2;
+            for (int j = lane; j < n4; j += 128) {
+                const bool two = j + 64 < n4;
+                const float4 wa = w4[j], wb = two ? w4[j + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < MB; ++q)
+                    if (b0 + q < B) {
+                        const float4* x4 = reinterpret_cast<const float4*>(x + (long)(b0 + q) * in);
+                        const float4 xa = x4[j], xb = two ? x4[j + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        acc[q] += (wa.x * xa.x + wa.y * xa.y) + (wa.z * xa.z + wa.w * xa.w) + (wb.x * xb.x + wb.y * xb.y) + (wb.z * xb.z + wb.w * xb.w);
+                    }
+            }
+        } else
         for (int j = lane; j < in; j += 64) {
             const float wv = wrow[j];
 #pragma unroll
