@@ -32,6 +32,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef LA_STAMP
 #define LA_STAMP 0
 #endif
+#ifndef LA_HALO_SB
+#define LA_HALO_SB 0       // halo kernel: 1 = ONE set of B fragments, refilled in place (each 32-pixel sub-tile right after its MFMAs)
+#endif
+#ifndef LA_HALO_WAVES
+#define LA_HALO_WAVES 2    // waves per SIMD the halo kernel is compiled for (3 needs <= 168 registers)
+#endif
 #ifndef LA_GATHER
 #define LA_GATHER 1      // fp16 flat kernel: 1 = lane-contiguous 16-byte pieces (8 lanes per pixel record), 0 = one pixel half-record per lane
 #endif
@@ -762,7 +768,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
 #define H_UNITS (8 * HALO_PX)          // (4-channel group, halo pixel) load units per chunk
 #define H_UPT 182                      // units per tap (9 x 182 >= 1632)
 template <int MT, int FMT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void la_conv_bf16_halo_kernel(LaConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LA_HALO_WAVES))) void la_conv_bf16_halo_kernel(LaConvArgs a) {
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     constexpr bool F16 = FMT == FMT_F16X2;
     constexpr int WM_ = MT / 32;                   // wave grid WM_ x WN_ over the MT x 128 tile: every wave owns 32 rows
@@ -943,6 +949,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     __syncthreads();
     STAMP(3);
 
+#if LA_HALO_SB
+    // single-buffer form: bf holds the fragments of ONE K-step; sub-tile j is re-loaded for the following K-step right after its own
+    // three MFMAs have issued, so its LDS latency runs under the MFMAs of the other sub-tiles and no second fragment set is live
+    bf16x8 bf[NTERM][NJ];
+    auto mma_refill = [&](bf16x8 (&af)[NTERM][TM], const unsigned char* buf, int shift, int ks, bool refill) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if constexpr (NTERM == 3) {
+                acc[0][j] = la_mma<F16>(af[2][0], bf[0][j], acc[0][j]);
+                acc[0][j] = la_mma<F16>(af[0][0], bf[2][j], acc[0][j]);
+                acc[0][j] = la_mma<F16>(af[1][0], bf[1][j], acc[0][j]);
+            }
+            acc[0][j] = la_mma<F16>(af[1][0], bf[0][j], acc[0][j]);
+            acc[0][j] = la_mma<F16>(af[0][0], bf[1][j], acc[0][j]);
+            acc[0][j] = la_mma<F16>(af[0][0], bf[0][j], acc[0][j]);
+            if (refill) {
+                const int p = (wn * NJ + j) * HALO_W + shift + l31;
+                const int o = p * HPITCH + ((((ks * 2 + lh) ^ (p >> 2)) & 3) << 4);
+#pragma unroll
+                for (int q = 0; q < NTERM; ++q) bf[q][j] = *reinterpret_cast<const bf16x8*>(buf + q * HPLANE + o);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto chunk = [&](int cc, auto has_next) {
+        constexpr bool NEXT = decltype(has_next)::value;
+        const unsigned char* cur = smem + (cc & 1) * HBUF;
+        unsigned char* nxt = smem + ((cc + 1) & 1) * HBUF;
+        Slice sl;
+        sl.wr = -1;
+        sl.ok = false;
+        read_b(cur, (int)(shpack & 127u), 0, bf);
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            const int shift = (int)((shpack >> (7 * t)) & 127u);
+            const int tn = t + 1 < 9 ? t + 1 : 0;
+            const int ccn = t + 1 < 9 ? cc : (NEXT ? cc + 1 : 0);
+            const int shift_n = (int)((shpack >> (7 * (t + 1 < 9 ? t + 1 : 8))) & 127u);
+            mma_refill(acur[0], cur, shift, 1, true);          // K-step 0; refilled with this tap's K-step 1
+            load_a(ccn, tn, 0, acur[0]);
+            if (NEXT) {
+                slice_write(nxt, sl);
+                slice_load(cc + 1, t, sl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_refill(acur[1], cur, shift_n, 0, t + 1 < 9);   // K-step 1; refilled with the next tap's K-step 0 (not across the barrier)
+            load_a(ccn, tn, 1, acur[1]);
+        }
+        if (NEXT) slice_write(nxt, sl);
+    };
+#else
     bf16x8 bf0[NTERM][NJ], bf1[NTERM][NJ];
     auto chunk = [&](int cc, auto has_next) {
         constexpr bool NEXT = decltype(has_next)::value;
@@ -980,6 +1037,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
         }
         if (NEXT) slice_write(nxt, sl);
     };
+#endif
     for (int cc = 0; cc < nck; ++cc) {
         if (cc + 1 < nck) chunk(cc, std::true_type{});
         else chunk(cc, std::false_type{});

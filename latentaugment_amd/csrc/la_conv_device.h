@@ -127,18 +127,29 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                float xv[16][NJ];
-                if (x0) {
+                // xin of the next four-row group is requested while this group is processed (two groups of 4 x NJ registers live,
+                // not all sixteen rows: the epilogue is the register peak of the kernels)
+                float xn[4][NJ];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) xv[r][j] = x0[(long)(i * 32 + (r & 3) + 8 * (r >> 2)) * HWo + np[j]];
-                }
+                    for (int j = 0; j < NJ; ++j) xn[q][j] = x0 ? x0[(long)(i * 32 + q) * HWo + np[j]] : 0.f;
                 // four rows at a time (r = 4g .. 4g+3 are four CONSECUTIVE channels), so that the per-row reductions over the 32
                 // lanes of a half-wave run as one multi-value butterfly: 2 + 1 exchanges halve the values per lane from 4 to 1
                 // (lane bits 4, 3 pick the row), 3 more finish it -- 6 shuffles per 4 rows and quantity instead of 20
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
+                    float xv[4][NJ];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) xv[q][j] = xn[q][j];
+                    if (g4 < 3) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) xn[q][j] = x0 ? x0[(long)(i * 32 + q + 8 * (g4 + 1)) * HWo + np[j]] : 0.f;
+                    }
                     float part[4], dd[4], mx[4], dwe[SEAM_MAXC][4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -155,7 +166,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                             for (int c = 0; c < SEAM_MAXC; ++c) we[c] = c < imgc ? red[16 + c][mw + mr] : 0.f;
 #pragma unroll
                             for (int j = 0; j < NJ; ++j) {
-                                const float v = acc[i][j][r], y = xv[r][j];
+                                const float v = acc[i][j][r], y = xv[q][j];
                                 const bool pos = y > 0.f;
                                 const float sl = fabsf(y) >= s_cl ? 0.f : (pos ? s_pos : s_neg);
                                 float g = v * sc;
@@ -176,7 +187,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                             for (int j = 0; j < NJ; ++j) {
                                 const float v = acc[i][j][r];
                                 o0[(long)mr * HWo + np[j]] = v * sc;
-                                if (x0) part[q] += v * xv[r][j];
+                                if (x0) part[q] += v * xv[q][j];
                             }
                         }
                     }
@@ -296,13 +307,6 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
         const float* ad = (o2 && a.addend) ? a.addend + ((long)b * a.M + m0 + mw) * HWo : nullptr;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            float av[16][NJ];
-            if (ad) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) av[r][j] = ad[(long)(i * 32 + (r & 3) + 8 * (r >> 2)) * HWo + np[j]];
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mr = i * 32 + (r & 3) + 8 * (r >> 2);
@@ -317,7 +321,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                         v = fminf(fmaxf(v, -cl), cl);
                     }
                     if (!LA_NOSTORE || v == 1.2345e30f) o0[(long)mr * HWo + np[j]] = v;
-                    if (o2) o2[(long)mr * HWo + np[j]] = v + (ad ? av[r][j] : 0.f);
+                    if (o2) o2[(long)mr * HWo + np[j]] = v + (ad ? ad[(long)mr * HWo + np[j]] : 0.f);
                     if (rgbc > 0) {
 #pragma unroll
                         for (int c = 0; c < RGB_MAXC; ++c)
