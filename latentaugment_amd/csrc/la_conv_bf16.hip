@@ -32,12 +32,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef LA_STAMP
 #define LA_STAMP 0
 #endif
-#ifndef LA_HALO_SB
-#define LA_HALO_SB 0       // halo kernel: 1 = ONE set of B fragments, refilled in place (each 32-pixel sub-tile right after its MFMAs)
-#endif
-#ifndef LA_HALO_WAVES
-#define LA_HALO_WAVES 2    // waves per SIMD the halo kernel is compiled for (3 needs <= 168 registers)
-#endif
 #ifndef LA_GATHER
 #define LA_GATHER 1      // fp16 flat kernel: 1 = lane-contiguous 16-byte pieces (8 lanes per pixel record), 0 = one pixel half-record per lane
 #endif
@@ -767,8 +761,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
 #define HPITCH 64
 #define H_UNITS (8 * HALO_PX)          // (4-channel group, halo pixel) load units per chunk
 #define H_UPT 182                      // units per tap (9 x 182 >= 1632)
-template <int MT, int FMT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LA_HALO_WAVES))) void la_conv_bf16_halo_kernel(LaConvArgs a) {
+// WV = waves per SIMD the kernel is compiled for.  2: two sets of B fragments (K-step 1 is read under the MFMAs of K-step 0), the chunk
+// loop in a with-next and a last instance.  3 (<= 168 registers, three workgroups per CU -- the partner workgroups cover a
+// workgroup's prologue and store bursts): ONE set of B fragments, every 32-pixel sub-tile re-loaded for the following K-step right
+// after its own three MFMAs, and ONE instance of the chunk loop (the last chunk issues dummy loads): the merge of two instances
+// cost a second set of 64 accumulator registers and 64 moves per chunk.  Measured per 154.6-GFLOP launch (WV 3 against 2):
+// 128->128 @256^2 fwd -9.5 %, bwd -7 %; 256->256 @128^2 fwd -8 %, bwd -8 %; 512->512 @64^2 +-0 (two rounds of workgroups only) --
+// la_conv_bf16_dispatch uses WV 3 for every 128-row fp16 launch.
+template <int MT, int FMT, int WV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void la_conv_bf16_halo_kernel(LaConvArgs a) {
+    constexpr bool SB = WV == 3;
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     constexpr bool F16 = FMT == FMT_F16X2;
     constexpr int WM_ = MT / 32;                   // wave grid WM_ x WN_ over the MT x 128 tile: every wave owns 32 rows
@@ -820,10 +822,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LA_HALO_WAV
     // ---- halo slices.  Every load is unconditional (clamped address; out-of-image pixels are zeroed on the way to LDS,
     // channels past C meet zero weights), so the compiler can count them: no wait in the tap loop is a vmcnt(0).
     struct Slice { float x[4]; int wr, c0; bool ok; };
-    auto slice_load = [&](int cc, int t, Slice& sl) {
+    auto slice_load = [&](int cc, int t, Slice& sl, bool live = true) {      // !live (uniform): one dword of traffic per wave, nothing written
         const int lt = (tid + 64 * t) & 255;                      // the idle lanes rotate over the waves
         int u = t * H_UPT + (lt < H_UPT ? lt : H_UPT - 1);
-        const bool valid = lt < H_UPT && u < H_UNITS;
+        const bool valid = live && lt < H_UPT && u < H_UNITS;
         u = u < H_UNITS ? u : H_UNITS - 1;
         const int c4 = u / HALO_PX, hp = u - c4 * HALO_PX;
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
@@ -837,7 +839,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LA_HALO_WAV
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             unsigned vo, so;
-            if (fast) { vo = (unsigned)(c4 * 4) * HWin * EB + off; so = (unsigned)(cc * KCB + j) * HWin * EB; }
+            if (fast) { vo = live ? (unsigned)(c4 * 4) * HWin * EB + off : 0u; so = live ? (unsigned)(cc * KCB + j) * HWin * EB : 0u; }
             else {
                 const int c = cc * KCB + c4 * 4 + j;
                 vo = (unsigned)(c < a.C ? c : a.C - 1) * HWin * EB + off;
@@ -949,7 +951,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LA_HALO_WAV
     __syncthreads();
     STAMP(3);
 
-#if LA_HALO_SB
+  if constexpr (SB) {
     // single-buffer form: bf holds the fragments of ONE K-step; sub-tile j is re-loaded for the following K-step right after its own
     // three MFMAs have issued, so its LDS latency runs under the MFMAs of the other sub-tiles and no second fragment set is live
     bf16x8 bf[NTERM][NJ];
@@ -973,10 +975,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LA_HALO_WAV
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto chunk = [&](int cc, auto has_next) {
-        constexpr bool NEXT = decltype(has_next)::value;
+    for (int cc = 0; cc < nck; ++cc) {
         const unsigned char* cur = smem + (cc & 1) * HBUF;
         unsigned char* nxt = smem + ((cc + 1) & 1) * HBUF;
+        const bool has_next = cc + 1 < nck;
         Slice sl;
         sl.wr = -1;
         sl.ok = false;
@@ -985,21 +987,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LA_HALO_WAV
         for (int t = 0; t < 9; ++t) {
             const int shift = (int)((shpack >> (7 * t)) & 127u);
             const int tn = t + 1 < 9 ? t + 1 : 0;
-            const int ccn = t + 1 < 9 ? cc : (NEXT ? cc + 1 : 0);
+            const int ccn = t + 1 < 9 ? cc : (has_next ? cc + 1 : 0);
             const int shift_n = (int)((shpack >> (7 * (t + 1 < 9 ? t + 1 : 8))) & 127u);
             mma_refill(acur[0], cur, shift, 1, true);          // K-step 0; refilled with this tap's K-step 1
             load_a(ccn, tn, 0, acur[0]);
-            if (NEXT) {
-                slice_write(nxt, sl);
-                slice_load(cc + 1, t, sl);
-            }
+            slice_write(nxt, sl);
+            slice_load(has_next ? cc + 1 : cc, t, sl, has_next);      // (last chunk: dummy loads, nothing staged)
             __builtin_amdgcn_sched_barrier(0);
             mma_refill(acur[1], cur, shift_n, 0, t + 1 < 9);   // K-step 1; refilled with the next tap's K-step 0 (not across the barrier)
             load_a(ccn, tn, 1, acur[1]);
         }
-        if (NEXT) slice_write(nxt, sl);
-    };
-#else
+        slice_write(nxt, sl);
+        __syncthreads();       // next halo complete, everyone done with this one (and, at the end, LDS free for the epilogue)
+    }
+  } else {
     bf16x8 bf0[NTERM][NJ], bf1[NTERM][NJ];
     auto chunk = [&](int cc, auto has_next) {
         constexpr bool NEXT = decltype(has_next)::value;
@@ -1037,7 +1038,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LA_HALO_WAV
         }
         if (NEXT) slice_write(nxt, sl);
     };
-#endif
     for (int cc = 0; cc < nck; ++cc) {
         if (cc + 1 < nck) chunk(cc, std::true_type{});
         else chunk(cc, std::false_type{});
@@ -1046,6 +1046,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LA_HALO_WAV
 #endif
         __syncthreads();       // next halo complete, everyone done with this one (and, at the end, LDS free for the epilogue)
     }
+  }
     if (F16) {
         const float inv = 1.f / (a.acc_scale_w[0] * a.acc_scale_x[b]);
 #pragma unroll
@@ -1063,6 +1064,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LA_HALO_WAV
 template <int FMT>
 static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, hipStream_t stream) {
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
+    constexpr int W3 = NTERM == 2 ? 3 : 2;      // (the three-term format does not fit three waves: its W3 alias is the plain kernel)
     const size_t lds128 = (size_t)2 * NTERM * NT * BPITCH, lds64 = lds128;     // two pixel buffers (>= the epilogue's 4 * MT floats)
     if (!split && la_conv_bf16_uses_halo(as)) {
         // two halo buffers (>= the epilogue's 4 * MT floats) + the per-channel factor table
@@ -1074,15 +1076,20 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         if (!attr_done[dev].load(std::memory_order_acquire)) {
             const int cap = 2 * 3 * HALO_PX * HPITCH + 4096 * (int)sizeof(float);
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<64, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<32, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, FMT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, FMT, W3>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<64, FMT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<32, FMT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
             if (e != hipSuccess) { la_set_error(hipGetErrorString(e)); return LA_ERR_HIP; }
             attr_done[dev].store(true, std::memory_order_release);
         }
-        if (MTsel == 128) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, FMT>), grid, dim3(256), h128, stream, as);
-        else if (MTsel == 64) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<64, FMT>), grid, dim3(256), h64, stream, as);
-        else hipLaunchKernelGGL((la_conv_bf16_halo_kernel<32, FMT>), grid, dim3(256), h64, stream, as);
+        // three-wave form for the fp16 x2 launches on 128-row tiles (see the kernel comment); dev knob LA_HALO_W3=0|1
+        static const int w3_knob = []() { const char* e = getenv("LA_HALO_W3"); return e ? atoi(e) : -1; }();
+        const bool w3 = NTERM == 2 && MTsel == 128 && (w3_knob >= 0 ? w3_knob != 0 : true);
+        if (MTsel == 128 && w3) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, FMT, W3>), grid, dim3(256), h128, stream, as);
+        else if (MTsel == 128) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, FMT, 2>), grid, dim3(256), h128, stream, as);
+        else if (MTsel == 64) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<64, FMT, 2>), grid, dim3(256), h64, stream, as);
+        else hipLaunchKernelGGL((la_conv_bf16_halo_kernel<32, FMT, 2>), grid, dim3(256), h64, stream, as);
         return LA_OK;
     }
     if (MTsel == 128) {
