@@ -425,8 +425,11 @@ extern "C" int la_debug_stamps(unsigned long long* out, int n) {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define BPITCH 64
-template <int MT, bool SPLIT, int FMT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void la_conv_bf16_kernel(LaConvArgs a_in) {
+// WV = waves per SIMD the kernel is compiled for (3: fp16 x2 pieces form only): as in the halo kernel below, ONE set of B fragments
+// (K-step 1 re-loaded in place under the MFMAs of K-step 0; the next step's K-step 0 after the barrier) and one set of weight
+// fragments re-loaded right after its MFMAs have issued.
+template <int MT, bool SPLIT, int FMT, int WV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void la_conv_bf16_kernel(LaConvArgs a_in) {
     // merged output phases: blockIdx.z = phase * B + sample; the phase's grid, output offset and taps replace the launch-wide ones
     LaConvArgs a = a_in;
     int bz = blockIdx.z;
@@ -666,6 +669,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     const int sblk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 #endif
     STAMP(0);
+    if constexpr (WV == 3) {
+      if (nstep > 0) {
+        static_assert(WV != 3 || (FMT == FMT_F16X2 && LA_GATHER == 1), "the three-wave form exists for the fp16 pieces loader only");
+        int c1 = ck_beg, t1 = 0;
+        auto adv = [&](int& c, int& t) {
+            if (t + 1 < ntaps) ++t;
+            else if (c + 1 < ck_end) { ++c; t = 0; }
+        };
+        bf16x8 acur[2][NTERM][TM], bf[NTERM][NJ];
+        load_b(c1, t1);
+        load_a(c1, t1, 0, acur[0]);
+        load_a(c1, t1, 1, acur[1]);
+        adv(c1, t1);                                   // (c1, t1) = step 1
+        int c2 = c1, t2 = t1;
+        write_b(smem);
+        __syncthreads();
+        load_b(c1, t1);
+        adv(c2, t2);                                   // (c2, t2) = step 2
+#pragma unroll 1
+        for (int s = 0; s < nstep; ++s) {
+            const unsigned char* cur = smem + (s & 1) * BBUF;
+            unsigned char* nxt = smem + ((s + 1) & 1) * BBUF;
+            read_b(cur, 0, bf);
+            write_b(nxt);                              // step s+1 (loaded during step s-1)
+            load_b(c2, t2);                            // step s+2
+            __builtin_amdgcn_sched_barrier(0);
+            // K-step 0, every sub-tile re-loaded with its K-step 1 fragments right after its MFMAs
+            {
+                const int o1 = rbase + ((((2 + lh) ^ rsw) & 3) << 4);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[0][j] = la_mma<true>(acur[0][1][0], bf[0][j], acc[0][j]);
+                    acc[0][j] = la_mma<true>(acur[0][0][0], bf[1][j], acc[0][j]);
+                    acc[0][j] = la_mma<true>(acur[0][0][0], bf[0][j], acc[0][j]);
+#pragma unroll
+                    for (int q = 0; q < NTERM; ++q) bf[q][j] = *reinterpret_cast<const bf16x8*>(cur + q * BPLANE + j * 32 * BPITCH + o1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            load_a(c1, t1, 0, acur[0]);                // weights of step s+1, K-step 0
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                acc[0][j] = la_mma<true>(acur[1][1][0], bf[0][j], acc[0][j]);
+                acc[0][j] = la_mma<true>(acur[1][0][0], bf[1][j], acc[0][j]);
+                acc[0][j] = la_mma<true>(acur[1][0][0], bf[0][j], acc[0][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(c1, t1, 1, acur[1]);
+            c1 = c2; t1 = t2;
+            adv(c2, t2);
+            __syncthreads();
+        }
+      }
+    } else
     if (nstep > 0) {
         // (chunk, tap) of steps s, s+1, s+2; past the end they stay on the last valid step (harmless re-loads)
         int c1 = ck_beg, t1 = 0;
@@ -1092,12 +1149,19 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
         else hipLaunchKernelGGL((la_conv_bf16_halo_kernel<32, FMT, 2>), grid, dim3(256), h64, stream, as);
         return LA_OK;
     }
-    if (MTsel == 128) {
-        if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT>), grid, dim3(256), lds128, stream, as);
-        else hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT>), grid, dim3(256), lds128, stream, as);
+    // three-wave form of the 128-row fp16 x2 launches (kernel comment); dev knob LA_FLAT_W3=0|1
+    static const int f3_knob = []() { const char* e = getenv("LA_FLAT_W3"); return e ? atoi(e) : -1; }();
+    const bool f3 = FMT == FMT_F16X2 && LA_GATHER == 1 && MTsel == 128 && (f3_knob >= 0 ? f3_knob != 0 : true);
+    constexpr int FW3 = (FMT == FMT_F16X2 && LA_GATHER == 1) ? 3 : 2;
+    if (MTsel == 128 && f3) {
+        if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT, FW3>), grid, dim3(256), lds128, stream, as);
+        else hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT, FW3>), grid, dim3(256), lds128, stream, as);
+    } else if (MTsel == 128) {
+        if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT, 2>), grid, dim3(256), lds128, stream, as);
+        else hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT, 2>), grid, dim3(256), lds128, stream, as);
     } else {
-        if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<64, true, FMT>), grid, dim3(256), lds64, stream, as);
-        else hipLaunchKernelGGL((la_conv_bf16_kernel<64, false, FMT>), grid, dim3(256), lds64, stream, as);
+        if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<64, true, FMT, 2>), grid, dim3(256), lds64, stream, as);
+        else hipLaunchKernelGGL((la_conv_bf16_kernel<64, false, FMT, 2>), grid, dim3(256), lds64, stream, as);
     }
     return LA_OK;
 }
