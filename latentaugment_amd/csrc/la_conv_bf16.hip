@@ -840,7 +840,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     constexpr int HBUF = NTERM * HPLANE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][NTERM][HALO_PX][HPITCH] + scl[nck*32]
     float (*red)[MT] = reinterpret_cast<float (*)[MT]>(smem);
-    float* scl = reinterpret_cast<float*>(smem + 2 * HBUF);     // per-channel factor: style modulation (x fp16 sample scale)
+    // per-channel factor (style modulation x fp16 sample scale) behind the halo buffers; a single-chunk launch (<= 32 input channels: the
+    // top layers of the 1024^2 generators) never stages a second chunk and gets ONE buffer, i.e. twice the workgroups per CU
+    float* scl = reinterpret_cast<float*>(smem + (a.C > KCB ? 2 : 1) * HBUF);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -1125,7 +1127,10 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
     const size_t lds128 = (size_t)2 * NTERM * NT * BPITCH, lds64 = lds128;     // two pixel buffers (>= the epilogue's 4 * MT floats)
     if (!split && la_conv_bf16_uses_halo(as)) {
         // two halo buffers (>= the epilogue's 4 * MT floats) + the per-channel factor table
-        const size_t h128 = (size_t)2 * NTERM * HALO_PX * HPITCH + (size_t)la_cdiv(as.C, KCB) * KCB * sizeof(float), h64 = h128;
+        size_t h128 = (size_t)(as.C > KCB ? 2 : 1) * NTERM * HALO_PX * HPITCH + (size_t)la_cdiv(as.C, KCB) * KCB * sizeof(float);
+        const size_t epi = (size_t)160 * MTsel + (size_t)2048 * (MTsel / 32);      // what the epilogue addresses (row tables + fused-ToRGB partials)
+        if (h128 < epi) h128 = epi;
+        const size_t h64 = h128;
         // > 64 KB of dynamic LDS needs the opt-in, and the attribute is per DEVICE: track it per device (atomic flags: the
         // entry points may be entered from several host threads, one per device)
         static std::atomic<bool> attr_done[64];
