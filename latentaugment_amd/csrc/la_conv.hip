@@ -199,8 +199,8 @@ __global__ __launch_bounds__(256) void la_conv_igemm_kernel(LaConvArgs a) {
 }
 
 // Split-K finisher: sums the K slices in a fixed order and applies the same epilogue as the direct kernel (deterministic).
-// One wave per (b, m) plane for grids below 256 positions, a whole workgroup per plane above (the kernel is pure latency:
-// a wave walking a 32x32 plane makes 16 dependent round trips).
+// One wave per (b, m) plane, four planes per workgroup (the kernel is pure latency; with 16-byte loads a wave covers a 32x32 plane
+// in four steps).
 template <int PPB>      // planes per workgroup: 4 (one wave each) or 1
 __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a_in) {
     __shared__ float wpart[4];
@@ -439,8 +439,9 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
                 else if (MTsel == 128) hipLaunchKernelGGL((la_conv_igemm_kernel<128, true>), grid, dim3(256), 0, stream, as);
                 else hipLaunchKernelGGL((la_conv_igemm_kernel<64, true>), grid, dim3(256), 0, stream, as);
                 const unsigned nz = nphase > 0 ? nphase : 1;
-                if (Gmax >= 256) hipLaunchKernelGGL(la_conv_splitk_finish_kernel<1>, dim3(a.M, a.B, nz), dim3(256), 0, stream, as);
-                else hipLaunchKernelGGL(la_conv_splitk_finish_kernel<4>, dim3(la_cdiv(a.M, 4), a.B, nz), dim3(256), 0, stream, as);
+                // one wave per (b, m) plane, four planes per workgroup, at every split-K size (<= 34x34): a whole workgroup per plane
+                // (the <1> form) measured 21 against 13 us on the 8 x 512 x 32^2 launches
+                hipLaunchKernelGGL(la_conv_splitk_finish_kernel<4>, dim3(la_cdiv(a.M, 4), a.B, nz), dim3(256), 0, stream, as);
                 // the consumer's operand scale (LaConvArgs::seam_xs_out): thousands of short finish workgroups lowering one slot per
                 // sample at the same moment serialise on it (measured 21 -> 65 us), so this form reduces the plane maxima instead
                 if (as.seam_xs_out && as.seam_ddn_part && as.epi == LA_EPI_BWD) {
