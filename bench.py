@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- augmented images/s of the latent-optimisation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its own N ranks, see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one batch through the plugin API exactly as the reference's driver runs it (backbone_latentaug.py:99-106):
@@ -15,6 +15,11 @@ of the augmented batch in get_output() are inside the timed region, as they are 
 N > 1 (one rank per GPU, RCCL): every rank holds the same global batch of 8*N samples and calls the same three plugin
 methods; `LatentAug.forward` hands rank k samples [8k, 8k+8) and returns the whole batch to every rank with ONE
 all_gather over xGMI (weak scaling: 8 images per GPU).
+
+Launching.  Under `torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) the process is one
+rank.  A plain `python bench.py --gpus N` with N > 1 and no WORLD_SIZE is the PARENT: before anything touches the GPU it starts
+N fresh child interpreters of this file (one rank per GPU, rendezvous on 127.0.0.1 at a free port), waits for them and exits
+non-zero if any of them failed; it never exec()s and never initialises HIP itself.
 
 Reported next to the metric:
   * roofline -- HIP-event brackets around every launch of ONE extra batch run right after the timed region (the timed
@@ -225,8 +230,47 @@ def roofline_leg(lib, _lib, args, one_step, elapsed_per_step):
     return roof
 
 
+def self_launch(n):
+    """Parent of a plain `python bench.py --gpus N` (N > 1): N child ranks of this file, nothing else.  Runs before torch is
+    imported, so this process never initialises the GPU; the children are fresh interpreters (no fork of GPU state, no exec)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
+        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs) or any(rc not in (None, 0) for rc in rcs):
+            break
+        time.sleep(0.2)
+    if any(rc not in (None, 0) for rc in rcs):      # one rank died: the others would wait in a collective for ever
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+    rcs = []
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=60))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(p.wait())
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit(f'bench.py: ranks failed (rank, exit code): {bad}')
+    raise SystemExit(0)
+
+
 def main():
     args = apply_preset(parse())
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args.gpus)
     import torch
     import torch.distributed as dist
 
@@ -234,7 +278,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start one rank per GPU')
     if args.force_device >= 0:
         local_rank = args.force_device
     torch.cuda.set_device(local_rank)

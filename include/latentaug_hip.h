@@ -280,6 +280,13 @@ int la_latent_opt_set_graph(la_latent_opt* h, int enable);
  * w_trace [steps][B][w_dim] = the optimised latent after every step, img_trace [steps][B][C][R][R] = the image synthesised in
  * every step.  While either is set the loop launches eagerly. */
 int la_latent_opt_set_trace(la_latent_opt* h, float* w_trace, float* img_trace);
+/* dw_trace [steps][B][w_dim] (device, or NULL) = dL/dw of every step, L = -latent - pix - lpips + disc (util_latent_aug.py:270):
+ * the tensor `loss.backward()` leaves in w_opt.grad (:275) before Adam consumes it.  While set the loop launches eagerly. */
+int la_latent_opt_set_grad_trace(la_latent_opt* h, float* dw_trace);
+/* The banks handed to la_latent_opt_create / _set_lpips (register_buffer('W'/'X'/'fea_*'), util_latent_aug.py:137-171) must stay
+ * IMMUTABLE for the life of the handle: their column sums are reduced once (both criterion modes) and every later gradient uses
+ * them.  A caller that does rewrite bank contents in place calls this before the next la_latent_opt_run. */
+int la_latent_opt_invalidate_banks(la_latent_opt* h);
 /* w0 [B][w_dim] -> img_out [B][C][R][R], w_aug_out [B][num_ws][w_dim]; losses_out (may be NULL) [steps][4] =
  * weighted {latent, pix, disc, lpips} per step. */
 int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const float* const* final_noises, float* img_out,

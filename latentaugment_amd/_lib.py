@@ -108,6 +108,8 @@ SIGNATURES = {
     'la_latent_opt_set_crop_pos': (_I, [_P, _I, _I]),
     'la_latent_opt_set_graph': (_I, [_P, _I]),
     'la_latent_opt_set_trace': (_I, [_P, _P, _P]),
+    'la_latent_opt_set_grad_trace': (_I, [_P, _P]),
+    'la_latent_opt_invalidate_banks': (_I, [_P]),
     'la_prof_begin': (_I, []),
     'la_prof_end': (_I, [_P, _P, _P, _P]),
     'la_prof_set_stride': (_I, [_I]),

@@ -30,10 +30,11 @@ struct la_latent_opt {
     // step-invariant launch sequence: device-side step counter + Adam bias-correction table + crop position, so that ONE
     // captured step (hipGraph) is replayed for every step of every batch of the same size
     float* adam_tab;        // device [steps][2]
-    float* adam_tab_host;   // host copy (malloc), uploaded at the head of every run
+    float* adam_tab_host;   // host copy (malloc), uploaded ONCE (first run; constant afterwards)
+    int adam_tab_valid;
     int* step_ctr;          // device
     int* crop_dev;          // device {y0, x0}
-    int crop_host[2];
+    float* trace_dw;        // optional [steps][B][w_dim]: dL/dw of every step (la_latent_opt_set_grad_trace); forces eager launches
     int graph_mode;         // 0 eager, 1 replay a captured step (default)
     int graph_B;            // batch the captured step was built for (0: none)
     hipGraph_t graph;
@@ -120,6 +121,24 @@ extern "C" int la_latent_opt_set_trace(la_latent_opt* h, float* w_trace, float* 
     return LA_OK;
 }
 
+// dL/dw [steps][B][w_dim] of every step (L = -latent - pix - lpips + disc, util_latent_aug.py:270): what Adam consumes, before
+// its sign-like normalisation hides magnitudes.  Parity tests compare step 1 with a float64 gradient at full size.
+extern "C" int la_latent_opt_set_grad_trace(la_latent_opt* h, float* dw_trace) {
+    LA_CHECK_ARG(h, "latent_opt_set_grad_trace: null handle");
+    h->trace_dw = dw_trace;
+    return LA_OK;
+}
+
+// The banks (W, X crops, LPIPS features) are CONSTANTS of the handle: their column sums are reduced once and reused by every later
+// step and batch.  A caller that rewrites bank contents in place must call this before the next run (the loss scalars are always
+// computed from the live banks; without this call the gradient would keep using the old sums).
+extern "C" int la_latent_opt_invalidate_banks(la_latent_opt* h) {
+    LA_CHECK_ARG(h, "latent_opt_invalidate_banks: null handle");
+    h->colsums_valid = 0;
+    h->l_colsum_valid = 0;
+    return LA_OK;
+}
+
 extern "C" int la_latent_opt_set_graph(la_latent_opt* h, int enable) {
     LA_CHECK_ARG(h, "latent_opt_set_graph: null handle");
     h->graph_mode = enable ? 1 : 0;
@@ -182,6 +201,9 @@ __global__ void la_lpips_gfeat_kernel(const float* __restrict__ feat, const floa
     g[i] = coef2 * (mrows * feat[i] - colsum[(long)c * F + k]);
 }
 
+// crop window position by value (no host buffer that a later call could overwrite while a copy is still in flight)
+__global__ void la_set_int2_kernel(int* __restrict__ dst, int a, int b) { dst[0] = a; dst[1] = b; }
+
 static int refresh_colsums(la_latent_opt* h, hipStream_t stream) {
     int rc;
     const long cc2 = (long)h->cfg.crop * h->cfg.crop;
@@ -208,9 +230,12 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     LA_HIP(hipMemsetAsync(h->m, 0, nw * sizeof(float), stream));
     LA_HIP(hipMemsetAsync(h->v, 0, nw * sizeof(float), stream));
     LA_HIP(hipMemsetAsync(h->step_ctr, 0, sizeof(int), stream));
-    if (c.steps > 0) LA_HIP(hipMemcpyAsync(h->adam_tab, h->adam_tab_host, sizeof(float) * 2 * (size_t)c.steps, hipMemcpyHostToDevice, stream));
-    h->crop_host[0] = h->crop_y; h->crop_host[1] = h->crop_x;
-    LA_HIP(hipMemcpyAsync(h->crop_dev, h->crop_host, sizeof(int) * 2, hipMemcpyHostToDevice, stream));
+    if (c.steps > 0 && !h->adam_tab_valid) {      // constant after create: one (host-blocking, pageable) upload per handle, not per batch
+        LA_HIP(hipMemcpyAsync(h->adam_tab, h->adam_tab_host, sizeof(float) * 2 * (size_t)c.steps, hipMemcpyHostToDevice, stream));
+        LA_HIP(hipStreamSynchronize(stream));
+        h->adam_tab_valid = 1;
+    }
+    hipLaunchKernelGGL(la_set_int2_kernel, dim3(1), dim3(1), 0, stream, h->crop_dev, h->crop_y, h->crop_x);
     const bool use_disc = c.w_disc != 0.f;
     LA_CHECK_ARG(!use_disc || h->d, "latent_opt_run: w_disc != 0 but no discriminator attached (la_latent_opt_set_disc)");
     const bool use_lpips = c.w_lpips != 0.f;
@@ -299,7 +324,7 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     // Replay of a captured step.  The step is captured AFTER one eager execution with the same batch size (module loading,
     // per-device attribute opt-ins and every other first-use effect happen outside the capture).  While the launch profiler
     // (la_prof_begin .. la_prof_end) is on, launches stay eager so that its event brackets see them.  If capture is refused the handle falls back to eager launches of the same kernels.
-    const bool tracing = h->trace_w || h->trace_img;
+    const bool tracing = h->trace_w || h->trace_img || h->trace_dw;
     const bool replay = h->graph_mode == 1 && !want_losses && !tracing && c.steps > 0 && !la_prof_enabled();
     int first_graph_step = 1;
     if (replay && (!h->graph_exec || h->graph_B != B)) {
@@ -329,6 +354,7 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
                 LA_HIP(hipMemcpyAsync(h->trace_img + (size_t)(step - 1) * B * h->imgc * h->R * h->R, la_synth_image(h->g),
                                       sizeof(float) * (size_t)B * h->imgc * h->R * h->R, hipMemcpyDeviceToDevice, stream));
             if (h->trace_w) LA_HIP(hipMemcpyAsync(h->trace_w + (size_t)(step - 1) * nw, h->w_opt, sizeof(float) * nw, hipMemcpyDeviceToDevice, stream));
+            if (h->trace_dw) LA_HIP(hipMemcpyAsync(h->trace_dw + (size_t)(step - 1) * nw, h->dw, sizeof(float) * nw, hipMemcpyDeviceToDevice, stream));
         }
     }
     if ((rc = la_broadcast_mix(h->w_opt, w0, w_aug_out, B, h->num_ws, wd, c.alpha, c.soft_aug, stream))) return rc;

@@ -311,7 +311,8 @@ class LatentAug:
 
     def run_local(self, w, final_noises=None, want_losses=False, crop_pos=None, trace=None):
         """w [b,1,w_dim] on this device -> (img [b,C,R,R], w_aug [b,num_ws,w_dim], losses or None).
-        trace (optional): dict that receives 'w' [steps,b,w_dim] and 'img' [steps,b,C,R,R], the per-step snapshots."""
+        trace (optional): dict that receives the per-step snapshots 'w' [steps,b,w_dim] (latent after the step) and 'img'
+        [steps,b,C,R,R]; trace['want'] (default ('w', 'img')) selects them, and may name 'grad' [steps,b,w_dim] = dL/dw."""
         if self.feat is not None:
             if crop_pos is None:
                 crop_pos = getattr(self, 'crop_params', None)
@@ -329,21 +330,31 @@ class LatentAug:
             if final_noises is None:
                 final_noises = self.engine.make_noises(b)
             fn = self.engine.noise_pointer_array(final_noises)
-        tw = ti = None
+        tw = ti = tg = None
+        want_img = trace is not None and 'img' in trace.get('want', ('w', 'img'))
         if trace is not None and self.num_epochs > 0:
             tw = torch.empty([self.num_epochs, b, self.w_dim], device=self.device, dtype=torch.float32)
-            ti = torch.empty([self.num_epochs, b, self.engine.img_channels, self.res, self.res], device=self.device, dtype=torch.float32)
+            if want_img:
+                ti = torch.empty([self.num_epochs, b, self.engine.img_channels, self.res, self.res], device=self.device, dtype=torch.float32)
+            if 'grad' in trace.get('want', ()):
+                tg = torch.empty([self.num_epochs, b, self.w_dim], device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
             if tw is not None:
                 _lib.check(self._lib.la_latent_opt_set_trace(self._h, _lib.ptr(tw), _lib.ptr(ti)), 'la_latent_opt_set_trace')
+                _lib.check(self._lib.la_latent_opt_set_grad_trace(self._h, _lib.ptr(tg)), 'la_latent_opt_set_grad_trace')
             try:
                 _lib.check(self._lib.la_latent_opt_run(self._h, _lib.ptr(w), b, fn, _lib.ptr(img), _lib.ptr(w_aug),
                                                        _lib.ptr(losses), _lib.stream_ptr()), 'la_latent_opt_run')
             finally:
                 if tw is not None:
                     _lib.check(self._lib.la_latent_opt_set_trace(self._h, None, None), 'la_latent_opt_set_trace')
+                    _lib.check(self._lib.la_latent_opt_set_grad_trace(self._h, None), 'la_latent_opt_set_grad_trace')
         if tw is not None:
-            trace['w'], trace['img'] = tw, ti
+            trace['w'] = tw
+            if ti is not None:
+                trace['img'] = ti
+            if tg is not None:
+                trace['grad'] = tg
         self._keep = final_noises
         return img, w_aug, losses
 
@@ -370,8 +381,13 @@ class LatentAug:
             if trace and 'w' in trace and fname:      # snapshots only with a batch of one (:292-295)
                 base = os.path.splitext(os.path.basename(str(fname[0])))[0]
                 tw, ti = trace['w'].cpu().numpy(), trace['img'].cpu().numpy()
+                w_in = trace.get('w_in')
                 for e in range(self.num_epochs):
+                    # w_<name>_<e>.pkl: the reference passes the loop's INPUT latent `w` to snap_w (:292, :636), so its file holds
+                    # the same array at every epoch; mirrored.  The latent after this epoch's update goes to w_opt_<name>_<e>.pkl.
                     with open(os.path.join(self.save_dir, f'w_{base}_{e}.pkl'), 'wb') as f:
+                        pickle.dump((w_in if w_in is not None else tw[e]).squeeze(), f, pickle.HIGHEST_PROTOCOL)
+                    with open(os.path.join(self.save_dir, f'w_opt_{base}_{e}.pkl'), 'wb') as f:
                         pickle.dump(tw[e].squeeze(), f, pickle.HIGHEST_PROTOCOL)
                     if ti.shape[2] >= 2:
                         row = np.concatenate([ti[e, 0, 0], ti[e, 0, 1]], axis=1)      # modality A | modality B
@@ -409,7 +425,12 @@ class LatentAug:
                     fn = self.engine.make_noises(hi - lo, sample_seeds=[noise_seed + i for i in range(lo, hi)])
                 else:
                     fn = None
-                img, w_aug, _ = self.run_local(w[lo:hi], fn)
+                if self._verbose_flag and rank == 0:
+                    # first-batch log of the reference (:278-300): rank 0 reports its own shard, as replica 0 of a DataParallel run would
+                    img, w_aug = self._run_verbose(w[lo:hi], fn, fname[lo:hi] if fname is not None else None)
+                else:
+                    img, w_aug, _ = self.run_local(w[lo:hi], fn)
+                self._verbose_flag = False
             else:
                 img = torch.empty([0, self.engine.img_channels, self.res, self.res], device=self.device)
                 w_aug = torch.empty([0, self.num_ws, self.w_dim], device=self.device)
@@ -421,16 +442,24 @@ class LatentAug:
             w_aug = full[:, n_img:].reshape(B, self.num_ws, self.w_dim)
             return img, w_aug
         if self._verbose_flag:
-            import time
-            trace = {} if w.shape[0] == 1 else None
-            torch.cuda.synchronize(self.device)
-            t0 = time.time()
-            img, w_aug, losses = self.run_local(w, final_noises, want_losses=True, trace=trace)
-            torch.cuda.synchronize(self.device)
-            self._log_first_batch(losses, time.time() - t0, trace, fname)
+            img, w_aug = self._run_verbose(w, final_noises, fname)
             self._verbose_flag = False
             return img, w_aug
         img, w_aug, _ = self.run_local(w, final_noises)
+        return img, w_aug
+
+    def _run_verbose(self, w, final_noises, fname):
+        """One batch with the reference's first-batch artefacts (:278-300): loss scalars of every epoch, and with a batch of one the
+        per-epoch snapshots."""
+        import time
+        trace = {} if w.shape[0] == 1 else None
+        torch.cuda.synchronize(self.device)
+        t0 = time.time()
+        img, w_aug, losses = self.run_local(w, final_noises, want_losses=True, trace=trace)
+        torch.cuda.synchronize(self.device)
+        if trace is not None:
+            trace['w_in'] = w.detach().cpu().numpy()
+        self._log_first_batch(losses, time.time() - t0, trace, fname)
         return img, w_aug
 
     __call__ = forward
@@ -449,6 +478,34 @@ class LatentAug:
 
     def forward_ganrand(self, z, noises=None):
         """reference :202-205: w_aug = G.mapping(z, c=None, truncation_psi); img = G.synthesis(w_aug)  (rand_aug mode)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            # rand_aug with a process group: per-rank capacity is the shard (constructor), so the batch is sharded exactly as in
+            # forward() -- rank 0's z is the batch's (the reference draws it once on the host, latent_aug.py:306-308), rank k maps and
+            # synthesises samples [k*b, (k+1)*b), ONE all_gather returns image + latent to every rank
+            B = z.shape[0]
+            rank = dist.get_rank(self.group)
+            lo, hi, per = shard_bounds(B, dist.get_world_size(self.group), rank)
+            _, _, noise_seed = broadcast_controls((0, 0), self.group, self.device)
+            gloo = dist.get_backend(self.group) == 'gloo'
+            zb = z.detach().to('cpu' if gloo else self.device, torch.float32).contiguous()
+            dist.broadcast(zb, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            n_img = self.engine.img_channels * self.res * self.res
+            if hi > lo:
+                ws = self.mapping.forward(zb[lo:hi].to(self.device), self.num_ws, self.truncation_psi)
+                if noises is not None:
+                    fn = [t[lo:hi].contiguous() if t is not None else None for t in noises]
+                elif self.final_noise_mode == 'random':
+                    fn = self.engine.make_noises(hi - lo, sample_seeds=[noise_seed + i for i in range(lo, hi)])
+                else:
+                    fn = None
+                img = self.engine.forward(ws, noise_mode=self.final_noise_mode, noises=fn)
+                flat = torch.cat([img.reshape(hi - lo, -1), ws.reshape(hi - lo, -1)], dim=1)
+            else:
+                flat = torch.empty([0, n_img + self.num_ws * self.w_dim], device=self.device)
+            full = gather_shards(flat, per, B, self.group)
+            return (full[:, :n_img].reshape(B, self.engine.img_channels, self.res, self.res),
+                    full[:, n_img:].reshape(B, self.num_ws, self.w_dim))
         ws = self.mapping.forward(z.to(self.device), self.num_ws, self.truncation_psi)
         img = self.engine.forward(ws, noise_mode=self.final_noise_mode, noises=noises)
         return img, ws

@@ -6,9 +6,9 @@ from latentaugment_amd import synthetic
 # criterion weights of config E: the authors' values (backbone_latentaug.py:46-54); banks at Pelvis scale (latent_aug.py:78-79)
 CONFIGS = {
     'B': dict(res=256, channel_base=32768, batch=8, steps=20, M_w=1024, M_x=256, w_latent=0.001, w_pix=0.1, w_disc=0.0, w_lpips=0.0),
-    'C': dict(res=512, channel_base=32768, batch=4, steps=5, M_w=1024, M_x=256, w_latent=0.001, w_pix=0.1, w_disc=0.0, w_lpips=0.0),
-    'D': dict(res=1024, channel_base=32768, batch=2, steps=3, M_w=1024, M_x=64, w_latent=0.001, w_pix=0.1, w_disc=0.0, w_lpips=0.0),
-    'E': dict(res=256, channel_base=16384, batch=8, steps=5, M_w=6026, M_x=1572, w_latent=0.001, w_pix=0.1, w_disc=0.01, w_lpips=10.0),
+    'C': dict(res=512, channel_base=32768, batch=4, steps=20, M_w=1024, M_x=256, w_latent=0.001, w_pix=0.1, w_disc=0.0, w_lpips=0.0),
+    'D': dict(res=1024, channel_base=32768, batch=2, steps=10, M_w=1024, M_x=256, w_latent=0.001, w_pix=0.1, w_disc=0.0, w_lpips=0.0),
+    'E': dict(res=256, channel_base=16384, batch=8, steps=20, M_w=6026, M_x=1572, w_latent=0.001, w_pix=0.1, w_disc=0.01, w_lpips=10.0),
 }
 CROP = 64          # crop_size_aug
 CROP_SEED = 6      # python `random` seed of the crop position
