@@ -271,6 +271,9 @@ int la_latent_opt_set_disc(la_latent_opt* h, la_disc* d);
 size_t la_latent_opt_lpips_workspace_bytes(int img_channels, int F, int S, long Mf, int max_batch);
 int la_latent_opt_set_lpips(la_latent_opt* h, la_feat* f, const float* bankF, long Mf, int S, float pre_scale,
                             float pre_shift, void* ws, size_t ws_bytes);
+/* Per-channel input affine of the feature net, x_k * scale[k] + shift[k] for the n (<= 3) repeated channels of :394 -- the
+ * (x - mean_k) / std_k input layer inside NVIDIA's TorchScript vgg16.pt (util_latent_aug.py:35-43).  Overrides the scalar pair. */
+int la_latent_opt_set_lpips_preproc(la_latent_opt* h, const float* scale, const float* shift, int n);
 int la_latent_opt_set_crop_pos(la_latent_opt* h, int x, int y);
 /* Launch mode of the step loop (util_latent_aug.py:219-276).  1 (default): one optimisation step is captured as a hipGraph
  * after its first eager execution and replayed for every further step and batch of the same size -- the loop is ~230 short
@@ -322,6 +325,8 @@ int la_prof_end(double* total_ms, long* launches, double* flops, double* bytes);
 /* la_prof_set_stride(k): bracket a hashed 1-in-k sample of the launches instead of all of them (an event pair costs ~3 us on
  * the stream); la_prof_end then reports the sampled launches' ms / count / FLOPs / bytes, la_prof_total_launches() all of them. */
 int la_prof_set_stride(int stride);
+/* Development only: selects a kernel variant for in-process A/B timing (scripts/bench_layer.py --ab).  All knobs are 0 in the product. */
+int la_dev_knob_set(int id, int value);
 long la_prof_total_launches(void);
 /* Per kernel class (la_prof_num_classes() entries per array): 0 contraction / halo, 1 contraction / flat, 2 contraction /
  * split-K incl. its finish pass, 3 contraction / exact-fp32 MFMA, 4 operand preparation (plane maxima, pre-split copy),

@@ -109,10 +109,12 @@ SIGNATURES = {
     'la_latent_opt_set_graph': (_I, [_P, _I]),
     'la_latent_opt_set_trace': (_I, [_P, _P, _P]),
     'la_latent_opt_set_grad_trace': (_I, [_P, _P]),
+    'la_latent_opt_set_lpips_preproc': (_I, [_P, _P, _P, _I]),
     'la_latent_opt_invalidate_banks': (_I, [_P]),
     'la_prof_begin': (_I, []),
     'la_prof_end': (_I, [_P, _P, _P, _P]),
     'la_prof_set_stride': (_I, [_I]),
+    'la_dev_knob_set': (_I, [_I, _I]),
     'la_prof_total_launches': (_L, []),
     'la_prof_num_classes': (_I, []),
     'la_prof_end_classes': (_I, [_P, _P, _P, _P, _I]),

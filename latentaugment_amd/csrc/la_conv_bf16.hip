@@ -359,7 +359,8 @@ bool la_conv_bf16_uses_halo(const LaConvArgs& a) {
     if (a.in_sy != 1 || a.in_sx != 1 || a.out_sy != 1 || a.out_sx != 1 || a.out_oy != 0 || a.out_ox != 0) return false;
     if ((a.Gx & 31) != 0 || (a.Gy & 3) != 0 || a.Gy != a.Hout || a.Gx != a.Wout || a.ntaps != 9) return false;
     if ((long)a.Gy * a.Gx <= 1156) return false;                         // split-K territory (la_conv.hip SPLITK_MAX_G)
-    if ((long)a.C * a.Hin * a.Win >= (1l << 29) || a.C > 4096) return false;   // 32-bit byte offsets inside one sample
+    if ((long)a.C * a.Hin * a.Win >= (1l << 28) || a.C > 4096) return false;   // 32-bit byte offsets inside one sample, below the
+                                                                             // out-of-range sentinel of the pixel-stationary loader
     for (int t = 0; t < a.ntaps; ++t)
         if (a.tap_dy[t] < -1 || a.tap_dy[t] > 1 || a.tap_dx[t] < -1 || a.tap_dx[t] > 1) return false;
     return true;
@@ -825,9 +826,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
 // cost a second set of 64 accumulator registers and 64 moves per chunk.  Measured per 154.6-GFLOP launch (WV 3 against 2):
 // 128->128 @256^2 fwd -9.5 %, bwd -7 %; 256->256 @128^2 fwd -8 %, bwd -8 %; 512->512 @64^2 +-0 (two rounds of workgroups only) --
 // la_conv_bf16_dispatch uses WV 3 for every 128-row fp16 launch.
-template <int MT, int FMT, int WV>
+// MF = 1 (three-wave fp16 x2 form on 128-row tiles only): the same wave tile (32 rows x 128 pixels) on v_mfma_f32_16x16x32_f16 -- 2 x 8
+// tiles of 16 x 16, one MFMA per (tile, term pair) over the whole 32-channel chunk.  A 16x16x32 fragment feeds half the FLOPs of a
+// 32x32x16 one, so with the same 32 fragment registers per operand every pixel fragment is read from LDS twice per tap (once per
+// 16-row half); the weight fragments of a half die at the middle of the tap and are re-loaded then, as the K-step fragments are in the
+// 32x32x16 form.  Same weight pack (a 16-row fragment is four 256-byte pieces of the 32-row block), LDS slots swizzled by
+// 2 * ((pixel >> 2) & 1) (conflict-free for this lane map at every tap shift).  The accumulators are brought into the 32x32 layout
+// through LDS before the shared epilogue.
+template <int MT, int FMT, int WV, int MF = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void la_conv_bf16_halo_kernel(LaConvArgs a) {
     constexpr bool SB = WV == 3;
+    static_assert(MF == 0 || (WV == 3 && FMT == FMT_F16X2 && MT == 128), "the MF forms exist for the three-wave fp16 x2 kernel on 128-row tiles");
+    // MF bits: 1 = 16x16x32 MFMA; 2 = dev ablation (the loader skips the modulation and the fp16 split arithmetic: WRONG results, timing
+    // only); 4 = pixel-stationary halo loader (below)
+    constexpr bool M16 = (MF & 1) != 0, ABL = (MF & 2) != 0, PSL = (MF & 4) != 0;
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     constexpr bool F16 = FMT == FMT_F16X2;
     constexpr int WM_ = MT / 32;                   // wave grid WM_ x WN_ over the MT x 128 tile: every wave owns 32 rows
@@ -872,10 +884,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
 
     // tap table -> two packed scalars, so the tap loop needs no indexed kernarg reads
     unsigned long long shpack = 0ull, wpack = 0ull;
+    unsigned xpack = 0u;                       // 1 + dx of every tap (PSL: the LDS slot swizzle follows the halo COLUMN)
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         shpack |= (unsigned long long)((1 + a.tap_dy[t]) * HALO_W + (1 + a.tap_dx[t])) << (7 * t);
         wpack |= (unsigned long long)a.tap_w[t] << (4 * t);
+        xpack |= (unsigned)(1 + a.tap_dx[t]) << (2 * t);
     }
 
     // ---- halo slices.  Every load is unconditional (clamped address; out-of-image pixels are zeroed on the way to LDS,
@@ -892,7 +906,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         sl.ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
         const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
         const unsigned off = (unsigned)(iyc * a.Win + ixc) * EB;
-        sl.wr = valid ? hp * HPITCH + ((((c4 >> 1) ^ (hp >> 2)) & 3) << 4) + (c4 & 1) * 8 : -1;
+        const int swz = M16 ? ((hp >> 2) & 1) << 1 : (hp >> 2);
+        sl.wr = valid ? hp * HPITCH + ((((c4 >> 1) ^ swz) & 3) << 4) + (c4 & 1) * 8 : -1;
         sl.c0 = cc * KCB + c4 * 4;
         const bool fast = cc * KCB + KCB <= a.C;                  // uniform: only a ragged last chunk clamps channels
 #pragma unroll
@@ -916,6 +931,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
             const float4 f = *reinterpret_cast<const float4*>(scl + sl.c0);
             f32x2 v0 = {sl.x[0] * f.x, sl.x[1] * f.y}, v1 = {sl.x[2] * f.z, sl.x[3] * f.w};
+            if constexpr (ABL) {
+                const uint2 w = make_uint2(__builtin_bit_cast(unsigned, sl.x[0]), __builtin_bit_cast(unsigned, sl.x[2]));
+                *reinterpret_cast<uint2*>(buf + sl.wr) = w;
+                *reinterpret_cast<uint2*>(buf + HPLANE + sl.wr) = w;
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < NTERM; ++q) {
                 uint2 w;
@@ -930,6 +951,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
                 }
                 *reinterpret_cast<uint2*>(buf + q * HPLANE + sl.wr) = sl.ok ? w : make_uint2(0u, 0u);
             }
+        }
+    };
+
+    // ---- pixel-stationary form of the halo loader (PSL).  The slices above give every thread a different (channel group, halo pixel)
+    // unit in every tap and recompute its image position, clamps and LDS slot from scratch: ~45 integer instructions per tap and
+    // thread (five of them quarter-rate 32-bit multiplies) beside the MFMAs.  Here thread hp < 204 owns halo pixel hp for the whole
+    // kernel -- image offset, validity and LDS row are computed ONCE -- and tap t (0..7) stages channel group t of the next chunk
+    // for it (tap 8 repeats the loads of tap 0 and drops them, so that every wait in the tap loop stays a counted vmcnt): the channel is
+    // wave-uniform, i.e. scalar arithmetic, and what is left per tap are the four loads, the split and one XOR for the LDS slot.
+    // With it the 16-byte slots of a pixel row are XOR-swizzled by the halo COLUMN (hx >> 2) instead of the linear pixel index: equally
+    // conflict-free (a fragment read covers consecutive columns of one halo row), but the swizzle of a fragment read then depends on
+    // the lane and the tap's dx only -- not on the tile row or dy -- so ONE lane address per tap serves every fragment read of the tap
+    // through immediate offsets (was: five instructions per read).  Out-of-image pixels are loaded with an out-of-range buffer
+    // offset, which the hardware returns as zeros (no select per value).
+    const bool ps_act = tid < HALO_PX;
+    unsigned ps_off = 0u; int ps_row = 0, ps_swz = 0; bool ps_ok = false;
+    if constexpr (PSL) {
+        const int hp = ps_act ? tid : 0;
+        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+        const int iy = y0 + hy, ix = x0 + hx;
+        ps_ok = ps_act && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
+        ps_off = ps_ok ? (unsigned)(iyc * a.Win + ixc) * EB : 0x7ffffff0u;      // (raw buffer: voffset >= num_records reads as 0)
+        ps_row = hp * HPITCH;
+        ps_swz = M16 ? ((hx >> 2) & 1) << 1 : (hx >> 2) & 3;
+    }
+    auto ps_load = [&](int cc, int t, float (&x)[4]) {      // cc, t: wave-uniform.  Tap 8 (and the last chunk, which passes its own
+        // cc) re-loads data that is already on its way / in L2 instead of branching around the loads: a uniform condition here is
+        // turned into scalar branches with one load form per path, and the waits of the tap loop stop being exact counts
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = cc * KCB + (t & 7) * 4 + j;
+            c = c < a.C ? c : a.C - 1;                                 // (ragged last chunk: the channel meets zero weights)
+            x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, ps_off, (unsigned)c * HWin * EB, 0));
+        }
+    };
+    auto ps_write = [&](unsigned char* buf, int cc, int t, const float (&x)[4]) {      // the slice loaded with the same (cc, t)
+        if (t < 8 && ps_act) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            const float4 f = *reinterpret_cast<const float4*>(scl + cc * KCB + t * 4);
+            unsigned char* dst = buf + ps_row + ((((t >> 1) ^ ps_swz) & 3) << 4) + (t & 1) * 8;
+            if constexpr (ABL) {
+                const uint2 w = make_uint2(__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[2]));
+                *reinterpret_cast<uint2*>(dst) = w;
+                *reinterpret_cast<uint2*>(dst + HPLANE) = w;
+                return;
+            }
+            // scalar fp32 arithmetic on purpose: v_pk_mul_f32 / v_pk_fma_f32 beside MFMAs cost ~20 cycles each (MI355X_MICROARCH.md,
+            // 'price of one filler beside MFMAs'); only the two conversions are packed
+            const float p0 = x[0] * f.x, p1 = x[1] * f.y, p2 = x[2] * f.z, p3 = x[3] * f.w;
+            const f16x2 h0 = __builtin_convertvector(f32x2{p0, p1}, f16x2), h1 = __builtin_convertvector(f32x2{p2, p3}, f16x2);
+            const float r0 = __builtin_fmaf(x[0], f.x, -(float)h0[0]), r1 = __builtin_fmaf(x[1], f.y, -(float)h0[1]);
+            const float r2 = __builtin_fmaf(x[2], f.z, -(float)h1[0]), r3 = __builtin_fmaf(x[3], f.w, -(float)h1[1]);
+            const f16x2 l0 = __builtin_convertvector(f32x2{r0, r1}, f16x2), l1 = __builtin_convertvector(f32x2{r2, r3}, f16x2);
+            const uint2 wh = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+            const uint2 wl = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+            *reinterpret_cast<uint2*>(dst) = wh;
+            *reinterpret_cast<uint2*>(dst + HPLANE) = wl;
         }
     };
 
@@ -954,11 +1034,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
                 dst[q][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_off[i], so + q * term_bytes, 0));
     };
     // B fragments: lane (l31, lh) of N-subtile j reads slot ks*2 + lh of halo pixel (wn*NJ + j) * 34 + shift + l31
-    auto read_b = [&](const unsigned char* buf, int shift, int ks, bf16x8 (&dst)[NTERM][NJ]) {
+    // PSL (column swizzle): byte offset of this lane's K-step 0 fragment of tile row 0 for a tap; K-step 1 = ^ 32, tile row j = + j * 34 * 64
+    auto lane_b = [&](int shift, int dxp) -> int {
+        return (shift + l31) * HPITCH + (((lh ^ ((l31 + dxp) >> 2)) & 3) << 4);
+    };
+    auto read_b = [&](const unsigned char* buf, int shift, int ks, bf16x8 (&dst)[NTERM][NJ], int lb = 0) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int p = (wn * NJ + j) * HALO_W + shift + l31;
-            const int o = p * HPITCH + ((((ks * 2 + lh) ^ (p >> 2)) & 3) << 4);
+            int o;
+            if constexpr (PSL) o = (lb ^ (ks << 5)) + (wn * NJ + j) * HALO_W * HPITCH;
+            else {
+                const int p = (wn * NJ + j) * HALO_W + shift + l31;
+                o = p * HPITCH + ((((ks * 2 + lh) ^ (p >> 2)) & 3) << 4);
+            }
 #pragma unroll
             for (int q = 0; q < NTERM; ++q) dst[q][j] = *reinterpret_cast<const bf16x8*>(buf + q * HPLANE + o);
         }
@@ -990,7 +1078,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
 
     // ---- prologue: chunk 0's halo (all nine slices in flight at once) and the first tap's weights
     bf16x8 acur[2][NTERM][TM];
-    {
+    if constexpr (PSL) {
+        float pre[8][4];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) ps_load(0, t, pre[t]);
+        if constexpr (!M16) { load_a(0, 0, 0, acur[0]); load_a(0, 0, 1, acur[1]); }
+        {
+            const float xs = F16 ? a.acc_scale_x[b] : 1.f;
+            for (int k = tid; k < nck * KCB; k += 256)
+                scl[k] = k < a.C ? (a.in_scale ? a.in_scale[(long)b * a.scale_stride + k] : 1.f) * xs : 0.f;
+        }
+        __syncthreads();                           // scl is complete before any slice is scaled with it
+#pragma unroll
+        for (int t = 0; t < 8; ++t) ps_write(smem, 0, t, pre[t]);
+    } else {
         Slice pre[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) slice_load(0, t, pre[t]);
@@ -1010,11 +1111,133 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     __syncthreads();
     STAMP(3);
 
+  if constexpr (M16) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int c16 = lane & 15, kq = lane >> 4;
+    f32x4 acc16[2][8];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc16[mi][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // weight fragments of a 16-row half: lane (c16, kq) holds rows mi*16 + c16, channels 8 kq .. 8 kq + 7 of the chunk
+    int mblk16 = (m0 + wm * 32) >> 5;
+    mblk16 = mblk16 < (Mp >> 5) ? mblk16 : (Mp >> 5) - 1;
+    const unsigned a16_off = (unsigned)mblk16 * 2048u + (unsigned)(kq * 32 + c16) * 16u;
+    auto load_a16 = [&](int cc, int t, int mi, f16x8 (&dst)[2]) {
+        const unsigned tw = (unsigned)((wpack >> (4 * t)) & 15u);
+        const unsigned so = (tw * nck + cc) * slab_bytes;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            dst[q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, a16_off + (unsigned)mi * 256u, so + q * term_bytes, 0));
+    };
+    // pixel fragment of tile n (tile row n >> 1, x half n & 1): lane (c16, kq) reads slot kq of its pixel's 64-byte row
+    // (PSL, column swizzle: lb16 = this lane's offset for the tap, the tile adds an immediate)
+    auto lane_b16 = [&](int shift, int dxp) -> int {
+        return (shift + c16) * HPITCH + (((kq ^ ((((c16 + dxp) >> 2) & 1) << 1)) & 3) << 4);
+    };
+    auto read_b16 = [&](const unsigned char* buf, int shift, int n, f16x8 (&dst)[2], int lb16 = 0) {
+        int o;
+        if constexpr (PSL) o = lb16 + ((n >> 1) * HALO_W + (n & 1) * 16) * HPITCH;
+        else {
+            const int p = (n >> 1) * HALO_W + shift + (n & 1) * 16 + c16;
+            o = p * HPITCH + (((kq ^ (((p >> 2) & 1) << 1)) & 3) << 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dst[q] = *reinterpret_cast<const f16x8*>(buf + q * HPLANE + o);
+    };
+    f16x8 a16[2][2], b16[4][2];
+    // (issue order pinned: the tap loop's first wait is counted for "everything but the two youngest loads" on both of its entries)
+    __builtin_amdgcn_sched_barrier(0);
+    load_a16(0, 0, 0, a16[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    load_a16(0, 0, 1, a16[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int cc = 0; cc < nck; ++cc) {
+        const unsigned char* cur = smem + (cc & 1) * HBUF;
+        unsigned char* nxt = smem + ((cc + 1) & 1) * HBUF;
+        const bool has_next = cc + 1 < nck;
+        Slice sl;
+        sl.wr = -1;
+        sl.ok = false;
+        float psx[4] = {0.f, 0.f, 0.f, 0.f};
+        int lb_cur = PSL ? lane_b16((int)(shpack & 127u), (int)(xpack & 3u)) : 0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) read_b16(cur, (int)(shpack & 127u), n, b16[n], lb_cur);
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            const int shift = (int)((shpack >> (7 * t)) & 127u);
+            const int tn = t + 1 < 9 ? t + 1 : 0;
+            const int ccn = t + 1 < 9 ? cc : (has_next ? cc + 1 : 0);
+            const int shift_n = (int)((shpack >> (7 * (t + 1 < 9 ? t + 1 : 8))) & 127u);
+            const int lb_nxt = PSL ? lane_b16(shift_n, (int)((xpack >> (2 * (t + 1 < 9 ? t + 1 : 8))) & 3u)) : 0;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    f16x8 (&bs)[2] = b16[n & 3];
+                    acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][1], bs[0], acc16[mi][n], 0, 0, 0);   // lh
+                    acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][0], bs[1], acc16[mi][n], 0, 0, 0);   // hl
+                    acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][0], bs[0], acc16[mi][n], 0, 0, 0);   // hh
+                    // the slot is re-filled with the tile four steps ahead: (mi, n + 4), then (mi + 1, n - 4) of this tap (the same
+                    // pixels again for the other 16 rows), then tile n - 4 of the next tap (never across the chunk barrier)
+                    if (n < 4) read_b16(cur, shift, n + 4, bs, lb_cur);
+                    else if (mi == 0) read_b16(cur, shift, n - 4, bs, lb_cur);
+                    else if (t + 1 < 9) read_b16(cur, shift_n, n - 4, bs, lb_nxt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                load_a16(ccn, tn, mi, a16[mi]);          // this half's weights of the next tap: half a tap to land
+                if (mi == 0) {
+                    if constexpr (PSL) {
+                        if (has_next && t >= 1) ps_write(nxt, cc + 1, t - 1, psx);      // the slice loaded one tap ago
+                        ps_load(has_next ? cc + 1 : cc, t, psx);
+                    } else {
+                        slice_write(nxt, sl);
+                        slice_load(has_next ? cc + 1 : cc, t, sl, has_next);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            lb_cur = lb_nxt;
+        }
+        if constexpr (!PSL) slice_write(nxt, sl);      // (PSL: tap 8 loads nothing)
+        __syncthreads();
+    }
+    // 16x16 tiles -> the 32x32 accumulator layout of the epilogue, through LDS (free after the loop's last barrier), two tile rows
+    // at a time: image [wave][64 pixels][36 floats] (32 rows + 4 of padding), 16-byte writes and reads
+    {
+        const float inv = 1.f / (a.acc_scale_w[0] * a.acc_scale_x[b]);
+        float* tb = reinterpret_cast<float*>(smem) + wid * (64 * 36);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            if (hf) __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int n4 = 0; n4 < 4; ++n4) {
+                    const int n = hf * 4 + n4;
+                    const int px = (n4 >> 1) * 32 + (n & 1) * 16 + c16;
+                    *reinterpret_cast<f32x4*>(tb + px * 36 + mi * 16 + kq * 4) = acc16[mi][n] * inv;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(tb + (jj * 32 + l31) * 36 + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[0][hf * 2 + jj][4 * g + r] = v[r];
+                }
+        }
+        __syncthreads();
+    }
+    la_conv_epilogue<MT, false, true, WM_>(a, acc, red, ntile, m0, G, G);
+    return;
+  } else
   if constexpr (SB) {
     // single-buffer form: bf holds the fragments of ONE K-step; sub-tile j is re-loaded for the following K-step right after its own
     // three MFMAs have issued, so its LDS latency runs under the MFMAs of the other sub-tiles and no second fragment set is live
     bf16x8 bf[NTERM][NJ];
-    auto mma_refill = [&](bf16x8 (&af)[NTERM][TM], const unsigned char* buf, int shift, int ks, bool refill) {
+    auto mma_refill = [&](bf16x8 (&af)[NTERM][TM], const unsigned char* buf, int shift, int ks, bool refill, int lb = 0) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if constexpr (NTERM == 3) {
@@ -1026,8 +1249,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             acc[0][j] = la_mma<F16>(af[0][0], bf[1][j], acc[0][j]);
             acc[0][j] = la_mma<F16>(af[0][0], bf[0][j], acc[0][j]);
             if (refill) {
-                const int p = (wn * NJ + j) * HALO_W + shift + l31;
-                const int o = p * HPITCH + ((((ks * 2 + lh) ^ (p >> 2)) & 3) << 4);
+                int o;
+                if constexpr (PSL) o = (lb ^ (ks << 5)) + (wn * NJ + j) * HALO_W * HPITCH;
+                else {
+                    const int p = (wn * NJ + j) * HALO_W + shift + l31;
+                    o = p * HPITCH + ((((ks * 2 + lh) ^ (p >> 2)) & 3) << 4);
+                }
 #pragma unroll
                 for (int q = 0; q < NTERM; ++q) bf[q][j] = *reinterpret_cast<const bf16x8*>(buf + q * HPLANE + o);
             }
@@ -1041,22 +1268,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         Slice sl;
         sl.wr = -1;
         sl.ok = false;
-        read_b(cur, (int)(shpack & 127u), 0, bf);
+        float psx[4] = {0.f, 0.f, 0.f, 0.f};
+        int lb = PSL ? lane_b((int)(shpack & 127u), (int)(xpack & 3u)) : 0;      // lane address of the current tap (PSL)
+        read_b(cur, (int)(shpack & 127u), 0, bf, lb);
 #pragma unroll 1
         for (int t = 0; t < 9; ++t) {
             const int shift = (int)((shpack >> (7 * t)) & 127u);
             const int tn = t + 1 < 9 ? t + 1 : 0;
             const int ccn = t + 1 < 9 ? cc : (has_next ? cc + 1 : 0);
             const int shift_n = (int)((shpack >> (7 * (t + 1 < 9 ? t + 1 : 8))) & 127u);
-            mma_refill(acur[0], cur, shift, 1, true);          // K-step 0; refilled with this tap's K-step 1
+            mma_refill(acur[0], cur, shift, 1, true, lb);      // K-step 0; refilled with this tap's K-step 1
+            if constexpr (PSL) lb = lane_b(shift_n, (int)((xpack >> (2 * (t + 1 < 9 ? t + 1 : 8))) & 3u));
             load_a(ccn, tn, 0, acur[0]);
-            slice_write(nxt, sl);
-            slice_load(has_next ? cc + 1 : cc, t, sl, has_next);      // (last chunk: dummy loads, nothing staged)
+            if constexpr (PSL) {
+                if (has_next && t >= 1) ps_write(nxt, cc + 1, t - 1, psx);      // the slice loaded one tap ago
+                ps_load(has_next ? cc + 1 : cc, t, psx);
+            } else {
+                slice_write(nxt, sl);
+                slice_load(has_next ? cc + 1 : cc, t, sl, has_next);      // (last chunk: dummy loads, nothing staged)
+            }
             __builtin_amdgcn_sched_barrier(0);
-            mma_refill(acur[1], cur, shift_n, 0, t + 1 < 9);   // K-step 1; refilled with the next tap's K-step 0 (not across the barrier)
+            mma_refill(acur[1], cur, shift_n, 0, t + 1 < 9, lb);   // K-step 1; refilled with the next tap's K-step 0 (not across the barrier)
             load_a(ccn, tn, 1, acur[1]);
         }
-        slice_write(nxt, sl);
+        if constexpr (!PSL) slice_write(nxt, sl);      // (PSL: tap 8 loads nothing)
         __syncthreads();       // next halo complete, everyone done with this one (and, at the end, LDS free for the epilogue)
     }
   } else {
@@ -1148,6 +1383,34 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
         // three-wave form for the fp16 x2 launches on 128-row tiles (see the kernel comment); dev knob LA_HALO_W3=0|1
         static const int w3_knob = []() { const char* e = getenv("LA_HALO_W3"); return e ? atoi(e) : -1; }();
         const bool w3 = NTERM == 2 && MTsel == 128 && (w3_knob >= 0 ? w3_knob != 0 : true);
+        if constexpr (FMT == FMT_F16X2) {
+            // fp16 x2 launches on 128-row tiles with more than one chunk: the 16x16x32 / pixel-stationary form (MF 5, kernel comment).
+            // Dev knob (in-process A/B): 0 = this default, 8 = the round-2 form (MF 0), otherwise the MF bits to run.
+            const int knob = la_dev_knob(LA_KNOB_HALO_MF);
+            const int mf = knob == 0 ? 5 : (knob == 8 ? 0 : knob);
+            if (MTsel == 128 && w3 && as.C > KCB && mf > 0) {
+                auto go = [&](auto tag) -> int {
+                    constexpr int MFV = decltype(tag)::value;
+                    static std::atomic<bool> done[64];
+                    if (!done[dev].load(std::memory_order_acquire)) {
+                        const int cap = 2 * 3 * HALO_PX * HPITCH + 4096 * (int)sizeof(float);
+                        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, FMT_F16X2, 3, MFV>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess) {
+                            la_set_error("halo MF: hipFuncSetAttribute failed"); return LA_ERR_HIP;
+                        }
+                        done[dev].store(true, std::memory_order_release);
+                    }
+                    hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, FMT_F16X2, 3, MFV>), grid, dim3(256), h128, stream, as);
+                    return LA_OK;
+                };
+                switch (mf) {
+                    case 1: return go(std::integral_constant<int, 1>{});
+                    case 4: return go(std::integral_constant<int, 4>{});
+                    case 5: return go(std::integral_constant<int, 5>{});
+                    case 7: return go(std::integral_constant<int, 7>{});      // (loader ablation: wrong results)
+                    default: break;
+                }
+            }
+        }
         if (MTsel == 128 && w3) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, FMT, W3>), grid, dim3(256), h128, stream, as);
         else if (MTsel == 128) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, FMT, 2>), grid, dim3(256), h128, stream, as);
         else if (MTsel == 64) hipLaunchKernelGGL((la_conv_bf16_halo_kernel<64, FMT, 2>), grid, dim3(256), h64, stream, as);

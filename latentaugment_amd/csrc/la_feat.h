@@ -29,3 +29,8 @@ int la_crop_repeat_ex(const float* img, float* xc, int B, int imgc, int R, int S
                       float shift, hipStream_t stream);
 int la_crop_repeat_grad_ex(const float* gxc, float* g_img, int B, int imgc, int R, int S, int y0, int x0, const int* pos_dev, int rep,
                            float scale, hipStream_t stream);
+// per-repeated-channel affine ([rep] values each, rep <= 4): the input layer of an ImageNet-style net, (x - mean_k) / std_k
+int la_crop_repeat_ex3(const float* img, float* xc, int B, int imgc, int R, int S, int y0, int x0, const int* pos_dev, int rep,
+                       const float* scale, const float* shift, hipStream_t stream);
+int la_crop_repeat_grad_ex3(const float* gxc, float* g_img, int B, int imgc, int R, int S, int y0, int x0, const int* pos_dev, int rep,
+                            const float* scale, hipStream_t stream);

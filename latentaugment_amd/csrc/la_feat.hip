@@ -345,21 +345,23 @@ extern "C" int la_feat_backward(la_feat* h, const float* gfeat, float* gx, hipSt
 //   xc[(c*B + b)][k][y][x] = img[b][c][y0+y][x0+x] * scale + shift      k = 0..rep-1
 // (pos != null: the window position {y0, x0} is read from device memory, so that a captured launch follows the position the
 //  host draws per forward)
+struct LaPreAffine { float scale[4], shift[4]; };      // per repeated channel k (k < rep <= 4)
 __global__ void la_crop_repeat_kernel(const float* __restrict__ img, float* __restrict__ xc, int B, int imgc, int R, int S, int y0,
-                                      int x0, int rep, float scale, float shift, long total, const int* __restrict__ pos) {
+                                      int x0, int rep, LaPreAffine pre, long total, const int* __restrict__ pos) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     if (pos) { y0 = pos[0]; x0 = pos[1]; }
     const int x = (int)(i % S), y = (int)((i / S) % S);
     const long rest = i / ((long)S * S);
     const long n = rest / rep;
+    const int k = (int)(rest - n * rep);
     const int c = (int)(n / B), b = (int)(n - (long)c * B);
-    xc[i] = img[(((long)b * imgc + c) * R + y0 + y) * R + x0 + x] * scale + shift;
+    xc[i] = img[(((long)b * imgc + c) * R + y0 + y) * R + x0 + x] * pre.scale[k] + pre.shift[k];
 }
 
-// g_img[b][c][y0+y][x0+x] += scale * sum_k gxc[(c*B+b)][k][y][x]
+// g_img[b][c][y0+y][x0+x] += sum_k scale[k] * gxc[(c*B+b)][k][y][x]
 __global__ void la_crop_repeat_bwd_kernel(const float* __restrict__ gxc, float* __restrict__ g_img, int B, int imgc, int R, int S,
-                                          int y0, int x0, int rep, float scale, long total, const int* __restrict__ pos) {
+                                          int y0, int x0, int rep, LaPreAffine pre, long total, const int* __restrict__ pos) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     if (pos) { y0 = pos[0]; x0 = pos[1]; }
@@ -367,32 +369,49 @@ __global__ void la_crop_repeat_bwd_kernel(const float* __restrict__ gxc, float* 
     const long n = i / ((long)S * S);
     const int c = (int)(n / B), b = (int)(n - (long)c * B);
     float acc = 0.f;
-    for (int k = 0; k < rep; ++k) acc += gxc[((n * rep + k) * S + y) * S + x];
-    g_img[(((long)b * imgc + c) * R + y0 + y) * R + x0 + x] += acc * scale;
+    for (int k = 0; k < rep; ++k) acc += gxc[((n * rep + k) * S + y) * S + x] * pre.scale[k];
+    g_img[(((long)b * imgc + c) * R + y0 + y) * R + x0 + x] += acc;
 }
 
-int la_crop_repeat_ex(const float* img, float* xc, int B, int imgc, int R, int S, int y0, int x0, const int* pos_dev, int rep, float scale,
-                      float shift, hipStream_t stream) {
-    LA_CHECK_ARG(img && xc && y0 >= 0 && x0 >= 0 && y0 + S <= R && x0 + S <= R && rep >= 1, "crop_repeat: bad arguments");
+// scale / shift: one value per repeated channel ([rep], rep <= 4) -- e.g. the (x - mean_k) / std_k of an ImageNet-style input layer
+int la_crop_repeat_ex3(const float* img, float* xc, int B, int imgc, int R, int S, int y0, int x0, const int* pos_dev, int rep,
+                       const float* scale, const float* shift, hipStream_t stream) {
+    LA_CHECK_ARG(img && xc && y0 >= 0 && x0 >= 0 && y0 + S <= R && x0 + S <= R && rep >= 1 && rep <= 4 && scale && shift, "crop_repeat: bad arguments");
+    LaPreAffine pre;
+    for (int k = 0; k < 4; ++k) { pre.scale[k] = scale[k < rep ? k : rep - 1]; pre.shift[k] = shift[k < rep ? k : rep - 1]; }
     const long total = (long)B * imgc * rep * S * S;
-    hipLaunchKernelGGL(la_crop_repeat_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, stream, img, xc, B, imgc, R, S, y0, x0, rep, scale,
-                       shift, total, pos_dev);
+    hipLaunchKernelGGL(la_crop_repeat_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, stream, img, xc, B, imgc, R, S, y0, x0, rep, pre,
+                       total, pos_dev);
     LA_CHECK_LAUNCH();
     return LA_OK;
+}
+int la_crop_repeat_ex(const float* img, float* xc, int B, int imgc, int R, int S, int y0, int x0, const int* pos_dev, int rep, float scale,
+                      float shift, hipStream_t stream) {
+    const float sc[4] = {scale, scale, scale, scale}, sh[4] = {shift, shift, shift, shift};
+    LA_CHECK_ARG(rep >= 1 && rep <= 4, "crop_repeat: rep must be 1..4");
+    return la_crop_repeat_ex3(img, xc, B, imgc, R, S, y0, x0, pos_dev, rep, sc, sh, stream);
 }
 extern "C" int la_crop_repeat_f32(const float* img, float* xc, int B, int imgc, int R, int S, int y0, int x0, int rep, float scale,
                                   float shift, hipStream_t stream) {
     return la_crop_repeat_ex(img, xc, B, imgc, R, S, y0, x0, nullptr, rep, scale, shift, stream);
 }
 
-int la_crop_repeat_grad_ex(const float* gxc, float* g_img, int B, int imgc, int R, int S, int y0, int x0, const int* pos_dev, int rep,
-                           float scale, hipStream_t stream) {
-    LA_CHECK_ARG(gxc && g_img && y0 >= 0 && x0 >= 0 && y0 + S <= R && x0 + S <= R && rep >= 1, "crop_repeat_grad: bad arguments");
+int la_crop_repeat_grad_ex3(const float* gxc, float* g_img, int B, int imgc, int R, int S, int y0, int x0, const int* pos_dev, int rep,
+                            const float* scale, hipStream_t stream) {
+    LA_CHECK_ARG(gxc && g_img && y0 >= 0 && x0 >= 0 && y0 + S <= R && x0 + S <= R && rep >= 1 && rep <= 4 && scale, "crop_repeat_grad: bad arguments");
+    LaPreAffine pre;
+    for (int k = 0; k < 4; ++k) { pre.scale[k] = scale[k < rep ? k : rep - 1]; pre.shift[k] = 0.f; }
     const long total = (long)B * imgc * S * S;
     hipLaunchKernelGGL(la_crop_repeat_bwd_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, stream, gxc, g_img, B, imgc, R, S, y0, x0, rep,
-                       scale, total, pos_dev);
+                       pre, total, pos_dev);
     LA_CHECK_LAUNCH();
     return LA_OK;
+}
+int la_crop_repeat_grad_ex(const float* gxc, float* g_img, int B, int imgc, int R, int S, int y0, int x0, const int* pos_dev, int rep,
+                           float scale, hipStream_t stream) {
+    const float sc[4] = {scale, scale, scale, scale};
+    LA_CHECK_ARG(rep >= 1 && rep <= 4, "crop_repeat_grad: rep must be 1..4");
+    return la_crop_repeat_grad_ex3(gxc, g_img, B, imgc, R, S, y0, x0, pos_dev, rep, sc, stream);
 }
 extern "C" int la_crop_repeat_grad_f32(const float* gxc, float* g_img, int B, int imgc, int R, int S, int y0, int x0, int rep,
                                        float scale, hipStream_t stream) {

@@ -24,7 +24,7 @@ struct la_latent_opt {
     // LPIPS criterion (la_latent_opt_set_lpips)
     la_feat* f;
     const float* bankF; long Mf; int F, S, crop_x, crop_y;
-    float pre_scale, pre_shift;
+    float pre_scale[4], pre_shift[4];     // input affine of the feature net, per repeated channel
     float *l_xc, *l_feat, *l_gfeat, *l_gxc, *l_colsum, *l_yx, *l_yy, *l_xx;
     int l_colsum_valid;
     // step-invariant launch sequence: device-side step counter + Adam bias-correction table + crop position, so that ONE
@@ -171,7 +171,7 @@ extern "C" int la_latent_opt_set_lpips(la_latent_opt* h, la_feat* f, const float
     LA_CHECK_ARG(h && f && bankF && Mf >= 1 && S >= 1 && ws, "latent_opt_set_lpips: bad arguments");
     const int F = la_feat_num_features(f);
     LA_CHECK_ARG(ws_bytes >= la_latent_opt_lpips_workspace_bytes(h->imgc, F, S, Mf, h->maxB), "latent_opt_set_lpips: workspace too small");
-    h->f = f; h->bankF = bankF; h->Mf = Mf; h->F = F; h->S = S; h->pre_scale = pre_scale; h->pre_shift = pre_shift;
+    h->f = f; h->bankF = bankF; h->Mf = Mf; h->F = F; h->S = S; for (int k = 0; k < 4; ++k) { h->pre_scale[k] = pre_scale; h->pre_shift[k] = pre_shift; }
     char* base = (char*)ws; size_t off = 0;
     auto take = [&](size_t n) { float* p = (float*)(base + off); off += al(n); return p; };
     const size_t n = (size_t)h->imgc * h->maxB;
@@ -180,6 +180,15 @@ extern "C" int la_latent_opt_set_lpips(la_latent_opt* h, la_feat* f, const float
     h->l_colsum = take((size_t)h->imgc * F);
     h->l_yx = take(LA_YX_FLOATS(Mf, h->maxB)); h->l_yy = take(LA_YY_FLOATS(Mf)); h->l_xx = take(LA_XX_FLOATS(h->maxB));
     h->l_colsum_valid = 0;
+    drop_graph(h);
+    return LA_OK;
+}
+
+// per-channel input affine of the feature net (the three repeated channels of :394): x_k * scale[k] + shift[k], e.g. the
+// (x - mean_k) / std_k input layer of NVIDIA's vgg16.pt.  Overrides the scalar pair of la_latent_opt_set_lpips.
+extern "C" int la_latent_opt_set_lpips_preproc(la_latent_opt* h, const float* scale, const float* shift, int n) {
+    LA_CHECK_ARG(h && scale && shift && n >= 1 && n <= 4, "latent_opt_set_lpips_preproc: bad arguments");
+    for (int k = 0; k < 4; ++k) { h->pre_scale[k] = scale[k < n ? k : n - 1]; h->pre_shift[k] = shift[k < n ? k : n - 1]; }
     drop_graph(h);
     return LA_OK;
 }
@@ -296,7 +305,7 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
                 const int N = h->imgc * B;
                 const long FF = h->F;
                 if (c.w_pix == 0.f && !use_disc) LA_HIP(hipMemsetAsync(h->g_img, 0, sizeof(float) * (size_t)B * h->imgc * h->R * h->R, st));
-                if ((rc = la_crop_repeat_ex(img, h->l_xc, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, h->crop_dev, 3, h->pre_scale, h->pre_shift, st))) return rc;
+                if ((rc = la_crop_repeat_ex3(img, h->l_xc, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, h->crop_dev, 3, h->pre_scale, h->pre_shift, st))) return rc;
                 if ((rc = la_feat_forward(h->f, h->l_xc, N, h->l_feat, st))) return rc;
                 if (L) {
                     for (int ch = 0; ch < h->imgc; ++ch)
@@ -308,7 +317,7 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
                 hipLaunchKernelGGL(la_lpips_gfeat_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, st, h->l_feat, h->l_colsum, h->l_gfeat,
                                    B, (int)FF, -2.f * lp_coef, (float)h->Mf, total);
                 if ((rc = la_feat_backward(h->f, h->l_gfeat, h->l_gxc, st))) return rc;
-                if ((rc = la_crop_repeat_grad_ex(h->l_gxc, h->g_img, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, h->crop_dev, 3, h->pre_scale, st)))
+                if ((rc = la_crop_repeat_grad_ex3(h->l_gxc, h->g_img, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, h->crop_dev, 3, h->pre_scale, st)))
                     return rc;
             }
             if ((rc = la_synth_backward(h->g, h->g_img, h->dws, st))) return rc;

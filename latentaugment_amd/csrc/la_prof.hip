@@ -15,6 +15,16 @@ static struct {
     unsigned seq;            // all bracketable launches seen since la_prof_begin
 } g_prof;
 
+// dev knobs: kernel-variant selectors so that two variants can be timed in interleaved rounds of ONE process (cdna_hip_programming.md
+// rule 24).  Every knob defaults to 0 = the shipped configuration.
+static int g_knob[LA_NKNOB];
+int la_dev_knob(int id) { return id >= 0 && id < LA_NKNOB ? g_knob[id] : 0; }
+extern "C" int la_dev_knob_set(int id, int value) {
+    LA_CHECK_ARG(id >= 0 && id < LA_NKNOB, "dev_knob_set: unknown knob");
+    g_knob[id] = value;
+    return LA_OK;
+}
+
 extern "C" int la_prof_set_stride(int stride) {
     LA_CHECK_ARG(stride >= 1 && stride <= 64, "prof: stride must be 1..64");
     g_prof.stride = stride;

@@ -460,14 +460,17 @@ __global__ __launch_bounds__(256) void la_rows_sum_inplace_kernel(float* __restr
     if (r < rows0) { row = a0 + r * n0; n = n0; }
     else if (r - rows0 < rows1) { row = a1 + (r - rows0) * n1; n = n1; }
     else return;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    // The per-tile partials of a row (up to 8192 of them at 1024^2) are summed in float64: they are tiny next to the contraction
+    // that produced them, and against a smooth image gradient the sum is much smaller than its terms -- a float32 sum of the
+    // partials was the part of the style-gradient noise at 1024^2 that is NOT inherent in forming the data gradient first.
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
     int k = lane;
-    for (; k + 192 < n; k += 256) { v0 += row[k]; v1 += row[k + 64]; v2 += row[k + 128]; v3 += row[k + 192]; }
-    for (; k < n; k += 64) v0 += row[k];
-    float v = (v0 + v1) + (v2 + v3);
+    for (; k + 192 < n; k += 256) { v0 += (double)row[k]; v1 += (double)row[k + 64]; v2 += (double)row[k + 128]; v3 += (double)row[k + 192]; }
+    for (; k < n; k += 64) v0 += (double)row[k];
+    double v = (v0 + v1) + (v2 + v3);
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft, 64);
-    if (lane == 0) row[0] = v;
+    if (lane == 0) row[0] = (float)v;
 }
 
 __global__ __launch_bounds__(256) void la_style_bwd_conv_kernel(const float* __restrict__ ds_part, int ntiles,
@@ -538,14 +541,17 @@ __global__ __launch_bounds__(256) void la_rows_sum_all_kernel(LaRowSegs g) {
     }
     const int n = g.n[sg];
     float* row = g.ptr[sg] + (r - g.row0[sg]) * n;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    // The per-tile partials of a row (up to 8192 of them at 1024^2) are summed in float64: they are tiny next to the contraction
+    // that produced them, and against a smooth image gradient the sum is much smaller than its terms -- a float32 sum of the
+    // partials was the part of the style-gradient noise at 1024^2 that is NOT inherent in forming the data gradient first.
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
     int k = lane;
-    for (; k + 192 < n; k += 256) { v0 += row[k]; v1 += row[k + 64]; v2 += row[k + 128]; v3 += row[k + 192]; }
-    for (; k < n; k += 64) v0 += row[k];
-    float v = (v0 + v1) + (v2 + v3);
+    for (; k + 192 < n; k += 256) { v0 += (double)row[k]; v1 += (double)row[k + 64]; v2 += (double)row[k + 128]; v3 += (double)row[k + 192]; }
+    for (; k < n; k += 64) v0 += (double)row[k];
+    double v = (v0 + v1) + (v2 + v3);
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft, 64);
-    if (lane == 0) row[0] = v;
+    if (lane == 0) row[0] = (float)v;
 }
 
 __global__ __launch_bounds__(256) void la_style_bwd_conv_all_kernel(LaStyleFinish f) {

@@ -55,6 +55,15 @@ def write_png_gray(path, a):
                 chunk(b'IEND', b''))
 
 
+def _preproc3(p):
+    """opt.lpips_preproc -> ((s0, s1, s2), (b0, b1, b2)): a scalar pair applies to all three repeated channels."""
+    scale, shift = p
+    scale = tuple(float(v) for v in scale) if hasattr(scale, '__len__') else (float(scale),) * 3
+    shift = tuple(float(v) for v in shift) if hasattr(shift, '__len__') else (float(shift),) * 3
+    assert len(scale) == 3 and len(shift) == 3
+    return scale, shift
+
+
 def shard_bounds(batch, world_size, rank):
     """Contiguous sample range of a rank: [rank*b, (rank+1)*b) with b = ceil(batch / world_size)."""
     per = (batch + world_size - 1) // world_size
@@ -132,11 +141,19 @@ class LatentAug:
         # (3 fp16 MFMAs per product, fp32 accumulate); 'bf16x3' = 3 bf16 terms (6 MFMAs, no range scaling needed).  Both pass
         # every fp32 parity test at unchanged tolerances.  'f32' = exact fp32 MFMA; 'bf16x2' approximate.
         self.precision = getattr(opt, 'precision', 'f16x2')
+        self._script_path = None
         if self.w_lpips > 0 and feature_net is None:
-            raise NotImplementedError(
-                'w_lpips > 0 needs `feature_net=` (op list for synthesis.FeatureEngine, e.g. vgg16_lpips_ops(...)) and '
-                "banks['fea']: the NVIDIA vgg16.pt / LPIPS weights the reference downloads (util_latent_aug.py:36) are not "
-                'obtainable offline')
+            # the reference's default perceptual net (`lpips_script`): NVIDIA's TorchScript vgg16.pt, fetched from a URL by load_vgg()
+            # (:35-43).  There is no network here: a LOCAL copy is accepted at opt.lpips_script_path or <model_dir>/vgg16.pt.
+            cands = [getattr(opt, 'lpips_script_path', None)]
+            if getattr(opt, 'lpips_script', 'lpips_script') == 'lpips_script' and getattr(opt, 'model_dir', None):
+                cands.append(os.path.join(opt.model_dir, 'vgg16.pt'))
+            self._script_path = next((c for c in cands if c and os.path.isfile(c)), None)
+            if self._script_path is None:
+                raise NotImplementedError(
+                    'w_lpips > 0 needs `feature_net=` (op list for synthesis.FeatureEngine, e.g. vgg16_lpips_ops(...)) or a local copy '
+                    "of NVIDIA's TorchScript vgg16.pt at opt.lpips_script_path / <model_dir>/vgg16.pt (the reference downloads it, "
+                    "util_latent_aug.py:36; there is no network here), and banks['fea'] or the interim image zip to build them from")
         if generator is None:
             # load_stylegan (reference :466-484): <model_dir>/<dataset>/training-runs/<dataset_name>/<modalities>/<exp>/<pkl>
             from . import formats
@@ -239,8 +256,16 @@ class LatentAug:
         if self.w_lpips > 0:
             # perceptual criterion (reference :160-171, :387-409): features of crop_size_aug^2 crops, one bank per modality
             imgc = self.engine.img_channels
-            self.feat = FeatureEngine(feature_net, self.device, in_res=self.crop_size, max_batch=imgc * max_local,
-                                      precision=self.precision)
+            if feature_net is not None:
+                self.feat = FeatureEngine(feature_net, self.device, in_res=self.crop_size, max_batch=imgc * max_local,
+                                          precision=self.precision)
+            else:
+                print(f'Loading VGG16 from: {self._script_path}')
+                self.feat = FeatureEngine.from_torchscript(self._script_path, self.device, in_res=self.crop_size,
+                                                           max_batch=imgc * max_local, precision=self.precision)
+                if not hasattr(opt, 'lpips_preproc'):
+                    # the script's own input layer, (x - mean_k) / std_k; the reference hands it the synthesised crop as it is (:394-395)
+                    opt.lpips_preproc = (self.feat.pre_scale, self.feat.pre_shift)
             if 'fea' not in banks:
                 if not (getattr(opt, 'interim_dir', None) and getattr(opt, 'dataset_aug', None)):
                     raise _lib.LatentAugHipError("w_lpips > 0 needs banks['fea'] or the interim image zip to build them from")
@@ -250,11 +275,13 @@ class LatentAug:
             self.Fbank = torch.stack([t.to(device=self.device, dtype=torch.float32) for t in fea]).contiguous()   # [C][Mf][F]
             assert self.Fbank.shape[2] == self.feat.num_features, 'feature bank does not match the feature net'
             Mf = self.Fbank.shape[1]
-            scale, shift = getattr(opt, 'lpips_preproc', (1.0, 0.0))
+            scale, shift = _preproc3(getattr(opt, 'lpips_preproc', (1.0, 0.0)))
             nb = lib.la_latent_opt_lpips_workspace_bytes(imgc, self.feat.num_features, self.crop_size, Mf, max_local)
             self._lpips_ws = torch.empty([nb], dtype=torch.uint8, device=self.device)
-            _lib.check(lib.la_latent_opt_set_lpips(h, self.feat.handle, _lib.ptr(self.Fbank), Mf, self.crop_size, float(scale),
-                                                   float(shift), _lib.ptr(self._lpips_ws), nb), 'la_latent_opt_set_lpips')
+            _lib.check(lib.la_latent_opt_set_lpips(h, self.feat.handle, _lib.ptr(self.Fbank), Mf, self.crop_size, float(scale[0]),
+                                                   float(shift[0]), _lib.ptr(self._lpips_ws), nb), 'la_latent_opt_set_lpips')
+            _lib.check(lib.la_latent_opt_set_lpips_preproc(h, (C.c_float * 3)(*scale), (C.c_float * 3)(*shift), 3),
+                       'la_latent_opt_set_lpips_preproc')
 
     def _build_feature_banks(self, opt):
         """fea_<mode> banks (reference :160-171 / extract_features_mode_torchscript :565-580): per real image and modality,
@@ -266,7 +293,9 @@ class LatentAug:
         ds = formats.ImgDataset(os.path.join(root, opt.dataset_name_aug + '.zip'), split=self.phase, modalities=self.modalities,
                                 resolution=self.res)
         raw = getattr(opt, 'lpips_bank_range', 'unit') == 'raw'
-        scale, shift = getattr(opt, 'lpips_preproc', (1.0, 0.0))
+        scale, shift = _preproc3(getattr(opt, 'lpips_preproc', (1.0, 0.0)))
+        sc_t = torch.tensor(scale, device=self.device).reshape(1, 3, 1, 1)
+        sh_t = torch.tensor(shift, device=self.device).reshape(1, 3, 1, 1)
         out = []
         for mode_id, mode in enumerate(self.modalities):
             def feature_fn(x, mode_id=mode_id):
@@ -274,14 +303,16 @@ class LatentAug:
                 if not raw:
                     t = t / 127.5 - 1
                 ax, ay = self.crop_window(get_params(self.res, self.crop_size, self.preprocess)['crop_pos'])
-                t = t[:, :, ay:ay + self.crop_size, ax:ax + self.crop_size].repeat(1, 3, 1, 1) * scale + shift   # plumbing
+                t = t[:, :, ay:ay + self.crop_size, ax:ax + self.crop_size].repeat(1, 3, 1, 1) * sc_t + sh_t   # plumbing
                 return self.feat.forward(t.contiguous()).cpu().numpy()
             # The reference names the cache '<mode>-<crop>-features_jit-...': its contents also depend on the input range, the
             # preprocess and the feature-net weights, so those are folded into the tag -- a cache written by the reference (raw
             # 0..255 inputs, NVIDIA's weights) or under other settings is never picked up silently.
             tag = f'{mode}-{self.crop_size}'
-            if not (raw and (scale, shift) == (1.0, 0.0) and getattr(opt, 'lpips_cache_compat', False)):
-                tag += f"-{'raw' if raw else 'unit'}-s{scale:g}-b{shift:g}-w{self.feat.weights_digest}"
+            if not (raw and (scale, shift) == ((1.0,) * 3, (0.0,) * 3) and getattr(opt, 'lpips_cache_compat', False)):
+                def fmt(v):
+                    return f'{v[0]:g}' if v[0] == v[1] == v[2] else '_'.join(f'{t:g}' for t in v)
+                tag += f"-{'raw' if raw else 'unit'}-s{fmt(scale)}-b{fmt(shift)}-w{self.feat.weights_digest}"
             st = formats.compute_stats(ds, 'features_jit', os.path.join(root, 'cache_dir'), cache_tag=tag,
                                        step=opt.step_img, feature_fn=feature_fn)
             out.append(st.get_all_torch())

@@ -410,6 +410,41 @@ class FeatureEngine:
         self.num_features = lib.la_feat_num_features(h)
         _lib.check(lib.la_feat_set_precision(h, PRECISIONS[precision]), 'la_feat_set_precision')
 
+    @classmethod
+    def from_torchscript(cls, src, device, in_res, max_batch, precision='f32', probe_seed=0, rtol=2e-3):
+        """Engine for a local TorchScript `vgg16.pt` (reference: util_latent_aug.py:35-43, call :394-395).  Every candidate mapping of
+        `vgg16_from_torchscript` is checked ONCE, at load time, against the module's own
+        `module(x, resize_images=False, return_lpips=True)` on a small probe batch (the scripted module runs on the host for this
+        check only; the criterion itself never calls it); the first one that agrees is kept together with its input affine
+        (`engine.pre_scale`, `engine.pre_shift`), otherwise loading fails loudly."""
+        cands = vgg16_from_torchscript(src)
+        g = torch.Generator().manual_seed(probe_seed)
+        probe = torch.rand([2, 1, in_res, in_res], generator=g).repeat(1, 3, 1, 1) * 255.0      # the 0..255 range the script is written for
+        with torch.no_grad():
+            try:
+                want = cands[0].source(probe, resize_images=False, return_lpips=True)
+            except (RuntimeError, TypeError):
+                want = cands[0].source(probe)
+        want = want.reshape(2, -1).to(torch.float32)
+        errs = []
+        for c in cands:
+            eng = cls(c.ops, device, in_res, max_batch=max(max_batch, 2), precision='f32')
+            if eng.num_features != want.shape[1]:
+                errs.append(float('inf'))
+                continue
+            x = probe * torch.tensor(c.pre_scale).reshape(1, 3, 1, 1) + torch.tensor(c.pre_shift).reshape(1, 3, 1, 1)      # plumbing
+            got = eng.forward(x.to(eng.device)).cpu()
+            err = float((got - want).norm() / want.norm().clamp_min(1e-30))
+            errs.append(err)
+            if err <= rtol:
+                if precision != 'f32' or max_batch != eng.max_batch:
+                    eng = cls(c.ops, device, in_res, max_batch=max_batch, precision=precision)
+                eng.pre_scale, eng.pre_shift, eng.lin_is_sqrt = c.pre_scale, c.pre_shift, c.lin_is_sqrt
+                return eng
+            del eng
+        raise _lib.LatentAugHipError('TorchScript feature net: no mapping of its tensors onto the VGG16-LPIPS op list reproduces the '
+                                     f"module's own output (relative errors of the candidates: {errs}); refusing to guess")
+
     def __del__(self):
         h = getattr(self, '_h', None)
         if h:
@@ -453,3 +488,97 @@ def vgg16_lpips_ops(state_dict, lins):
         if i in pool_after:
             ops.append(('maxpool',))
     return ops
+
+
+# ------------------------------------------------------------------------------------------------------------
+# A local copy of the reference's default perceptual net: NVIDIA's TorchScript `vgg16.pt` (util_latent_aug.py:35-43 loads it
+# with torch.jit.load from a URL; :394-395 calls it as vgg16(x, resize_images=False, return_lpips=True)).
+class ScriptedFeatureNet:
+    """What `vgg16_from_torchscript` extracts: the FeatureEngine op list plus the module's own input layer as a per-channel
+    affine (`pre_scale`, `pre_shift`: x_k * scale_k + shift_k on the three repeated channels)."""
+
+    def __init__(self, ops, pre_scale, pre_shift, lin_is_sqrt, source):
+        self.ops, self.pre_scale, self.pre_shift, self.lin_is_sqrt, self.source = ops, pre_scale, pre_shift, lin_is_sqrt, source
+
+
+def _script_tensors(module):
+    sd = module.state_dict()
+    return [(k, v.detach().to('cpu', torch.float32)) for k, v in sd.items() if torch.is_tensor(v) and v.is_floating_point()]
+
+
+def vgg16_from_torchscript(src, map_location='cpu'):
+    """Parameter tensors of a TorchScript VGG16-LPIPS module -> candidate `ScriptedFeatureNet`s.
+
+    `src`: path / file object for torch.jit.load, or an already loaded ScriptModule.  The archive holds no Python source we
+    could read names from, so the layout is recognised from the tensors themselves, in state_dict order:
+      * the 3x3 convolutions: every 4-D [Co, Ci, 3, 3] tensor (13 of them, Ci of the first = 3) with the [Co] vector that follows
+        it (or `<name>.bias`);
+      * the five LPIPS channel weights: tensors with exactly C = 64, 128, 256, 512, 512 x (width / 64) elements that are not biases;
+      * the input layer: 3-element tensors named *mean* / *shift* and *std* / *scale*  ->  (x - mean_k) / std_k.
+    Two things cannot be read from the tensors: whether the stored channel weights are the lin weights or their square roots, and
+    whether an input layer without buffers is hard-coded in the script.  The function therefore returns the candidates (at most
+    four) and `FeatureEngine.from_torchscript` keeps the one that reproduces the module's OWN output on a probe batch; if none
+    does, loading fails -- a mapping is never trusted unverified."""
+    module = src if isinstance(src, torch.jit.ScriptModule) else torch.jit.load(src, map_location=map_location)
+    module = module.eval()
+    items = _script_tensors(module)
+    convs, used = [], set()
+    for idx, (k, v) in enumerate(items):
+        if v.ndim == 4 and v.shape[2:] == (3, 3):
+            bias = None
+            cand = k[:-len('weight')] + 'bias' if k.endswith('weight') else None
+            for j, (kj, vj) in enumerate(items):
+                if j in used or vj.ndim != 1 or vj.shape[0] != v.shape[0]:
+                    continue
+                if (cand is not None and kj == cand) or (cand is None and j == idx + 1):
+                    bias, _ = vj, used.add(j)
+                    break
+            if bias is None and idx + 1 < len(items) and items[idx + 1][1].ndim == 1 and items[idx + 1][1].shape[0] == v.shape[0]:
+                bias = items[idx + 1][1]
+                used.add(idx + 1)
+            if bias is None:
+                bias = torch.zeros([v.shape[0]])
+            used.add(idx)
+            convs.append((v, bias))
+    if len(convs) != 13 or convs[0][0].shape[1] != 3:
+        raise _lib.LatentAugHipError(f'TorchScript feature net: expected the 13 3x3 convolutions of VGG16 (first one on 3 channels), found '
+                                     f'{len(convs)}: not a vgg16.pt layout')
+    tap_convs = [1, 3, 6, 9, 12]                      # relu1_2, 2_2, 3_3, 4_3, 5_3
+    want = [convs[i][0].shape[0] for i in tap_convs]
+    lins, k = [], 0
+    for idx, (name, v) in enumerate(items):
+        if idx in used or k >= 5 or name.endswith('bias'):
+            continue
+        if v.numel() == want[k] and max(v.shape) == want[k] and float(v.min()) >= 0.0:
+            lins.append(v.reshape(-1))
+            used.add(idx)
+            k += 1
+    if len(lins) != 5:
+        raise _lib.LatentAugHipError(f'TorchScript feature net: found {len(lins)} of the 5 LPIPS channel-weight tensors {want}')
+    mean = std = None
+    for idx, (name, v) in enumerate(items):
+        if idx in used or v.numel() != 3:
+            continue
+        low = name.lower()
+        if mean is None and ('mean' in low or 'shift' in low):
+            mean = v.reshape(3)
+        elif std is None and ('std' in low or 'scale' in low):
+            std = v.reshape(3)
+    pres = [((1.0, 1.0, 1.0), (0.0, 0.0, 0.0))]
+    if mean is not None or std is not None:
+        m = mean if mean is not None else torch.zeros(3)
+        sd_ = std if std is not None else torch.ones(3)
+        pres.insert(0, (tuple(float(1.0 / t) for t in sd_), tuple(float(-a / t) for a, t in zip(m, sd_))))
+    out = []
+    for pre_scale, pre_shift in pres:
+        for lin_is_sqrt in (False, True):
+            ops = []
+            for i, (w, b) in enumerate(convs):
+                ops.append(('conv', w, b))
+                if i in tap_convs:
+                    ln = lins[tap_convs.index(i)]
+                    ops.append(('tap', ln.square() if lin_is_sqrt else ln))
+                    if i != tap_convs[-1]:
+                        ops.append(('maxpool',))
+            out.append(ScriptedFeatureNet(ops, pre_scale, pre_shift, lin_is_sqrt, module))
+    return out

@@ -24,6 +24,10 @@ def main():
     ap.add_argument('--up', action='store_true')
     ap.add_argument('--bwd', action='store_true')
     ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--ab', type=int, default=-1, help='dev knob id (la_dev_knob_set): time knob=0 against knob=1 in interleaved rounds of this process')
+    ap.add_argument('--rounds', type=int, default=7)
+    ap.add_argument('--va', type=int, default=0, help='knob value of arm A')
+    ap.add_argument('--vb', type=int, default=1, help='knob value of arm B')
     a = ap.parse_args()
     lib = _lib.load()
     dev = torch.device('cuda:0')
@@ -74,6 +78,32 @@ def main():
                                            cout, res, st)
         _lib.check(rc, 'layer')
 
+    if a.ab >= 0:
+        # interleaved A/B in one process (cdna_hip_programming.md rule 24): median and minimum of the per-round averages, and the
+        # largest difference of the two variants' outputs
+        outs, times = {}, {a.va: [], a.vb: []}
+        for v in (a.va, a.vb):
+            _lib.check(lib.la_dev_knob_set(a.ab, v))
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            outs[v] = (gx if a.bwd else y).clone()
+        dmax = float((outs[a.va] - outs[a.vb]).abs().max()) / float(outs[a.va].abs().max())
+        for _ in range(a.rounds):
+            for v in (a.va, a.vb):
+                _lib.check(lib.la_dev_knob_set(a.ab, v))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                times[v].append(e0.elapsed_time(e1) / a.iters * 1e3)
+        _lib.check(lib.la_dev_knob_set(a.ab, 0))
+        m0, m1 = float(np.median(times[a.va])), float(np.median(times[a.vb]))
+        print(f'res {res} {cin}->{cout} B{B} up={a.up} bwd={a.bwd} knob {a.ab}: {a.va} -> median {m0:.1f} min {min(times[a.va]):.1f} us | '
+              f'{a.vb} -> median {m1:.1f} min {min(times[a.vb]):.1f} us | ratio {m1 / m0:.3f} | max |out0 - out1| / max |out0| = {dmax:.2e}', flush=True)
+        return
     for _ in range(3):
         run()
     torch.cuda.synchronize()

@@ -67,12 +67,63 @@ def _run_case(name, dev, precision='f16x2'):
     random.seed(CROP_SEED)
     pos = get_params(c['res'], CROP)['crop_pos']
     assert tuple(pos) == tuple(int(v) for v in fx['crop_pos'])          # same draw as the reference's get_params
-    img, w_aug, losses = la.run_local(w0.to(dev), want_losses=True, crop_pos=pos)
+    trace = {'want': ('w', 'grad')}
+    img, w_aug, losses = la.run_local(w0.to(dev), want_losses=True, crop_pos=pos, trace=trace)
     torch.cuda.synchronize()
     w = w_aug[:, 0].cpu().numpy()
     assert float((w_aug - w_aug[:, :1]).abs().max()) == 0.0            # W space: every ws row is the optimised w
     isub = subsample(img.cpu(), c['res']).numpy()
+    _check_steps(name, c, fx, trace['w'].cpu().numpy(), trace['grad'].cpu().numpy(), STEP_SLACK[name])
     return c, fx, w0, w, isub, img.cpu(), losses.cpu().numpy()
+
+
+# slack of the per-step / gradient checks per config (the final-state checks take theirs from the test functions below)
+D_SLACK = 1.5
+STEP_SLACK = {'B': 1.5, 'C': 1.5, 'D': D_SLACK, 'E': 2.0}
+
+
+def _check_steps(name, c, fx, w_steps, g_steps, slack):
+    """(a) The gradient dL/dw of the FIRST step against float64: evaluated at the common start latent, before Adam's sign-like first
+    step hides magnitudes -- pins G backward, every criterion and (config E) D + feature-net backward at full size.  Bound: no
+    noisier than `slack` x the reference's own float32 gradient (both measured against float64), plus a per-entry float32 net.
+    (b) The latent after EVERY step against the float64 trajectory: HIP's error stays within `slack` x the error of the reference's
+    float32 run at that step -- the drift-versus-step curve is observed over the whole loop, not extrapolated from its end."""
+    g64, g32 = fx['o64_grad1'], fx['ref32_grad1']
+    g = g_steps[0].astype(np.float64)
+    gmax = float(np.abs(g64).max())
+    e_h, e_r = np.abs(g - g64), np.abs(g32.astype(np.float64) - g64)
+    print(f'[{name}] dL/dw step 1 (max |g| {gmax:.3e}): HIP vs o64 max {e_h.max():.3e} rms {np.sqrt((e_h ** 2).mean()):.3e};  '
+          f'reference fp32 vs o64 max {e_r.max():.3e} rms {np.sqrt((e_r ** 2).mean()):.3e}')
+    # no noisier than the reference's own float32 gradient (rms at `slack`, the worst entry at twice that), and every entry inside a
+    # plain float32 net (the reference's worst entry on config B sits at 2.6e-5 of max |g|)
+    assert np.sqrt((e_h ** 2).mean()) <= slack * np.sqrt((e_r ** 2).mean()) + 1e-7 * gmax
+    assert e_h.max() <= 2 * slack * e_r.max() + 1e-6 * gmax, (e_h.max(), e_r.max())
+    assert np.all(e_h <= 1e-3 * np.abs(g64) + 1e-4 * gmax), float((e_h - 1e-3 * np.abs(g64)).max() / gmax)
+    o64, r32 = fx['o64_w_steps'].astype(np.float64), fx['ref32_w_steps'].astype(np.float64)
+    assert w_steps.shape == o64.shape == r32.shape == (c['steps'], c['batch'], 512)
+    # Statistic per step: the rms over the BULK of the entries -- all but the k = 0.3 % largest errors of each run.  In the first
+    # steps, where the bulk is still at 1e-6, a single gradient component next to a zero crossing that Adam steps the other way puts
+    # 2e-4 into one entry and triples the plain rms (seen on config C, step 2: one entry of 2048); which run that happens to is
+    # chance.  Those entries are bounded separately: the largest error at every step stays within 2 * slack of the reference's
+    # largest or within two Adam steps of 1e-2, and the plain rms, 99.9th percentile and maximum of the FINAL latent are asserted
+    # at `slack` in _check.
+    n = w_steps[0].size
+    k = max(2, int(np.ceil(0.003 * n)))
+
+    def bulk_rms(e):
+        return float(np.sqrt((np.sort(e.ravel())[:n - k] ** 2).mean()))
+    rows = []
+    for s in range(c['steps']):
+        eh, er = np.abs(w_steps[s] - o64[s]), np.abs(r32[s] - o64[s])
+        rows.append((bulk_rms(eh), bulk_rms(er), np.sqrt((eh ** 2).mean()), np.sqrt((er ** 2).mean()), eh.max(), er.max()))
+    rows = np.array(rows)
+    print(f'[{name}] latent error vs o64 per step, bulk rms (all but the {k} largest of {n}) HIP / reference fp32: ' +
+          ' '.join(f'{r[0]:.1e}/{r[1]:.1e}' for r in rows))
+    print(f'[{name}] ... plain rms HIP / reference fp32: ' + ' '.join(f'{r[2]:.1e}/{r[3]:.1e}' for r in rows))
+    # (o64_w_steps is stored in float32: 6e-8 relative on |w| ~ 1..4 is the floor of both error columns)
+    floor = 3e-7
+    assert np.all(rows[:, 0] <= slack * rows[:, 1] + floor), (rows[:, 0] / (rows[:, 1] + floor)).max()
+    assert np.all(rows[:, 4] <= np.maximum(2 * slack * rows[:, 5] + 10 * floor, 0.02)), (rows[:, 4] / (rows[:, 5] + floor)).max()
 
 
 def _check(name, c, fx, w0, w, isub, img, losses, slack=1.5):
@@ -130,26 +181,25 @@ def test_config_b_bench_workload_vs_reference(dev):
 
 
 def test_config_c_512_loop_vs_reference(dev):
-    """configs[2] per-GPU shape: config-f 512^2, B=4, 5-step loop."""
+    """configs[2] per-GPU shape: config-f 512^2, B=4, the full 20-step loop."""
     _check('C', *_run_case('C', dev))
 
 
 def test_config_d_1024_loop_vs_reference(dev):
-    """configs[3] per-GPU shape: config-f 1024^2, B=2, 3-step loop with the default f16x2 contraction (32-row halo tiles of
-    the 32-channel layers included).
+    """configs[3] per-GPU shape: config-f 1024^2, B=2, banks M_w=1024 / M_x=256, 10 steps of the 50-step loop (a float64 CPU run of
+    all 50 at 1024^2 takes hours; the per-step check above shows the error ratio over the steps that are run) with the default
+    f16x2 contraction (32-row halo tiles of the 32-channel layers included).
 
-    Slack 3 instead of 1.5 (measured 2.3, identical for the exact-fp32 MFMA mode, so it is not the split arithmetic):
-    the style gradient is formed here as  sum_p x[p] * (W^T * gz)[p]  (data gradient first, 2x forward FLOPs per step) where the
+    The style gradient is formed here as  sum_p x[p] * (W^T * gz)[p]  (data gradient first, 2x forward FLOPs per step) where the
     reference forms  sum_{o,k} W * (sum_p gz[p] x[p+k])  (weight gradient first, 3x).  Both are exact in real arithmetic; in
-    float32 the first rounds every pixel's K-term dot product before the million-pixel sum, and against the smooth image
-    gradient of the pixel criterion that is ~2x noisier at 1024^2 (scripts/diag_grad1024.py; equal at 256^2 and 512^2, where the
-    1.5 bound holds).  In absolute terms: 3.5e-6 on the latent after three steps of 1e-2."""
-    _check('D', *_run_case('D', dev), slack=3.0)
+    float32 the first rounds every pixel's K-term dot product before the million-pixel sum.  Since round 3 the per-tile partials
+    of that sum (8192 per row at 1024^2) are accumulated in float64 (la_rows_sum_*_kernel)."""
+    _check('D', *_run_case('D', dev), slack=D_SLACK)
 
 
 def test_config_e_all_criteria_pelvis_scale_vs_reference(dev):
     """configs[4] per-GPU shape: config-e 256^2, B=8, all four criteria at the authors' weights, banks M_w=6026 / M_x=1572,
-    VGG16-topology LPIPS net at full width on 64^2 crops (F = 499712 per image), discriminator at 256^2, 5 steps.
+    VGG16-topology LPIPS net at full width on 64^2 crops (F = 499712 per image), discriminator at 256^2, the full 20 steps.
 
     Slack 2 on the tail statistics (rms measured 1.08): with the discriminator's lrelu kinks and the ReLU / max-pool kinks of the
     VGG features in the loss, the trajectory is chaotic at this operating point -- the reference's OWN float32 run ends a third

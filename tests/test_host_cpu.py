@@ -154,3 +154,32 @@ def test_shard_gather_gloo_world2(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert 'ok' in o
+
+
+def test_torchscript_vgg16_mapping(tmp_path):
+    """A local TorchScript `vgg16.pt` (the reference torch.jit.load()s NVIDIA's from a URL, util_latent_aug.py:35-43, and calls it
+    with resize_images=False, return_lpips=True, :395): the loader recognises the 13 convolutions, the five LPIPS channel weights
+    and the input layer from the tensors of a synthetic scripted module, and exactly ONE of its candidates reproduces the module's
+    own output -- which one depends on whether the script stores the lin weights or their square roots, so nothing is assumed."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers_script import eval_ops_cpu, save_scripted_vgg
+    from latentaugment_amd import _lib
+    from latentaugment_amd.synthesis import vgg16_from_torchscript
+    for lin_sqrt in (False, True):
+        path = tmp_path / f'vgg16_{int(lin_sqrt)}.pt'
+        save_scripted_vgg(path, width=8, seed=3, lin_sqrt=lin_sqrt)
+        cands = vgg16_from_torchscript(str(path))
+        assert [op[0] for op in cands[0].ops].count('conv') == 13 and [op[0] for op in cands[0].ops].count('tap') == 5
+        assert [op[0] for op in cands[0].ops].count('maxpool') == 4
+        assert abs(cands[0].pre_scale[0] - 1 / 58.395) < 1e-7 and abs(cands[0].pre_shift[2] + 103.53 / 57.375) < 1e-5
+        x = torch.rand([2, 1, 32, 32], generator=torch.Generator().manual_seed(1)).repeat(1, 3, 1, 1) * 255
+        want = torch.jit.load(str(path))(x, resize_images=False, return_lpips=True)
+        good = []
+        for c in cands:
+            xx = x * torch.tensor(c.pre_scale).reshape(1, 3, 1, 1) + torch.tensor(c.pre_shift).reshape(1, 3, 1, 1)
+            good.append(float((eval_ops_cpu(c.ops, xx) - want).norm() / want.norm()) < 1e-5)
+        assert good.count(True) == 1 and cands[good.index(True)].lin_is_sqrt == lin_sqrt
+    # a scripted module that is not a VGG16 is refused
+    m = torch.jit.script(torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1)))
+    with pytest.raises(_lib.LatentAugHipError):
+        vgg16_from_torchscript(m)
