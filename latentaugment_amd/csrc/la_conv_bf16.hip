@@ -26,22 +26,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // FMT template parameter of the kernels below
-#ifndef LA_ABLATE
-#define LA_ABLATE 0      // dev builds only (11..15): knock out one stage of the flat kernel step loop to time the rest
-#endif
-#ifndef LA_STAMP
-#define LA_STAMP 0
-#endif
-#ifndef LA_GATHER
-#define LA_GATHER 1      // fp16 flat kernel: 1 = lane-contiguous 16-byte pieces (8 lanes per pixel record), 0 = one pixel half-record per lane
-#endif
-// issue-order fences of the halo tap loop (dev builds can override LA_FENCES: bit 0 = A, bit 1 = B, bit 2 = C)
-#ifndef LA_FENCES
-#define LA_FENCES 2
-#endif
-#define LA_FENCE_A do { if (LA_FENCES & 1) __builtin_amdgcn_sched_barrier(0); } while (0)
-#define LA_FENCE_B do { if (LA_FENCES & 2) __builtin_amdgcn_sched_barrier(0); } while (0)
-#define LA_FENCE_C do { if (LA_FENCES & 4) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define FMT_BF16X3 3
 #define FMT_BF16X2 2
 #define FMT_F16X2 16
@@ -261,8 +245,9 @@ int la_conv_xscale_from_pmax(const float* pmax, int nseg, const float* scale, in
     return LA_OK;
 }
 
-// Pre-split copy for the flat kernel, CHANNEL-INTERLEAVED: q[b][chunk][pixel][32 channels] (4 B per element fp16 {h | l<<16},
-// 8 B bf16 {h | m<<16, l}; channels past C are zeros).  The flat kernel's gather thread (pixel, 16-channel half) then reads its
+// Pre-split copy for the flat kernel, CHANNEL-INTERLEAVED: q[b][chunk][pixel][32 channels]; fp16: a 128-byte record per (chunk, pixel) =
+// the h terms of the 32 channels (64 B) followed by their l terms (64 B), so that a 16-byte piece is one LDS slot of one term;
+// bf16: 8 B per element {h | m<<16, l}.  Channels past C are zeros.  The flat kernel's gather thread (pixel, 16-channel half) then reads its
 // operand as 64 / 128 contiguous bytes (4 / 8 dwordx4) instead of 16 strided dwords, and a stride-2 gather wastes no sectors.
 // One workgroup = 32 channels x 64 pixels, transposed through LDS.
 template <bool F16>
@@ -305,11 +290,15 @@ __global__ __launch_bounds__(256) void la_presplit_t_kernel(const float* __restr
         const long p = p0 + px;
         if (p < HW) {
             unsigned* op = out + (((long)b * nck + cc) * HW + p) * (KCB * EW) + qt * 8 * EW;
-            if (F16) {
-                uint4 w0 = make_uint4(tile[0][px][qt * 8 + 0], tile[0][px][qt * 8 + 1], tile[0][px][qt * 8 + 2], tile[0][px][qt * 8 + 3]);
-                uint4 w1 = make_uint4(tile[0][px][qt * 8 + 4], tile[0][px][qt * 8 + 5], tile[0][px][qt * 8 + 6], tile[0][px][qt * 8 + 7]);
-                reinterpret_cast<uint4*>(op)[0] = w0;
-                reinterpret_cast<uint4*>(op)[1] = w1;
+            if (F16) {      // record = [h of 32 channels | l of 32 channels]: this thread's 8 channels are slot qt of each half
+                unsigned e[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[k] = tile[0][px][qt * 8 + k];
+                uint4* rec = reinterpret_cast<uint4*>(out + (((long)b * nck + cc) * HW + p) * KCB);
+                rec[qt] = make_uint4(__builtin_amdgcn_perm(e[1], e[0], 0x05040100u), __builtin_amdgcn_perm(e[3], e[2], 0x05040100u),
+                                     __builtin_amdgcn_perm(e[5], e[4], 0x05040100u), __builtin_amdgcn_perm(e[7], e[6], 0x05040100u));
+                rec[4 + qt] = make_uint4(__builtin_amdgcn_perm(e[1], e[0], 0x07060302u), __builtin_amdgcn_perm(e[3], e[2], 0x07060302u),
+                                         __builtin_amdgcn_perm(e[5], e[4], 0x07060302u), __builtin_amdgcn_perm(e[7], e[6], 0x07060302u));
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -382,6 +371,7 @@ int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
     LA_CHECK_ARG(a.ws && a.ws_bytes >= qb, "conv: split precisions need a workspace (la_modconv_workspace_bytes)");
     LA_CHECK_ARG(((size_t)a.ws & 15) == 0, "conv: workspace must be 16-byte aligned");
     LA_CHECK_ARG(a.B <= 64, "conv: split precisions support at most 64 samples per launch");
+    LA_CHECK_ARG(qb < 0x7ff00000u, "conv: pre-split operand too large for 32-bit buffer offsets");
     char* base = static_cast<char*>(a.ws);
     const size_t ws_bytes = a.ws_bytes;
     const dim3 pgrid((unsigned)la_cdiv(HW, 64), (unsigned)la_cdiv(a.C, KCB), (unsigned)a.B);
@@ -406,17 +396,6 @@ int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-#if LA_STAMP
-// dev builds only: s_memtime stamps of wave 0 of the first 4096 workgroups (la_debug_stamps reads them back)
-#define LA_NSTAMP 48
-__device__ unsigned long long la_stamps[4096 * LA_NSTAMP];
-#define STAMP(k) do { if (lane == 0 && wid == 0 && sblk < 4096) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); la_stamps[sblk * LA_NSTAMP + (k)] = t_; } } while (0)
-extern "C" int la_debug_stamps(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(la_stamps), (size_t)n * sizeof(unsigned long long));
-}
-#else
-#define STAMP(k) do {} while (0)
-#endif
 // Flat variant: 128 consecutive grid positions per tile, any stride / tap table / ragged grid, optional split-K.
 //   * B (pixels): thread (pixel, 16-channel half) gathers the tap-shifted inputs of one (chunk, tap) step with 16
 //     unconditional buffer loads (clamped addresses; out-of-image pixels are zeroed on the way to LDS), one step ahead,
@@ -488,22 +467,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     const int gx_l = nvalid ? g_l - gy_l * a.Gx : 0;
     const int iy0 = gy_l * a.in_sy, ix0 = gx_l * a.in_sx;
     const unsigned HWin = (unsigned)(a.Hin * a.Win);
-    // fp16 pieces (LA_GATHER): load k of a thread is the 16-byte piece (4 channels) tid & 7 of pixel k * 32 + (tid >> 3), so that the
-    // 8 lanes of a pixel read its whole 128-byte record and a wave instruction touches 8 lines instead of 64
-    constexpr bool PIECES = (FMT == FMT_F16X2) && (LA_GATHER == 1);
-    int piy0[4], pix0[4]; unsigned pbase[4]; bool pvalid[4];
+    // fp16 pieces: load k of a thread is the 16-byte piece tid & 7 of the 128-byte record of pixel k * 32 + (tid >> 3) -- pieces 0-3 are
+    // the h terms of channels 0-7 / 8-15 / 16-23 / 24-31 of the chunk, pieces 4-7 their l terms (la_presplit_t_kernel, la_fir4x4_adj_pack) --
+    // so that the 8 lanes of a pixel read its whole record (a wave instruction touches 8 lines instead of 64) and a piece IS one 16-byte
+    // LDS slot of one term: no unpacking between the load and the LDS write.
+    // Pixel-stationary addressing (as the halo kernel's loader): the record offset of the un-shifted pixel and the set of taps that fall
+    // outside the image are computed ONCE per piece; per step the tap adds a scalar to the offset and an out-of-image tap turns it
+    // into an out-of-range buffer offset, which the hardware reads as zeros -- 3 vector instructions per piece and step (was ~25:
+    // clamps, comparisons, a 64-bit multiply-add and a select per value).
+    constexpr bool PIECES = FMT == FMT_F16X2;
+    constexpr unsigned OOB = 0x7ff00000u;          // >= every operand size (checked by la_conv_prepare_input)
+    unsigned plin[4] = {0u, 0u, 0u, 0u}, pinv[4] = {0u, 0u, 0u, 0u};
+    if constexpr (PIECES) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int n_k = k * 32 + (tid >> 3);
-        const int nidx = ntile * NT + n_k;
-        pvalid[k] = nidx < Ntot;
-        const int bb = SPLIT ? (pvalid[k] ? nidx / G : 0) : bz;
-        const int g = SPLIT ? nidx - bb * G : nidx;
-        const int gy = pvalid[k] ? g / a.Gx : 0, gx = pvalid[k] ? g - gy * a.Gx : 0;
-        piy0[k] = gy * a.in_sy; pix0[k] = gx * a.in_sx;
-        pbase[k] = (SPLIT ? (unsigned)bb * ((unsigned)((a.C + KCB - 1) / KCB) * KCB * HWin * 4u) : 0u) + (unsigned)(tid & 7) * 16u;
+        for (int k = 0; k < 4; ++k) {
+            const int n_k = k * 32 + (tid >> 3);
+            const int nidx = ntile * NT + n_k;
+            const bool pv = nidx < Ntot;
+            const int bb = SPLIT ? (pv ? nidx / G : 0) : bz;
+            const int g = SPLIT ? nidx - bb * G : nidx;
+            const int gy = pv ? g / a.Gx : 0, gx = pv ? g - gy * a.Gx : 0;
+            const int py = gy * a.in_sy, px = gx * a.in_sx;
+            const unsigned base = (SPLIT ? (unsigned)bb * ((unsigned)((a.C + KCB - 1) / KCB) * KCB * HWin * 4u) : 0u) + (unsigned)(tid & 7) * 16u;
+            plin[k] = base + (unsigned)(py * a.Win + px) * (unsigned)(KCB * EB);
+            unsigned m = 0u;
+#pragma unroll
+            for (int t = 0; t < LA_CONV_MAX_TAPS; ++t) {
+                const int iy = py + a.tap_dy[t], ix = px + a.tap_dx[t];
+                const bool bad = !pv || iy < 0 || iy >= a.Hin || ix < 0 || ix >= a.Win;
+                m |= (bad ? 1u : 0u) << t;
+            }
+            pinv[k] = m;
+        }
     }
-    bool pok[4] = {false, false, false, false};
 
     const int nck = (a.C + KCB - 1) / KCB;
     int ck_beg = 0, ck_end = nck;
@@ -541,13 +537,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     auto load_b = [&](int cc, int t) {
         if constexpr (PIECES) {
             const int dy = (int)((dypack >> (4 * t)) & 15u) - 8, dx = (int)((dxpack >> (4 * t)) & 15u) - 8;
+            const unsigned delta = (unsigned)((dy * a.Win + dx) * (KCB * EB));      // (scalar)
             const unsigned so = (unsigned)cc * HWin * (KCB * EB);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int iy = piy0[k] + dy, ix = pix0[k] + dx;
-                pok[k] = pvalid[k] && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-                const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, pbase[k] + (unsigned)(iyc * a.Win + ixc) * (KCB * EB), so, 0);
+                const int bad = __builtin_amdgcn_sbfe((int)pinv[k], (unsigned)t, 1u);      // -1: the tap is outside the image for this piece
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (plin[k] + delta) | ((unsigned)bad & OOB), so, 0);
                 ex[4 * k] = v.x; ex[4 * k + 1] = v.y; ex[4 * k + 2] = v.z; ex[4 * k + 3] = v.w;
             }
             return;
@@ -579,19 +574,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     };
     const int wrow = n_l * BPITCH, wsw = (n_l >> 2) & 3;
     auto write_b = [&](unsigned char* buf) {
-        if constexpr (PIECES) {
-            const int s = tid & 7;
+        if constexpr (PIECES) {      // piece (tid & 7) = slot (tid & 3) of term (tid >> 2 & 1); the tile row only adds k * 32 rows
+            unsigned char* p0 = buf + ((tid >> 2) & 1) * BPLANE + (tid >> 3) * BPITCH + ((((tid & 3) ^ (tid >> 5)) & 3) << 4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int n_k = k * 32 + (tid >> 3);
-                unsigned char* p = buf + n_k * BPITCH + (((((s >> 1) ^ (n_k >> 2)) & 3) << 4) | ((s & 1) << 3));
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const unsigned sel = q == 1 ? 0x07060302u : 0x05040100u;
-                    const unsigned w0 = __builtin_amdgcn_perm(ex[4 * k + 1], ex[4 * k], sel), w1 = __builtin_amdgcn_perm(ex[4 * k + 3], ex[4 * k + 2], sel);
-                    *reinterpret_cast<uint2*>(p + q * BPLANE) = pok[k] ? make_uint2(w0, w1) : make_uint2(0u, 0u);
-                }
-            }
+            for (int k = 0; k < 4; ++k)
+                *reinterpret_cast<uint4*>(p0 + k * 32 * BPITCH) = make_uint4(ex[4 * k], ex[4 * k + 1], ex[4 * k + 2], ex[4 * k + 3]);
             return;
         }
 #pragma unroll
@@ -666,27 +653,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             }
     };
 
-#if LA_STAMP
-    const int sblk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-#endif
-    STAMP(0);
     if constexpr (WV == 3) {
       if (nstep > 0) {
-        static_assert(WV != 3 || (FMT == FMT_F16X2 && LA_GATHER == 1), "the three-wave form exists for the fp16 pieces loader only");
+        static_assert(WV != 3 || (FMT == FMT_F16X2 ), "the three-wave form exists for the fp16 pieces loader only");
         int c1 = ck_beg, t1 = 0;
         auto adv = [&](int& c, int& t) {
             if (t + 1 < ntaps) ++t;
             else if (c + 1 < ck_end) { ++c; t = 0; }
         };
         bf16x8 acur[2][NTERM][TM], bf[NTERM][NJ];
-        load_b(c1, t1);
-        load_a(c1, t1, 0, acur[0]);
-        load_a(c1, t1, 1, acur[1]);
+        // Prologue in the loop's own issue order -- [pieces of the step after next | weights K-step 0 | weights K-step 1] are the
+        // youngest loads when an iteration starts, on the first entry as on the back edge -- so that the counted waits of the loop
+        // (pieces: all but the 4 weight loads; weights: per K-step) hold for both and never fall back to vmcnt(0): with the weights
+        // requested first, every step began by waiting for the weight fragments issued just before its barrier.
+        const int c0 = c1, t0 = t1;
+        load_b(c0, t0);
         adv(c1, t1);                                   // (c1, t1) = step 1
         int c2 = c1, t2 = t1;
         write_b(smem);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
         load_b(c1, t1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(c0, t0, 0, acur[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(c0, t0, 1, acur[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
         adv(c2, t2);                                   // (c2, t2) = step 2
 #pragma unroll 1
         for (int s = 0; s < nstep; ++s) {
@@ -739,7 +731,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         int c2 = c1, t2 = t1;
         write_b(smem);
         __syncthreads();
-        STAMP(1);
         load_b(c1, t1);
         adv(c2, t2);                                   // (c2, t2) = step 2
 #pragma unroll 1
@@ -747,22 +738,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             const unsigned char* cur = smem + (s & 1) * BBUF;
             unsigned char* nxt = smem + ((s + 1) & 1) * BBUF;
             // (the fences pin the issue order: left alone, the scheduler sinks every load to just before its first use)
-#if LA_ABLATE == 13
-            if (s == 0) { read_b(cur, 0, bf0); read_b(cur, 1, bf1); }
-#else
             read_b(cur, 0, bf0);
             read_b(cur, 1, bf1);
-#endif
-#if LA_ABLATE != 12
             write_b(nxt);                              // step s+1 (loaded during step s-1)
-#endif
-#if LA_ABLATE != 11
             load_b(c2, t2);                            // step s+2
-#endif
-#if LA_ABLATE != 14
             load_a(c1, t1, 0, anxt[0]);                // weights of step s+1: a full step ahead (they may come from beyond L2)
             load_a(c1, t1, 1, anxt[1]);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             mma_step(acur[0], bf0);
             mma_step(acur[1], bf1);
@@ -774,15 +755,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
                     for (int i = 0; i < TM; ++i) acur[ks][q][i] = anxt[ks][q][i];
             c1 = c2; t1 = t2;
             adv(c2, t2);
-#if LA_ABLATE != 15
             __syncthreads();
-#endif
-#if LA_STAMP
-            if (s < 40) STAMP(2 + s);
-#endif
         }
     }
-    STAMP(44);
     if (F16) {
         // undo the power-of-two operand scales (exact)
         const float iw = 1.f / a.acc_scale_w[0];
@@ -798,7 +773,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         }
     }
     la_conv_epilogue<MT, SPLIT, false, WM_>(a, acc, red, ntile, m0, G, Ntot, SPLIT ? -1 : bz);
-    STAMP(45);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -871,10 +845,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     const int nck = (a.C + KCB - 1) / KCB;
     const long term_elems = a.wgt_bf16_term_elems;
     const int l31 = lane & 31, lh = lane >> 5;
-#if LA_STAMP
-    const int sblk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-#endif
-    STAMP(0);
     // buffer descriptors (wave-uniform): this sample's fp32 input, and the weight pack of this format
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.in) + (size_t)b * a.in_bstride, 0, (int)((unsigned)a.C * HWin * EB), 0x00020000);
@@ -1102,14 +1072,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             for (int k = tid; k < nck * KCB; k += 256)
                 scl[k] = k < a.C ? (a.in_scale ? a.in_scale[(long)b * a.scale_stride + k] : 1.f) * xs : 0.f;
         }
-        STAMP(1);
         __syncthreads();                           // scl is complete before any slice is scaled with it
 #pragma unroll
         for (int t = 0; t < 9; ++t) slice_write(smem, pre[t]);
     }
-    STAMP(2);
     __syncthreads();
-    STAMP(3);
 
   if constexpr (M16) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1313,31 +1280,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             const int shift_n = (int)((shpack >> (7 * (t + 1 < 9 ? t + 1 : 8))) & 127u);   // (last tap: harmless re-read)
             // (the fences pin the issue order: left alone, the scheduler sinks every load to just before its first use)
             read_b(cur, shift, 1, bf1);            // B of K-step 1 flies under the MFMAs of K-step 0
-            LA_FENCE_A;
             mma_step(acur[0], bf0);
-            LA_FENCE_B;
+            __builtin_amdgcn_sched_barrier(0);
             load_a(ccn, tn, 0, acur[0]);           // re-loaded as soon as its MFMAs have issued
             read_b(cur, shift_n, 0, bf0);          // B of the next tap's K-step 0
             if (NEXT) {
                 slice_write(nxt, sl);              // the slice loaded one tap ago
                 slice_load(cc + 1, t, sl);
             }
-            LA_FENCE_C;
             mma_step(acur[1], bf1);
-            LA_FENCE_B;
+            __builtin_amdgcn_sched_barrier(0);
             load_a(ccn, tn, 1, acur[1]);
-#if LA_STAMP
-            if (cc < 4) STAMP(4 + cc * 10 + t);
-#endif
         }
         if (NEXT) slice_write(nxt, sl);
     };
     for (int cc = 0; cc < nck; ++cc) {
         if (cc + 1 < nck) chunk(cc, std::true_type{});
         else chunk(cc, std::false_type{});
-#if LA_STAMP
-        if (cc < 4) STAMP(4 + cc * 10 + 9);
-#endif
         __syncthreads();       // next halo complete, everyone done with this one (and, at the end, LDS free for the epilogue)
     }
   }
@@ -1350,9 +1309,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
     }
-    STAMP(44);
     la_conv_epilogue<MT, false, true, WM_>(a, acc, red, ntile, m0, G, G);
-    STAMP(45);
 }
 
 template <int FMT>
@@ -1419,8 +1376,8 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
     }
     // three-wave form of the 128-row fp16 x2 launches (kernel comment); dev knob LA_FLAT_W3=0|1
     static const int f3_knob = []() { const char* e = getenv("LA_FLAT_W3"); return e ? atoi(e) : -1; }();
-    const bool f3 = FMT == FMT_F16X2 && LA_GATHER == 1 && MTsel == 128 && (f3_knob >= 0 ? f3_knob != 0 : true);
-    constexpr int FW3 = (FMT == FMT_F16X2 && LA_GATHER == 1) ? 3 : 2;
+    const bool f3 = FMT == FMT_F16X2  && MTsel == 128 && (f3_knob >= 0 ? f3_knob != 0 : true);
+    constexpr int FW3 = (FMT == FMT_F16X2 ) ? 3 : 2;
     if (MTsel == 128 && f3) {
         if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT, FW3>), grid, dim3(256), lds128, stream, as);
         else hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT, FW3>), grid, dim3(256), lds128, stream, as);

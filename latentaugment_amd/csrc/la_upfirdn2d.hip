@@ -465,8 +465,8 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
 
 // ------------------------------------------------------------------------------------------------------------------
 // Adjoint of the FIR that follows a transposed stride-2 conv (pad 2, flipped taps; upfirdn2d.py:255-266), writing its result
-// ALREADY in the form the stride-2 backward contraction reads: channel-interleaved [b][chunk][pixel][32 channels], each
-// element scaled by xscale[b] and split into two fp16 terms {h | l << 16}.  One pass replaces FIR adjoint + plane maxima +
+// ALREADY in the form the stride-2 backward contraction reads: [b][chunk][pixel][128-byte record], each element scaled by xscale[b]
+// and split into two fp16 terms, the record holding the h terms of the chunk's 32 channels followed by their l terms.  One pass replaces FIR adjoint + plane maxima +
 // pre-split copy (three passes over a [B][C][(2h+1)^2] tensor).
 // The power-of-two operand scale must be known before the first element is written, so it comes from a BOUND on the output,
 // |out| <= gain * sum|f| * max|in| (la_xscale_pmax with that factor), not from the output's exact maximum.  A looser scale costs
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void l
     const int Xb = blockIdx.x * 64, Yb = blockIdx.y * 8;
     const int X0 = Xb + xg * 4, Y0 = Yb + rs * 4;
     const float xs = a.xscale[b];
-    unsigned pk[4][4][4];                                 // [row][col][channel of the group]
+    unsigned pk[4][4][4];                                 // [row][col][channel of the group]: {h | l << 16}
     const bool lo_ok = X0 - 4 >= 0, mid_ok = X0 < a.W, hi_ok = X0 + 4 < a.W;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -552,13 +552,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void l
                 tile[pl * 8 + (cg ^ ((pl >> 2) & 7))] = make_uint4(pk[r][k][0], pk[r][k][1], pk[r][k][2], pk[r][k][3]);
             }
         __syncthreads();
+        // read-out: the record of a pixel is [h of its 32 channels | l of its 32 channels] (la_conv_bf16_kernel's pieces), so a thread
+        // takes two neighbouring channel groups (8 channels, 32 bytes of {h | l} pairs) and stores their h and l halves as 16-byte slots
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < 4; ++it) {
             const int idx = it * 256 + tid;
-            const int pl = idx >> 3, slot = idx & 7;
+            const int pl = idx >> 2, sp = idx & 3;
             const int lr = pl >> 6;
             const int Y = Yb + (lr >> 1) * 4 + half * 2 + (lr & 1), X = Xb + (pl & 63);
-            if (Y < a.Hz && X < a.Wz) op[((long)Y * a.Wz + X) * 8 + (slot ^ ((pl >> 2) & 7))] = tile[idx];
+            const int sw = (pl >> 2) & 7;
+            const uint4 e0 = tile[pl * 8 + ((2 * sp) ^ sw)], e1 = tile[pl * 8 + ((2 * sp + 1) ^ sw)];
+            if (Y < a.Hz && X < a.Wz) {
+                uint4* rec = op + ((long)Y * a.Wz + X) * 8;
+                rec[sp] = make_uint4(__builtin_amdgcn_perm(e0.y, e0.x, 0x05040100u), __builtin_amdgcn_perm(e0.w, e0.z, 0x05040100u),
+                                     __builtin_amdgcn_perm(e1.y, e1.x, 0x05040100u), __builtin_amdgcn_perm(e1.w, e1.z, 0x05040100u));
+                rec[4 + sp] = make_uint4(__builtin_amdgcn_perm(e0.y, e0.x, 0x07060302u), __builtin_amdgcn_perm(e0.w, e0.z, 0x07060302u),
+                                         __builtin_amdgcn_perm(e1.y, e1.x, 0x07060302u), __builtin_amdgcn_perm(e1.w, e1.z, 0x07060302u));
+            }
         }
     }
 }
