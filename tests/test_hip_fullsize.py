@@ -98,7 +98,9 @@ def _check_steps(name, c, fx, w_steps, g_steps, slack):
     # plain float32 net (the reference's worst entry on config B sits at 2.6e-5 of max |g|)
     assert np.sqrt((e_h ** 2).mean()) <= slack * np.sqrt((e_r ** 2).mean()) + 1e-7 * gmax
     assert e_h.max() <= 2 * slack * e_r.max() + 1e-6 * gmax, (e_h.max(), e_r.max())
-    assert np.all(e_h <= 1e-3 * np.abs(g64) + 1e-4 * gmax), float((e_h - 1e-3 * np.abs(g64)).max() / gmax)
+    # (config E: with the discriminator's and the feature net's ReLU / max-pool kinks in the loss the float32 gradient itself sits
+    #  1.7e-3 of max |g| from float64 in its worst entry -- for the reference's run exactly as for this one)
+    assert np.all(e_h <= 1e-3 * np.abs(g64) + max(1e-4 * gmax, 2 * float(e_r.max()))), float((e_h - 1e-3 * np.abs(g64)).max() / gmax)
     o64, r32 = fx['o64_w_steps'].astype(np.float64), fx['ref32_w_steps'].astype(np.float64)
     assert w_steps.shape == o64.shape == r32.shape == (c['steps'], c['batch'], 512)
     # Statistic per step: the rms over the BULK of the entries -- all but the k = 0.3 % largest errors of each run.  In the first
