@@ -44,6 +44,7 @@ enum { LA_PC_CONV_HALO = 0, LA_PC_CONV_FLAT, LA_PC_CONV_SPLITK, LA_PC_CONV_F32, 
 bool la_prof_enabled();      // profiler active: callers keep their launches eager
 int la_dev_knob(int id);     // kernel-variant selectors for in-process A/B measurements (la_dev_knob_set; all 0 in the product)
 #define LA_KNOB_HALO_MF 0     // halo contraction form: 0 = default, 8 = round-2 form, else the MF bits of la_conv_bf16_halo_kernel
+#define LA_KNOB_HALO_MING 1   // dev: grids of fewer points than this go to split-K instead of the halo kernel (0 = 1157: up to 34x34)
 #define LA_NKNOB 16
 int la_prof_open(int cls, double flops, double bytes, hipStream_t stream);     // -> slot or -1
 void la_prof_close(int slot, hipStream_t stream);

@@ -410,7 +410,7 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
         as.splitk_ws = reinterpret_cast<float*>(as.ws);
         splitk_floats = (long)(as.ws_bytes / sizeof(float));
     }
-    bool small = G <= SPLITK_MAX_G;
+    bool small = G <= SPLITK_MAX_G && !(bf && la_conv_bf16_uses_halo(as));      // (the halo kernel claims what it can run directly)
     long Gsum = G, Gmax = G, tiles_flat = la_cdiv((long)a.B * G, NT);
     if (nphase > 0) {
         Gsum = 0; Gmax = 0; tiles_flat = 0;

@@ -347,7 +347,12 @@ bool la_conv_bf16_uses_halo(const LaConvArgs& a) {
     if (a.precision == LA_PREC_F32 || a.in_q) return false;
     if (a.in_sy != 1 || a.in_sx != 1 || a.out_sy != 1 || a.out_sx != 1 || a.out_oy != 0 || a.out_ox != 0) return false;
     if ((a.Gx & 31) != 0 || (a.Gy & 3) != 0 || a.Gy != a.Hout || a.Gx != a.Wout || a.ntaps != 9) return false;
-    if ((long)a.Gy * a.Gx <= 1156) return false;                         // split-K territory (la_conv.hip SPLITK_MAX_G)
+    // Grids up to 34x34 stay on the split-K path (la_conv.hip SPLITK_MAX_G).  Round 3 measured the 32x32 layers (512 -> 512, K = 4608) on
+    // this kernel: 114 us against 135 us for slices + finish pass + pre-split copy in isolation, no difference inside a batch -- and
+    // the first-step gradient of the 1024^2 loop 12x further from float64 (rms 4.4e-6 against 3.7e-7 of max |g| 0.4; the reference's
+    // float32: 1.5e-6): K slices summed afterwards are a blocked summation, one accumulator walking all 4608 terms is not.  Dev knob
+    // LA_KNOB_HALO_MING: grids of at least that many points run here.
+    if ((long)a.Gy * a.Gx < (la_dev_knob(LA_KNOB_HALO_MING) ? la_dev_knob(LA_KNOB_HALO_MING) : 1157)) return false;
     if ((long)a.C * a.Hin * a.Win >= (1l << 28) || a.C > 4096) return false;   // 32-bit byte offsets inside one sample, below the
                                                                              // out-of-range sentinel of the pixel-stationary loader
     for (int t = 0; t < a.ntaps; ++t)

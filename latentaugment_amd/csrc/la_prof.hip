@@ -1,6 +1,7 @@
 // Opt-in launch profiler (bench.py's roofline leg): HIP events bracket launches on the launch stream, accumulated per KERNEL
 // CLASS together with the algorithmic work of the bracketed launches.  Off by default; the only process-global state in the
 // library.  While it is on, the step loop launches eagerly (no graph replay) so that the brackets see every launch.
+#include <stdlib.h>
 #include "la_common.h"
 
 #define LA_PROF_MAX 16384
@@ -18,6 +19,19 @@ static struct {
 // dev knobs: kernel-variant selectors so that two variants can be timed in interleaved rounds of ONE process (cdna_hip_programming.md
 // rule 24).  Every knob defaults to 0 = the shipped configuration.
 static int g_knob[LA_NKNOB];
+static const bool g_knob_env = []() {      // LA_DEV_KNOBS="id=value,id=value": initial knob values (development runs of whole test files)
+    const char* e = getenv("LA_DEV_KNOBS");
+    while (e && *e) {
+        char* end = nullptr;
+        const long id = strtol(e, &end, 10);
+        if (end == e || *end != '=') break;
+        const long v = strtol(end + 1, &end, 10);
+        if (id >= 0 && id < LA_NKNOB) g_knob[id] = (int)v;
+        e = *end == ',' ? end + 1 : end;
+        if (*end != ',') break;
+    }
+    return true;
+}();
 int la_dev_knob(int id) { return id >= 0 && id < LA_NKNOB ? g_knob[id] : 0; }
 extern "C" int la_dev_knob_set(int id, int value) {
     LA_CHECK_ARG(id >= 0 && id < LA_NKNOB, "dev_knob_set: unknown knob");
