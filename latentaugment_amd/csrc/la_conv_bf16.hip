@@ -815,7 +815,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
 template <int MT, int FMT, int WV, int MF = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void la_conv_bf16_halo_kernel(LaConvArgs a) {
     constexpr bool SB = WV == 3;
-    static_assert(MF == 0 || (WV == 3 && FMT == FMT_F16X2 && MT == 128), "the MF forms exist for the three-wave fp16 x2 kernel on 128-row tiles");
+    static_assert(MF == 0 || FMT == FMT_F16X2, "the MF forms exist for the fp16 x2 format");
+    static_assert((MF & 1) == 0 || (WV == 3 && MT == 128), "the 16x16x32 form exists for the three-wave kernel on 128-row tiles");
     // MF bits: 1 = 16x16x32 MFMA; 2 = dev ablation (the loader skips the modulation and the fp16 split arithmetic: WRONG results, timing
     // only); 4 = pixel-stationary halo loader (below)
     constexpr bool M16 = (MF & 1) != 0, ABL = (MF & 2) != 0, PSL = (MF & 4) != 0;
@@ -962,11 +963,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, ps_off, (unsigned)c * HWin * EB, 0));
         }
     };
-    auto ps_write = [&](unsigned char* buf, int cc, int t, const float (&x)[4]) {      // the slice loaded with the same (cc, t)
+    // per-channel factors of a slice (style x fp16 sample scale): requested at the START of the tap that writes the slice, half a tap
+    // before they are used, so that the LDS read is long complete and its wait does not drain the fragment reads in flight
+    auto ps_factors = [&](int cc, int t) -> float4 {
+        return *reinterpret_cast<const float4*>(scl + cc * KCB + (t & 7) * 4);
+    };
+    auto ps_write = [&](unsigned char* buf, int t, const float (&x)[4], const float4 f) {      // the slice loaded with the same t
         if (t < 8 && ps_act) {
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-            const float4 f = *reinterpret_cast<const float4*>(scl + cc * KCB + t * 4);
             unsigned char* dst = buf + ps_row + ((((t >> 1) ^ ps_swz) & 3) << 4) + (t & 1) * 8;
             if constexpr (ABL) {
                 const uint2 w = make_uint2(__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[2]));
@@ -1065,7 +1070,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         }
         __syncthreads();                           // scl is complete before any slice is scaled with it
 #pragma unroll
-        for (int t = 0; t < 8; ++t) ps_write(smem, 0, t, pre[t]);
+        for (int t = 0; t < 8; ++t) ps_write(smem, t, pre[t], ps_factors(0, t));
     } else {
         Slice pre[9];
 #pragma unroll
@@ -1142,6 +1147,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             const int ccn = t + 1 < 9 ? cc : (has_next ? cc + 1 : 0);
             const int shift_n = (int)((shpack >> (7 * (t + 1 < 9 ? t + 1 : 8))) & 127u);
             const int lb_nxt = PSL ? lane_b16(shift_n, (int)((xpack >> (2 * (t + 1 < 9 ? t + 1 : 8))) & 3u)) : 0;
+            float4 psf = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (PSL) { if (has_next && t >= 1) psf = ps_factors(cc + 1, t - 1); }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -1160,7 +1167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
                 load_a16(ccn, tn, mi, a16[mi]);          // this half's weights of the next tap: half a tap to land
                 if (mi == 0) {
                     if constexpr (PSL) {
-                        if (has_next && t >= 1) ps_write(nxt, cc + 1, t - 1, psx);      // the slice loaded one tap ago
+                        if (has_next && t >= 1) ps_write(nxt, t - 1, psx, psf);      // the slice loaded one tap ago
                         ps_load(has_next ? cc + 1 : cc, t, psx);
                     } else {
                         slice_write(nxt, sl);
@@ -1249,11 +1256,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             const int tn = t + 1 < 9 ? t + 1 : 0;
             const int ccn = t + 1 < 9 ? cc : (has_next ? cc + 1 : 0);
             const int shift_n = (int)((shpack >> (7 * (t + 1 < 9 ? t + 1 : 8))) & 127u);
+            float4 psf = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (PSL) { if (has_next && t >= 1) psf = ps_factors(cc + 1, t - 1); }
             mma_refill(acur[0], cur, shift, 1, true, lb);      // K-step 0; refilled with this tap's K-step 1
             if constexpr (PSL) lb = lane_b(shift_n, (int)((xpack >> (2 * (t + 1 < 9 ? t + 1 : 8))) & 3u));
             load_a(ccn, tn, 0, acur[0]);
             if constexpr (PSL) {
-                if (has_next && t >= 1) ps_write(nxt, cc + 1, t - 1, psx);      // the slice loaded one tap ago
+                if (has_next && t >= 1) ps_write(nxt, t - 1, psx, psf);      // the slice loaded one tap ago
                 ps_load(has_next ? cc + 1 : cc, t, psx);
             } else {
                 slice_write(nxt, sl);
@@ -1275,7 +1284,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         Slice sl;
         sl.wr = -1;
         sl.ok = false;
-        read_b(cur, (int)(shpack & 127u), 0, bf0);
+        float psx[4] = {0.f, 0.f, 0.f, 0.f};
+        int lb = PSL ? lane_b((int)(shpack & 127u), (int)(xpack & 3u)) : 0;      // lane address of the current tap (PSL)
+        read_b(cur, (int)(shpack & 127u), 0, bf0, lb);
 #pragma unroll 1
         for (int t = 0; t < 9; ++t) {
             const int shift = (int)((shpack >> (7 * t)) & 127u);
@@ -1284,20 +1295,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             const int ccn = t + 1 < 9 ? cc : (NEXT ? cc + 1 : 0);
             const int shift_n = (int)((shpack >> (7 * (t + 1 < 9 ? t + 1 : 8))) & 127u);   // (last tap: harmless re-read)
             // (the fences pin the issue order: left alone, the scheduler sinks every load to just before its first use)
-            read_b(cur, shift, 1, bf1);            // B of K-step 1 flies under the MFMAs of K-step 0
+            float4 psf = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (PSL) { if (NEXT && t >= 1) psf = ps_factors(cc + 1, t - 1); }
+            read_b(cur, shift, 1, bf1, lb);        // B of K-step 1 flies under the MFMAs of K-step 0
             mma_step(acur[0], bf0);
             __builtin_amdgcn_sched_barrier(0);
             load_a(ccn, tn, 0, acur[0]);           // re-loaded as soon as its MFMAs have issued
-            read_b(cur, shift_n, 0, bf0);          // B of the next tap's K-step 0
+            if constexpr (PSL) lb = lane_b(shift_n, (int)((xpack >> (2 * (t + 1 < 9 ? t + 1 : 8))) & 3u));
+            read_b(cur, shift_n, 0, bf0, lb);      // B of the next tap's K-step 0
             if (NEXT) {
-                slice_write(nxt, sl);              // the slice loaded one tap ago
-                slice_load(cc + 1, t, sl);
+                if constexpr (PSL) {
+                    if (t >= 1) ps_write(nxt, t - 1, psx, psf);      // the slice loaded one tap ago
+                    ps_load(cc + 1, t, psx);
+                } else {
+                    slice_write(nxt, sl);
+                    slice_load(cc + 1, t, sl);
+                }
             }
             mma_step(acur[1], bf1);
             __builtin_amdgcn_sched_barrier(0);
             load_a(ccn, tn, 1, acur[1]);
         }
-        if (NEXT) slice_write(nxt, sl);
+        if (NEXT && !PSL) slice_write(nxt, sl);      // (PSL: tap 8 loads nothing new)
     };
     for (int cc = 0; cc < nck; ++cc) {
         if (cc + 1 < nck) chunk(cc, std::true_type{});
@@ -1370,6 +1389,36 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
                     case 5: return go(std::integral_constant<int, 5>{});
                     case 7: return go(std::integral_constant<int, 7>{});      // (loader ablation: wrong results)
                     default: break;
+                }
+            }
+        }
+        if constexpr (FMT == FMT_F16X2) {
+            // every other fp16 x2 halo launch (64- / 32-row tiles, single-chunk launches): the pixel-stationary loader on the 32x32x16 form
+            // (MF 4); dev knob 8 = the round-2 loader
+            if (la_dev_knob(LA_KNOB_HALO_MF) != 8) {
+                auto attr = [&](const void* fn, std::atomic<bool>& flag) -> bool {
+                    if (!flag.load(std::memory_order_acquire)) {
+                        const int cap = 2 * 3 * HALO_PX * HPITCH + 4096 * (int)sizeof(float);
+                        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess) { la_set_error("halo PSL: hipFuncSetAttribute failed"); return false; }
+                        flag.store(true, std::memory_order_release);
+                    }
+                    return true;
+                };
+                static std::atomic<bool> d128[64], d64[64], d32[64];
+                if (MTsel == 128 && w3) {
+                    if (!attr(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, FMT_F16X2, 3, 4>), d128[dev])) return LA_ERR_HIP;
+                    hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, FMT_F16X2, 3, 4>), grid, dim3(256), h128, stream, as);
+                    return LA_OK;
+                }
+                if (MTsel == 64) {
+                    if (!attr(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<64, FMT_F16X2, 2, 4>), d64[dev])) return LA_ERR_HIP;
+                    hipLaunchKernelGGL((la_conv_bf16_halo_kernel<64, FMT_F16X2, 2, 4>), grid, dim3(256), h64, stream, as);
+                    return LA_OK;
+                }
+                if (MTsel == 32) {
+                    if (!attr(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<32, FMT_F16X2, 2, 4>), d32[dev])) return LA_ERR_HIP;
+                    hipLaunchKernelGGL((la_conv_bf16_halo_kernel<32, FMT_F16X2, 2, 4>), grid, dim3(256), h64, stream, as);
+                    return LA_OK;
                 }
             }
         }
