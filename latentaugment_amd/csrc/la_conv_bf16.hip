@@ -413,8 +413,12 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // WV = waves per SIMD the kernel is compiled for (3: fp16 x2 pieces form only): as in the halo kernel below, ONE set of B fragments
 // (K-step 1 re-loaded in place under the MFMAs of K-step 0; the next step's K-step 0 after the barrier) and one set of weight
 // fragments re-loaded right after its MFMAs have issued.
-template <int MT, bool SPLIT, int FMT, int WV>
+// MF = 1 (three-wave fp16 x2 form, 128-row tiles): the step on v_mfma_f32_16x16x32_f16, as in the halo kernel (2 x 8 tiles of 16 x 16
+// per wave, the pixel fragments read twice per step, LDS slots swizzled by 2 * ((pixel >> 2) & 1), accumulators brought into the
+// 32x32 layout through LDS before the shared epilogue).
+template <int MT, bool SPLIT, int FMT, int WV, int MF = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void la_conv_bf16_kernel(LaConvArgs a_in) {
+    static_assert(MF == 0 || (WV == 3 && FMT == FMT_F16X2 && MT == 128), "the 16x16x32 form exists for the three-wave fp16 x2 kernel on 128-row tiles");
     // merged output phases: blockIdx.z = phase * B + sample; the phase's grid, output offset and taps replace the launch-wide ones
     LaConvArgs a = a_in;
     int bz = blockIdx.z;
@@ -580,7 +584,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     const int wrow = n_l * BPITCH, wsw = (n_l >> 2) & 3;
     auto write_b = [&](unsigned char* buf) {
         if constexpr (PIECES) {      // piece (tid & 7) = slot (tid & 3) of term (tid >> 2 & 1); the tile row only adds k * 32 rows
-            unsigned char* p0 = buf + ((tid >> 2) & 1) * BPLANE + (tid >> 3) * BPITCH + ((((tid & 3) ^ (tid >> 5)) & 3) << 4);
+            const int wsw = MF ? ((tid >> 5) & 1) << 1 : (tid >> 5);      // slot swizzle of pixel k * 32 + (tid >> 3): by (pixel >> 2) & 3, MF: 2 * ((pixel >> 2) & 1)
+            unsigned char* p0 = buf + ((tid >> 2) & 1) * BPLANE + (tid >> 3) * BPITCH + ((((tid & 3) ^ wsw) & 3) << 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 *reinterpret_cast<uint4*>(p0 + k * 32 * BPITCH) = make_uint4(ex[4 * k], ex[4 * k + 1], ex[4 * k + 2], ex[4 * k + 3]);
@@ -658,6 +663,104 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             }
     };
 
+    if constexpr (MF == 1) {
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const int c16 = lane & 15, kq = lane >> 4;
+      f32x4 acc16[2][8];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int n = 0; n < 8; ++n) acc16[mi][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (nstep > 0) {
+        int c1 = ck_beg, t1 = 0;
+        auto adv = [&](int& c, int& t) {
+            if (t + 1 < ntaps) ++t;
+            else if (c + 1 < ck_end) { ++c; t = 0; }
+        };
+        int mblk16 = (m0 + wm * 32) >> 5;
+        mblk16 = mblk16 < (Mp >> 5) ? mblk16 : (Mp >> 5) - 1;
+        const unsigned a16_off = (unsigned)mblk16 * 2048u + (unsigned)(kq * 32 + c16) * 16u;
+        auto load_a16 = [&](int cc, int t, int mi, f16x8 (&dst)[2]) {
+            const unsigned tw = (unsigned)((wpack >> (4 * t)) & 15u);
+            const unsigned so = (tw * nck + cc) * slab_bytes;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                dst[q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, a16_off + (unsigned)mi * 256u, so + q * term_bytes, 0));
+        };
+        const int rb16 = c16 * BPITCH + (((kq ^ (((c16 >> 2) & 1) << 1)) & 3) << 4);      // tile n adds n * 16 rows
+        auto read_b16 = [&](const unsigned char* buf, int n, f16x8 (&dst)[2]) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) dst[q] = *reinterpret_cast<const f16x8*>(buf + q * BPLANE + n * 16 * BPITCH + rb16);
+        };
+        f16x8 a16[2][2], b16[4][2];
+        const int c0 = c1, t0 = t1;      // (prologue in the loop's issue order: see the 32x32x16 form below)
+        load_b(c0, t0);
+        adv(c1, t1);                                   // (c1, t1) = step 1
+        int c2 = c1, t2 = t1;
+        write_b(smem);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(c1, t1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a16(c0, t0, 0, a16[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a16(c0, t0, 1, a16[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        adv(c2, t2);                                   // (c2, t2) = step 2
+#pragma unroll 1
+        for (int s = 0; s < nstep; ++s) {
+            const unsigned char* cur = smem + (s & 1) * BBUF;
+            unsigned char* nxt = smem + ((s + 1) & 1) * BBUF;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) read_b16(cur, n, b16[n]);
+            write_b(nxt);                              // step s+1 (loaded during step s-1)
+            load_b(c2, t2);                            // step s+2
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    f16x8 (&bs)[2] = b16[n & 3];
+                    acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][1], bs[0], acc16[mi][n], 0, 0, 0);   // lh
+                    acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][0], bs[1], acc16[mi][n], 0, 0, 0);   // hl
+                    acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][0], bs[0], acc16[mi][n], 0, 0, 0);   // hh
+                    if (n < 4) read_b16(cur, n + 4, bs);                 // the slot is re-filled with the tile four sub-steps ahead
+                    else if (mi == 0) read_b16(cur, n - 4, bs);          // (the same pixels again for the other 16 rows)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                load_a16(c1, t1, mi, a16[mi]);         // this half's weights of step s+1
+            }
+            c1 = c2; t1 = t2;
+            adv(c2, t2);
+            __syncthreads();
+        }
+      }
+      // 16x16 tiles -> the 32x32 accumulator layout of the epilogue through LDS (free after the last barrier), two 32-pixel blocks at a time
+      {
+        float* tb = reinterpret_cast<float*>(smem) + wid * (64 * 36);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            if (hf) __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int n4 = 0; n4 < 4; ++n4) {
+                    const int n = hf * 4 + n4;
+                    *reinterpret_cast<f32x4*>(tb + (n4 * 16 + c16) * 36 + mi * 16 + kq * 4) = acc16[mi][n];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(tb + (jj * 32 + l31) * 36 + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[0][hf * 2 + jj][4 * g + r] = v[r];
+                }
+        }
+        __syncthreads();
+      }
+    } else
     if constexpr (WV == 3) {
       if (nstep > 0) {
         static_assert(WV != 3 || (FMT == FMT_F16X2 ), "the three-wave form exists for the fp16 pieces loader only");
@@ -1432,6 +1535,15 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
     static const int f3_knob = []() { const char* e = getenv("LA_FLAT_W3"); return e ? atoi(e) : -1; }();
     const bool f3 = FMT == FMT_F16X2  && MTsel == 128 && (f3_knob >= 0 ? f3_knob != 0 : true);
     constexpr int FW3 = (FMT == FMT_F16X2 ) ? 3 : 2;
+    if constexpr (FMT == FMT_F16X2) {
+        // 16x16x32 form of the three-wave kernel (dev knob LA_KNOB_FLAT_MF: 8 = the 32x32x16 form); its accumulator hand-over needs 36 KB of LDS
+        if (MTsel == 128 && f3 && la_dev_knob(LA_KNOB_FLAT_MF) != 8) {
+            const size_t lds_mf = lds128 > (size_t)4 * 64 * 36 * 4 ? lds128 : (size_t)4 * 64 * 36 * 4;
+            if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT_F16X2, 3, 1>), grid, dim3(256), lds_mf, stream, as);
+            else hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT_F16X2, 3, 1>), grid, dim3(256), lds_mf, stream, as);
+            return LA_OK;
+        }
+    }
     if (MTsel == 128 && f3) {
         if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT, FW3>), grid, dim3(256), lds128, stream, as);
         else hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT, FW3>), grid, dim3(256), lds128, stream, as);
