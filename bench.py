@@ -49,8 +49,8 @@ CONTRACTION = {
     'f32': dict(peak=MFMA_F32_PEAK_TFLOPS, kernel='la_conv_igemm_kernel (fp32 MFMA 32x32x2, exact fp32)', mfma_per_product=1),
     'bf16x3': dict(peak=MFMA_BF16_PEAK_TFLOPS / 6, kernel='la_conv_bf16_halo_kernel<FMT_BF16X3> (fp32 split into 3 bf16 terms, 6 bf16 '
                    'MFMA 32x32x16 per product, fp32 accumulate; fp32-class error)', mfma_per_product=6),
-    'f16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_halo_kernel<FMT_F16X2> (fp32 scaled by powers of two and split into '
-                  '2 fp16 terms, 3 fp16 MFMA 32x32x16 per product, fp32 accumulate; fp32-class error)', mfma_per_product=3),
+    'f16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_halo_kernel<128, FMT_F16X2, 3, 5> (fp32 scaled by powers of two and '
+                  'split into 2 fp16 terms, 3 fp16 MFMA 16x16x32 per product, fp32 accumulate; fp32-class error)', mfma_per_product=3),
     'bf16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_halo_kernel<NTERM=2> (2 bf16 terms, 3 bf16 MFMA per product; '
                    'approximate mode)', mfma_per_product=3),
 }
@@ -220,7 +220,7 @@ def roofline_leg(lib, _lib, args, one_step, elapsed_per_step):
                               'note': 'SURVEY 8(d): 700.2 MB per image-step (fwd+bwd) + 274.6 MB final forward per image + shared weights'}
     # HBM bytes per launch of the dominant class from the committed PMC passes of this workload (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate passes, scripts/make_profiles.sh): counters cannot be read from inside the process
-    pmc = os.path.join(ROOT, 'profiles', f'r02_pmc_traffic_{args.precision}.json')
+    pmc = os.path.join(ROOT, 'profiles', f'r03_pmc_traffic_{args.precision}.json')
     if os.path.isfile(pmc) and args.preset == 'B' and args.w_disc == 0 and args.batch == 8 and args.res == 256:
         pj = json.load(open(pmc))
         if pj.get('precision') == args.precision and dom in pj.get('classes', {}):
