@@ -419,6 +419,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 template <int MT, bool SPLIT, int FMT, int WV, int MF = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void la_conv_bf16_kernel(LaConvArgs a_in) {
     static_assert(MF == 0 || (WV == 3 && FMT == FMT_F16X2 && MT == 128), "the 16x16x32 form exists for the three-wave fp16 x2 kernel on 128-row tiles");
+    // MF = 2: MF = 1 on THREE pixel buffers.  The barrier at the end of step s then publishes the buffer of step s + 2, so the buffer of
+    // step s + 1 is already complete while step s computes: its first fragments are read under the last MFMAs of step s, and no LDS
+    // read latency is left exposed behind the barrier (two buffers: every step began with eight fragment reads nothing could cover).
     // merged output phases: blockIdx.z = phase * B + sample; the phase's grid, output offset and taps replace the launch-wide ones
     LaConvArgs a = a_in;
     int bz = blockIdx.z;
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             }
     };
 
-    if constexpr (MF == 1) {
+    if constexpr (MF >= 1) {
       typedef float f32x4 __attribute__((ext_vector_type(4)));
       const int c16 = lane & 15, kq = lane >> 4;
       f32x4 acc16[2][8];
@@ -694,6 +697,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         };
         f16x8 a16[2][2], b16[4][2];
         const int c0 = c1, t0 = t1;      // (prologue in the loop's issue order: see the 32x32x16 form below)
+      if constexpr (MF == 2) {
+        load_b(c0, t0);
+        adv(c1, t1);                                   // (c1, t1) = step 1
+        int c2 = c1, t2 = t1;
+        write_b(smem);                                 // step 0 -> buffer 0
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(c1, t1);
+        adv(c2, t2);                                   // (c2, t2) = step 2
+        write_b(smem + BBUF);                          // step 1 -> buffer 1
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(c2, t2);                                // step 2: written by iteration 0
+        __builtin_amdgcn_sched_barrier(0);
+        load_a16(c0, t0, 0, a16[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a16(c0, t0, 1, a16[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        adv(c2, t2);                                   // (c2, t2) = step 3
+#pragma unroll
+        for (int n = 0; n < 4; ++n) read_b16(smem, n, b16[n]);
+        int ib = 0;                                    // buffer of step s
+#pragma unroll 1
+        for (int s = 0; s < nstep; ++s) {
+            const int ib1 = ib == 2 ? 0 : ib + 1, ib2 = ib1 == 2 ? 0 : ib1 + 1;
+            const unsigned char* cur = smem + ib * BBUF;
+            const unsigned char* nx1 = smem + ib1 * BBUF;
+            write_b(smem + ib2 * BBUF);                // step s+2 (loaded during step s-1)
+            load_b(c2, t2);                            // step s+3
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more = s + 1 < nstep;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    f16x8 (&bs)[2] = b16[n & 3];
+                    acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][1], bs[0], acc16[mi][n], 0, 0, 0);   // lh
+                    acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][0], bs[1], acc16[mi][n], 0, 0, 0);   // hl
+                    acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][0], bs[0], acc16[mi][n], 0, 0, 0);   // hh
+                    if (n < 4) read_b16(cur, n + 4, bs);                 // the slot is re-filled with the tile four sub-steps ahead
+                    else if (mi == 0) read_b16(cur, n - 4, bs);          // (the same pixels again for the other 16 rows)
+                    else if (more) read_b16(nx1, n - 4, bs);             // first tiles of step s+1: published by the PREVIOUS barrier
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                load_a16(c1, t1, mi, a16[mi]);         // this half's weights of step s+1
+            }
+            adv(c1, t1);           // weights run one step ahead, pieces three
+            adv(c2, t2);
+            ib = ib1;
+            __syncthreads();
+        }
+      } else {
         load_b(c0, t0);
         adv(c1, t1);                                   // (c1, t1) = step 1
         int c2 = c1, t2 = t1;
@@ -734,6 +788,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             adv(c2, t2);
             __syncthreads();
         }
+      }
       }
       // 16x16 tiles -> the 32x32 accumulator layout of the epilogue through LDS (free after the last barrier), two 32-pixel blocks at a time
       {
@@ -1537,9 +1592,14 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
     constexpr int FW3 = (FMT == FMT_F16X2 ) ? 3 : 2;
     if constexpr (FMT == FMT_F16X2) {
         // 16x16x32 form of the three-wave kernel (dev knob LA_KNOB_FLAT_MF: 8 = the 32x32x16 form); its accumulator hand-over needs 36 KB of LDS
-        if (MTsel == 128 && f3 && la_dev_knob(LA_KNOB_FLAT_MF) != 8) {
+        const int fk = la_dev_knob(LA_KNOB_FLAT_MF);
+        if (MTsel == 128 && f3 && fk != 8) {
             const size_t lds_mf = lds128 > (size_t)4 * 64 * 36 * 4 ? lds128 : (size_t)4 * 64 * 36 * 4;
-            if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT_F16X2, 3, 1>), grid, dim3(256), lds_mf, stream, as);
+            const size_t lds_3 = (size_t)3 * NTERM * NT * BPITCH;      // three pixel buffers (>= the accumulator hand-over's 36 KB)
+            const bool three = fk == 2 || (fk == 0 && !split) || fk == 3;      // default: direct launches on three buffers (knob 2: both, 1: neither)
+            if (three && !split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT_F16X2, 3, 2>), grid, dim3(256), lds_3, stream, as);
+            else if (fk == 2 && split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT_F16X2, 3, 2>), grid, dim3(256), lds_3, stream, as);
+            else if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT_F16X2, 3, 1>), grid, dim3(256), lds_mf, stream, as);
             else hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT_F16X2, 3, 1>), grid, dim3(256), lds_mf, stream, as);
             return LA_OK;
         }
