@@ -156,6 +156,10 @@ int la_synth_create(int img_resolution, int img_channels, int w_dim, const int* 
 void la_synth_destroy(la_synth* h);
 /* contraction precision of every modulated conv of the engine (LA_PREC_*, default LA_PREC_F32) */
 int la_synth_set_precision(la_synth* h, int precision);
+/* f16x2 only: where the power-of-two operand scale of the FORWARD contractions comes from.  0 (default): the a-priori bound
+ * conv_clamp * max|style| (no pass over the data; float32-class as long as a layer's activations reach ~2^-16 of that bound
+ * somewhere, i.e. O(1e-2) and up).  1: the data maxima (two short passes per layer more; no such limit). */
+int la_synth_set_operand_scale(la_synth* h, int from_data);
 int la_synth_get_precision(const la_synth* h);
 /* ws element (b,l,j) = ws[b*ws_bstride + l*ws_lstride + j] (ws_lstride = 0: W space, one w per sample).
  * noise_mode 0 'none', 1 'const', 2 explicit unit-variance tensors noises[layer] [B][res][res] ('random' drawn by the caller).

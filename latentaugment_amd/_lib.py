@@ -64,6 +64,7 @@ SIGNATURES = {
     'la_synth_create': (_I, [_I, _I, _I, _P, _F, _P, _I, _P, _I, _P, _I, _I, _I, _P, _Z, _P, _P]),
     'la_synth_destroy': (None, [_P]),
     'la_synth_set_precision': (_I, [_P, _I]),
+    'la_synth_set_operand_scale': (_I, [_P, _I]),
     'la_synth_get_precision': (_I, [_P]),
     'la_synth_forward': (_I, [_P, _P, _L, _L, _I, _I, _P, _P, _P]),
     'la_synth_backward': (_I, [_P, _P, _P, _P]),

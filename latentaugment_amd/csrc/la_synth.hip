@@ -62,6 +62,7 @@ struct la_synth {
     float* xs_bound;         // [nconv]: bound on |input| of conv layer k: max|const| for the first, conv_clamp for the rest
     int lastB;
     int precision;
+    int data_scale;          // 1: forward fp16 operand scales from the data maxima (absmax / plane-maxima passes) instead of the clamp bound
     float* final_img;   // where the last forward put the full-resolution image
 };
 
@@ -299,6 +300,14 @@ extern "C" int la_synth_set_precision(la_synth* h, int precision) {
     return LA_OK;
 }
 extern "C" int la_synth_get_precision(const la_synth* h) { return h ? h->precision : -1; }
+// fp16 operand scale of the FORWARD contractions (f16x2 mode): 0 (default) from the a-priori bound conv_clamp * max|style| -- no pass
+// over the data; float32-class while a tensor reaches at least ~2^-16 of that bound somewhere -- or 1 from the data maxima (two
+// more short passes per layer, no such limit; what a generator without conv_clamp always gets).
+extern "C" int la_synth_set_operand_scale(la_synth* h, int from_data) {
+    LA_CHECK_ARG(h && (from_data == 0 || from_data == 1), "synth_set_operand_scale: 0 (bound) or 1 (data)");
+    h->data_scale = from_data;
+    return LA_OK;
+}
 
 extern "C" const float* la_synth_image(const la_synth* h) { return h ? h->final_img : nullptr; }
 extern "C" const float* la_synth_block_image(const la_synth* h, int k) { return (h && k >= 0 && k < h->nblocks) ? h->rgb[k].img : nullptr; }
@@ -318,11 +327,12 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
     if ((rc = la_demod_forward(h->dt, h->s_all, h->S, B, h->d_all, stream))) return rc;
     h->lastB = B;
     const bool f16 = h->precision == LA_PREC_F16X2;
-    const bool bound_scale = f16 && h->clamp > 0.f;
+    const bool bound_scale = f16 && h->clamp > 0.f && !h->data_scale;
     // scratch layout of the up layers: dense interleaved rows (plane maxima wanted: scalar FIR; dev knob LA_NO_ZT_PITCH) or column-planar
     static const bool zt_knob_dense = getenv("LA_NO_ZT_PITCH") != nullptr;
     const bool zt_dense = (f16 && !bound_scale) || zt_knob_dense;
-    if (bound_scale && (rc = la_xscale_from_bounds(h->dt, h->s_all, h->S, h->xs_bound, h->xs_fwd, B, stream, h->xs_bwd))) return rc;
+    // (also with data-based forward scales: the launch resets xs_bwd, the running scale slots of the backward pass)
+    if (f16 && h->clamp > 0.f && (rc = la_xscale_from_bounds(h->dt, h->s_all, h->S, h->xs_bound, h->xs_fwd, B, stream, h->xs_bwd))) return rc;
     int ci = 0;
     const float* x = h->cst;
     long x_bstride = 0;

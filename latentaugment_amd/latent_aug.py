@@ -175,6 +175,8 @@ class LatentAug:
             pass
         max_local = int(getattr(opt, 'max_local_batch', 0) or max_local)
         self.engine = SynthesisEngine.from_generator(generator, self.device, max_local, precision=self.precision)
+        if getattr(opt, 'operand_scale', 'bound') != 'bound':
+            self.engine.set_operand_scale(opt.operand_scale)      # 'data': fp16 operand scales from the data maxima (synthesis.py)
         assert self.engine.img_resolution == self.res, 'opt.img_resolution does not match the generator'
         assert self.engine.img_channels == len(self.modalities), 'one image channel per modality expected'
         self.num_ws, self.w_dim = self.engine.num_ws, self.engine.w_dim

@@ -95,6 +95,13 @@ class SynthesisEngine:
         self._lib = lib
         self.set_precision(precision)
 
+    def set_operand_scale(self, mode):
+        """f16x2 mode: 'bound' (default) takes the fp16 operand scale of the forward contractions from conv_clamp * max|style| -- no
+        pass over the data, float32-class while a layer's activations reach ~2^-16 of that bound (O(1e-2)) somewhere; 'data' takes it
+        from the data maxima (slower, no such limit)."""
+        _lib.check(self._lib.la_synth_set_operand_scale(self._h, {'bound': 0, 'data': 1}[mode]), 'la_synth_set_operand_scale')
+        self.operand_scale = mode
+
     def set_precision(self, precision):
         """'f32' exact fp32 MFMA | 'f16x2' scaled split-fp16, 3 MFMAs (fp32-class error) | 'bf16x3' split-bf16, 6 MFMAs
         (fp32-class error) | 'bf16x2' split-bf16, 3 MFMAs (approximate)."""
