@@ -29,40 +29,52 @@ def set_gpu_ids(gpu_ids):
     return out
 
 
+# The option surface is the contract with the reference's drivers (names, types, defaults: reference latent_aug.py:57-96); the help
+# texts are this package's own.  (flag, kwargs)
+_STR_OPTIONS = [
+    ('--gpu_ids_aug', dict(type=str, default='0', help='device index of the augmenter; one id per process (one rank per GPU). Negative / empty: no device, which this backend refuses')),
+    ('--dataset_aug', dict(metavar='DIR', default='Pelvis_2.1_repo_no_mask', help='dataset folder under model_dir / interim_dir')),
+    ('--dataset_name_aug', dict(metavar='DIR', default='Pelvis_2.1_repo_no_mask-num-375_train-0.70_val-0.20_test-0.10', help='name of the image zip and of the training-run folder')),
+    ('--modalities_aug', dict(metavar='DIR', default='MR_nonrigid_CT,MR_MR_T2', help='comma-separated modalities = image channels of the generator')),
+    ('--exp_stylegan', dict(metavar='DIR', default='00003', help='training-run prefix of the StyleGAN2 experiment')),
+    ('--network_pkl_stylegan', dict(metavar='DIR', default='network-snapshot-005320.pkl', help='network pickle inside that run (G_ema, D)')),
+    ('--dataset_w_name', dict(metavar='DIR', default='Pelvis_2.1_repo_no_mask-num-375_train-0.70_val-0.20_test-0.10-expinv_00001', help='zip of the inverted latents, one pickle per slice')),
+    ('--exp_inv', dict(metavar='DIR', default='00001', help='inversion experiment id (kept for command-line compatibility)')),
+    ('--network_pkl_inv', dict(metavar='DIR', default='', help='inversion network pickle (kept for command-line compatibility)')),
+]
+_NUM_OPTIONS = [
+    ('--img_resolution', int, 256, 'output resolution of the generator'),
+    ('--truncation_psi', float, 1.0, 'truncation of mapped latents (rand_aug / z inputs)'),
+    ('--step_img', int, 20, 'keep every n-th slice of a patient when the image bank is built'),
+    ('--step_w', int, 5, 'keep every n-th slice of a patient when the latent bank is built'),
+    ('--opt_num_epochs', int, 10, 'Adam steps on the latent per batch'),
+    ('--opt_lr', float, 0.01, 'Adam learning rate'),
+    ('--crop_size_aug', int, 64, 'side of the window the perceptual criterion looks at'),
+    ('--w_pix', float, 1.0, 'weight of the pixel-space distance to the image bank'),
+    ('--w_lpips', float, 1.0, 'weight of the perceptual distance to the feature bank'),
+    ('--w_latent', float, 1.0, 'weight of the latent-space distance to the latent bank'),
+    ('--w_disc', float, 1.0, 'weight of the discriminator (realism) term'),
+    ('--p_thres', float, 1.0, 'a batch is augmented when a uniform draw exceeds this value'),
+    ('--alpha', float, 1.0, 'soft_aug: weight of the moved latent in the blend with the inverted one'),
+]
+
+
 class LatentAugment(BaseAugment):
     @staticmethod
     def modify_commandline_options(parser, is_train):
-        parser.add_argument('--model_dir', help='Where to load the StyleGAN/MappingNetwork pretrained model', metavar='DIR', required=True)
-        parser.add_argument('--interim_dir', help='Where to save/load the data', metavar='DIR', required=True)
-        parser.add_argument('--gpu_ids_aug', type=str, default='0', help='gpu ids: e.g. 0  0,1,2, 0,2. use -1 for CPU')
-        parser.add_argument('--dataset_aug', help='', metavar='DIR', default="Pelvis_2.1_repo_no_mask")
-        parser.add_argument('--dataset_name_aug', help='', metavar='DIR', default="Pelvis_2.1_repo_no_mask-num-375_train-0.70_val-0.20_test-0.10")
-        parser.add_argument('--modalities_aug', help='', metavar='DIR', default="MR_nonrigid_CT,MR_MR_T2")
-        parser.add_argument('--img_resolution', help='Image resolution.', type=int, default=256)
-        parser.add_argument('--exp_stylegan', help='', metavar='DIR', default="00003")
-        parser.add_argument('--network_pkl_stylegan', help='', metavar='DIR', default="network-snapshot-005320.pkl")
-        parser.add_argument('--dataset_w_name', help='', metavar='DIR', default="Pelvis_2.1_repo_no_mask-num-375_train-0.70_val-0.20_test-0.10-expinv_00001")
-        parser.add_argument('--exp_inv', help='', metavar='DIR', default="00001")
-        parser.add_argument('--network_pkl_inv', help='', metavar='DIR', default="")
-        parser.add_argument('--truncation_psi', help='Truncation value.', type=float, default=1.0)
-        parser.add_argument('--rand_aug', action='store_true', help='Compute only random GAN augmentation.')
-        parser.add_argument('--lower_bound_clip', action='store_true', help='Clip the pixels values under -1 to -1.')
-        parser.add_argument('--step_img', help='Selection step to create the image dataset from which compute the distances.', type=int, default=20)
-        parser.add_argument('--step_w', help='Selection step to create the latent dataset from which compute the distances.', type=int, default=5)
-        parser.add_argument('--lpips_script', help='How to extract the features manifold.', type=str, default='lpips_script')
-        parser.add_argument('--opt_num_epochs', help='Number of optimization steps', type=int, default=10)
-        parser.add_argument('--opt_lr', help='Learning rate of optimization algorithm', type=float, default=0.01)
-        parser.add_argument('--init_w', help='Initialization point for latent codes [inv | random]', type=str, default='random')
-        parser.add_argument('--crop_size_aug', help='Size of the crop applied to images.', type=int, default=64)
-        parser.add_argument('--preprocess_aug', help='Type of preprocessing applied for augmentation pipeline [center_crop | random_crop | center_random_crop | original ]', type=str, default='center_random_crop')
-        parser.add_argument('--w_pix', help='Weight of recontruction loss', type=float, default=1.0)
-        parser.add_argument('--w_lpips', help='Weight of lpips loss', type=float, default=1.0)
-        parser.add_argument('--w_latent', help='Weight of latent loss', type=float, default=1.0)
-        parser.add_argument('--w_disc', help='Weight of discriminator loss.', type=float, default=1.0)
-        parser.add_argument('--p_thres', help='Augmentation probability.', type=float, default=1.0)
-        parser.add_argument('--soft_aug', help='Activate smooth augmentation via interpolation.', type=bool, default=False)
-        parser.add_argument('--alpha', help='Value for linear interpolation in soft_aug.', type=float, default=1.0)
-        parser.add_argument('--verbose_log', help='Print losses and time during the optimization process.', type=bool, default=False)
+        parser.add_argument('--model_dir', metavar='DIR', required=True, help='root of the pretrained networks (training-runs/...; a local vgg16.pt is looked up here)')
+        parser.add_argument('--interim_dir', metavar='DIR', required=True, help='root of the interim zips and of the bank cache')
+        for flag, kw in _STR_OPTIONS:
+            parser.add_argument(flag, **kw)
+        for flag, typ, default, text in _NUM_OPTIONS:
+            parser.add_argument(flag, type=typ, default=default, help=text)
+        parser.add_argument('--rand_aug', action='store_true', help='no optimisation: images of freshly mapped random z')
+        parser.add_argument('--lower_bound_clip', action='store_true', help='clamp output pixels at -1 from below')
+        parser.add_argument('--lpips_script', type=str, default='lpips_script', help="perceptual net: 'lpips_script' = the TorchScript vgg16.pt")
+        parser.add_argument('--init_w', type=str, default='random', help="start latent of the optimisation: 'inv' (inverted latent of the slice)")
+        parser.add_argument('--preprocess_aug', type=str, default='center_random_crop', help='window policy of the perceptual criterion: center_crop | random_crop | center_random_crop | original')
+        parser.add_argument('--soft_aug', type=bool, default=False, help='return a blend of the inverted and the moved latent (see --alpha)')
+        parser.add_argument('--verbose_log', type=bool, default=False, help='log losses / times of the first batch and write its snapshots')
         return parser
 
     def __init__(self, opt):
@@ -100,80 +112,82 @@ class LatentAugment(BaseAugment):
 
     @staticmethod
     def input_sanity_check(img):
-        assert isinstance(img, torch.Tensor)
-        assert img.dtype == torch.float32
-        assert img.shape == (1, 256, 256)
+        ok = isinstance(img, torch.Tensor) and img.dtype == torch.float32 and tuple(img.shape) == (1, 256, 256)
+        assert ok, 'expected one float32 [1, 256, 256] slice per modality'
 
     output_sanity_check = input_sanity_check
 
+    # ---- the dict protocol of the reference's drivers (reference :171-235)
     def set_input(self, data):
-        assert data['A_paths'] == data['B_paths']
-        self.real_A = data['A']
-        self.real_B = data['B']
-        self.fname = data['A_paths']
-        self.real_AB = torch.cat((self.real_A, self.real_B), dim=1)
+        """data = {'A', 'B': [B,1,r,r] float32 host tensors, 'A_paths', 'B_paths': per-sample file names (identical lists)}."""
+        paths = data['A_paths']
+        assert paths == data['B_paths'], 'paired modalities must come from the same slices'
+        self.fname = paths
+        self.real_A, self.real_B = data['A'], data['B']
+        self.real_AB = torch.cat([self.real_A, self.real_B], dim=1)
 
     def get_output(self):
-        real_AB_aug = self.real_AB_aug.detach().cpu()
-        real_A_aug = real_AB_aug[:, 0, :, :].unsqueeze(dim=1)
-        real_B_aug = real_AB_aug[:, 1, :, :].unsqueeze(dim=1)
-        if self.lower_bound_clip:
-            if real_A_aug.min().item() < -1:
-                real_A_aug = torch.clamp(real_A_aug, min=-1.0, max=None)
-            if real_B_aug.min().item() < -1:
-                real_B_aug = torch.clamp(real_B_aug, min=-1.0, max=None)
-        return {'A': real_A_aug, 'B': real_B_aug, 'A_paths': self.fname, 'B_paths': self.fname}
+        """The augmented pair on the host, one [B,1,r,r] tensor per modality, with the paths handed in."""
+        both = self.real_AB_aug.detach().cpu()
+        out = {}
+        for key, ch in (('A', 0), ('B', 1)):
+            plane = both[:, ch:ch + 1]
+            if self.lower_bound_clip and float(plane.min()) < -1:
+                plane = plane.clamp(min=-1.0)
+            out[key] = plane
+        out['A_paths'] = out['B_paths'] = self.fname
+        return out
+
+    def _latent_dict(self, w):
+        return {'w': w.detach().cpu().numpy().squeeze(), 'paths': '' if self.rand_aug else self.fname}
 
     def get_latent_output(self):
-        w_aug = reverse_broadcasting(self.w_AB_aug).detach().cpu().numpy().squeeze()
-        return {'w': w_aug, 'paths': self.fname if not self.rand_aug else ''}
+        return self._latent_dict(reverse_broadcasting(self.w_AB_aug))
 
     def get_latent_input(self):
-        w = self.w_AB.detach().cpu().numpy().squeeze()
-        return {'w': w, 'paths': self.fname if not self.rand_aug else ''}
+        return self._latent_dict(self.w_AB)
 
     def forward(self):
-        since = time.time()
-        if random.random() > self.p_thres and self.phase == 'train':
-            if self.rand_aug:
-                w_AB = self.sample_from_randn().to(self.device)
-                self.real_AB_aug, self.w_AB_aug = self.latent_aug.forward_ganrand(w_AB)
-                self.w_AB = self.w_AB_aug
-            else:
-                if self.init_w == 'inv':
-                    self.w_AB = self.sample_from_inversion(self.fname)
-                else:
-                    raise NotImplementedError
-                self.w_AB = self.w_AB.to(self.device)
-                self.real_AB_aug, self.w_AB_aug = self.latent_aug(self.w_AB, self.fname)
+        """One batch: with probability 1 - p_thres (training phase only) the latent optimisation, otherwise the inputs unchanged;
+        the wall time of the call is appended to stats_time either way (the drivers average stats_time[1:])."""
+        t0 = time.time()
+        u = random.random()                      # drawn in every phase, as in the reference: the python RNG stream stays aligned
+        augment = u > self.p_thres and self.phase == 'train'
+        if not augment:
+            self.real_AB_aug = torch.cat([self.real_A, self.real_B], dim=1)
+        elif self.rand_aug:
+            z = self.sample_from_randn().to(self.device)
+            self.real_AB_aug, self.w_AB_aug = self.latent_aug.forward_ganrand(z)
+            self.w_AB = self.w_AB_aug
         else:
-            self.real_AB_aug = torch.cat((self.real_A, self.real_B), dim=1)
+            if self.init_w != 'inv':
+                raise NotImplementedError(f"init_w = {self.init_w!r}: only 'inv' (the inverted latent of each slice) is defined")
+            self.w_AB = self.sample_from_inversion(self.fname).to(self.device)
+            self.real_AB_aug, self.w_AB_aug = self.latent_aug(self.w_AB, self.fname)
         if self.device.type == 'cuda':
             torch.cuda.synchronize(self.device)
-        time_elapsed = time.time() - since
+        dt = time.time() - t0
         if self.verbose_log:
-            print('Augmentation completed in {:.0f}m {:.3f}s'.format(time_elapsed // 60, time_elapsed % 60))
-        self.stats_time.append(time_elapsed)
+            print('Augmentation completed in {:.0f}m {:.3f}s'.format(dt // 60, dt % 60))
+        self.stats_time.append(dt)
 
     def sanity_check(self):
-        self.input_sanity_check(self.real_A[0])
-        self.input_sanity_check(self.real_B[0])
+        for t in (self.real_A[0], self.real_B[0]):
+            self.input_sanity_check(t)
         self.forward()
-        data = self.get_output()
-        self.output_sanity_check(data['A'][0])
-        self.output_sanity_check(data['B'][0])
+        out = self.get_output()
+        for key in ('A', 'B'):
+            self.output_sanity_check(out[key][0])
 
     def sample_from_randn(self):
         return torch.randn([self.batch_size, self.z_dim])
 
     def sample_from_inversion(self, fname):
         """Per-file inverted latent -> [len(fname), 1, w_dim] (reference :310-324; sized by the actual batch)."""
-        w = torch.empty([len(fname), self.num_ws, self.w_dim], dtype=torch.float32)
-        for i, fn in enumerate(fname):
-            out_w = np.asarray(self.stats_dataset_w.lookup(fn), dtype=np.float32)
-            if out_w.ndim == 1:
-                out_w = np.broadcast_to(out_w[None], (self.num_ws, self.w_dim))
-            w[i] = torch.from_numpy(np.ascontiguousarray(out_w))
-        w = reverse_broadcasting(w)
+        rows = []
+        for fn in fname:
+            code = np.asarray(self.stats_dataset_w.lookup(fn), dtype=np.float32)
+            rows.append(code.reshape(-1, self.w_dim)[:1])          # W space: row 0 of a [num_ws, w_dim] code, or the [w_dim] code itself
+        w = torch.from_numpy(np.ascontiguousarray(np.stack(rows)))
         assert w.shape == (len(fname), 1, self.w_dim)
         return w

@@ -8,10 +8,6 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef LA_NOSTORE
-#define LA_NOSTORE 0      // dev builds only: drop the fast-path output stores of the FWD / RAW epilogue (ablation; wrong results)
-#endif
-
 #define NT 128
 
 __device__ __forceinline__ float la_conv_epi_fwd(const LaConvArgs& a, float v, float dmv, float nz, float bv) {
@@ -320,7 +316,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                         v *= a.gain;
                         v = fminf(fmaxf(v, -cl), cl);
                     }
-                    if (!LA_NOSTORE || v == 1.2345e30f) o0[(long)mr * HWo + np[j]] = v;
+                    o0[(long)mr * HWo + np[j]] = v;
                     if (o2) o2[(long)mr * HWo + np[j]] = v + (ad ? ad[(long)mr * HWo + np[j]] : 0.f);
                     if (rgbc > 0) {
 #pragma unroll

@@ -64,6 +64,29 @@ def _preproc3(p):
     return scale, shift
 
 
+def write_curve_png(path, values, width=480, height=320, margin=24):
+    """Line plot of a sequence as an 8-bit greyscale PNG: frame, polyline, nothing else (the reference draws its per-key curves
+    with matplotlib, snapshot_stats :620-633; matplotlib is not a dependency here, so there are no tick labels or legend --
+    the numbers are in the .jsonl next to the picture)."""
+    v = np.asarray(list(values), dtype=np.float64)
+    img = np.full([height, width], 255, dtype=np.uint8)
+    x0, x1, y0, y1 = margin, width - margin - 1, margin, height - margin - 1
+    img[y0, x0:x1 + 1] = img[y1, x0:x1 + 1] = 0
+    img[y0:y1 + 1, x0] = img[y0:y1 + 1, x1] = 0
+    if v.size:
+        lo, hi = float(np.nanmin(v)), float(np.nanmax(v))
+        span = hi - lo if hi > lo else 1.0
+        xs = np.full(v.size, (x0 + x1) // 2) if v.size == 1 else np.round(x0 + 4 + (x1 - x0 - 8) * np.arange(v.size) / (v.size - 1)).astype(int)
+        ys = np.round(y1 - 4 - (y1 - y0 - 8) * (np.nan_to_num(v, nan=lo) - lo) / span).astype(int)
+        for i in range(v.size):
+            img[max(ys[i] - 2, 0):ys[i] + 3, max(xs[i] - 2, 0):xs[i] + 3] = 0          # marker
+            if i + 1 < v.size:
+                n = int(max(abs(xs[i + 1] - xs[i]), abs(ys[i + 1] - ys[i]), 1))
+                for t in range(n + 1):                                                 # segment, one pixel per step along the longer axis
+                    img[int(round(ys[i] + (ys[i + 1] - ys[i]) * t / n)), int(round(xs[i] + (xs[i + 1] - xs[i]) * t / n))] = 64
+    write_png_gray(path, img)
+
+
 def shard_bounds(batch, world_size, rank):
     """Contiguous sample range of a rank: [rank*b, (rank+1)*b) with b = ceil(batch / world_size)."""
     per = (batch + world_size - 1) // world_size
@@ -409,7 +432,10 @@ class LatentAug:
         if self.save_dir and self.num_epochs > 0:
             os.makedirs(self.save_dir, exist_ok=True)
             for stats, title in ((self.stats_loss, 'losses'), (self.stats_time, 'times [s]')):
-                with open(os.path.join(self.save_dir, f'{title}.jsonl'), 'w') as f:      # (the reference's per-key PNG plots need matplotlib)
+                ticks = list(stats.values())
+                for key in ticks[0].keys():      # one curve per logged quantity, named as snapshot_stats names them (:620-633)
+                    write_curve_png(os.path.join(self.save_dir, f'{title}_{key}.png'), [x[key] for x in ticks])
+                with open(os.path.join(self.save_dir, f'{title}.jsonl'), 'w') as f:
                     f.write(json.dumps(stats, indent=2) + '\n')
             if trace and 'w' in trace and fname:      # snapshots only with a batch of one (:292-295)
                 base = os.path.splitext(os.path.basename(str(fname[0])))[0]

@@ -183,3 +183,24 @@ def test_torchscript_vgg16_mapping(tmp_path):
     m = torch.jit.script(torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1)))
     with pytest.raises(_lib.LatentAugHipError):
         vgg16_from_torchscript(m)
+
+
+def test_curve_png_writer(tmp_path):
+    """The verbose_log curves (reference snapshot_stats, util_latent_aug.py:620-633) without matplotlib: a valid greyscale PNG whose
+    polyline rises where the values rise."""
+    import struct
+    import zlib
+    import numpy as np
+    from latentaugment_amd.latent_aug import write_curve_png
+    path = tmp_path / 'losses_loss.png'
+    write_curve_png(str(path), [0.0, 1.0, 4.0, 9.0])
+    blob = open(path, 'rb').read()
+    assert blob[:8] == b'\x89PNG\r\n\x1a\n'
+    w, h = struct.unpack('>II', blob[16:24])
+    n = struct.unpack('>I', blob[33:37])[0]
+    img = np.frombuffer(zlib.decompress(blob[41:41 + n]), np.uint8).reshape(h, w + 1)[:, 1:]
+    dark = np.argwhere(img[30:-30, 30:-30] == 0)                      # the markers (frame excluded)
+    first, last = dark[dark[:, 1] < 40], dark[dark[:, 1] > dark[:, 1].max() - 10]
+    assert first[:, 0].mean() > last[:, 0].mean() + 100           # image rows grow downwards: the last value sits far above the first
+    write_curve_png(str(path), [3.0])                              # a single epoch still gives a picture
+    write_curve_png(str(path), [])
