@@ -86,6 +86,8 @@ def parse():
     p.add_argument('--preset', default='B', choices=['B', 'E'],
                    help="B: BASELINE.json configs[1] (the metric's config). E: configs[4] per-GPU shape -- config-e 256^2, all four "
                         "criteria at the authors' weights (w_lpips 10, w_pix 0.1, w_latent 0.001, w_disc 0.01), Pelvis-scale banks")
+    p.add_argument('--operand-scale', default='bound', choices=['bound', 'data'],
+                   help="f16x2: fp16 operand scale of the forward contractions from the clamp bound (default) or from the data maxima")
     p.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured step')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true', help='skip the HIP-event leg (used under rocprofv3)')
@@ -110,7 +112,7 @@ def make_opt(args, local_rank, global_batch):
         truncation_psi=1.0, w_pix=args.w_pix, w_lpips=args.w_lpips, w_latent=args.w_latent, w_disc=args.w_disc, crop_size_aug=64,
         preprocess_aug='center_random_crop', soft_aug=False, alpha=1.0, verbose_log=False, rand_aug=False,
         lower_bound_clip=False, p_thres=0.0, init_w='inv', criterion_mode=args.criterion_mode, final_noise_mode='random',
-        precision=args.precision, hip_graph=not args.no_graph)
+        precision=args.precision, hip_graph=not args.no_graph, operand_scale=args.operand_scale)
 
 
 def cpu_model():
@@ -357,7 +359,7 @@ def main():
         'config': {'workload': f'SG2 config-{"f" if args.channel_base == 32768 else "e"} {args.res}x{args.res} 2-ch, '
                                f'random-init G, batch={args.batch}/GPU, {args.latent_steps} latent steps, '
                                f'w_latent={args.w_latent:g} w_pix={args.w_pix:g} w_disc={args.w_disc:g} w_lpips={args.w_lpips:g} '
-                               f'(M_w={args.M_w}, M_x={args.M_x}), contraction={args.precision}, '
+                               f'(M_w={args.M_w}, M_x={args.M_x}), contraction={args.precision}' + (', operand scale from data maxima' if args.operand_scale == 'data' else '') + ', '
                                f'timed call = set_input + LatentAugment.forward + get_output, '
                                f'launch mode = {"eager" if args.no_graph else "captured step replayed (hipGraph)"}',
                    'global_batch': gb, 'parallelism': f'dp{world}'},
