@@ -86,8 +86,8 @@ def parse():
     p.add_argument('--preset', default='B', choices=['B', 'E'],
                    help="B: BASELINE.json configs[1] (the metric's config). E: configs[4] per-GPU shape -- config-e 256^2, all four "
                         "criteria at the authors' weights (w_lpips 10, w_pix 0.1, w_latent 0.001, w_disc 0.01), Pelvis-scale banks")
-    p.add_argument('--operand-scale', default='bound', choices=['bound', 'data'],
-                   help="f16x2: fp16 operand scale of the forward contractions from the clamp bound (default) or from the data maxima")
+    p.add_argument('--operand-scale', default='auto', choices=['auto', 'bound', 'data'],
+                   help="f16x2: fp16 operand scale of the forward contractions: from the clamp bound, from the data maxima, or (default, as the plugin) calibrated once on the first batch")
     p.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured step')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true', help='skip the HIP-event leg (used under rocprofv3)')
