@@ -887,14 +887,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             else if (c + 1 < ck_end) { ++c; t = 0; }
         };
         bf16x8 acur[2][NTERM][TM], anxt[2][NTERM][TM], bf0[NTERM][NJ], bf1[NTERM][NJ];
-        load_b(c1, t1);
-        load_a(c1, t1, 0, acur[0]);
-        load_a(c1, t1, 1, acur[1]);
+        // (prologue in the loop's issue order -- pixel loads of the step after next, then the weight loads -- so that the loop's
+        //  waits are exact counts on both of its entries: see the three-wave form above)
+        const int c0 = c1, t0 = t1;
+        load_b(c0, t0);
         adv(c1, t1);                                   // (c1, t1) = step 1
         int c2 = c1, t2 = t1;
         write_b(smem);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
         load_b(c1, t1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(c0, t0, 0, acur[0]);
+        load_a(c0, t0, 1, acur[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
         adv(c2, t2);                                   // (c2, t2) = step 2
 #pragma unroll 1
         for (int s = 0; s < nstep; ++s) {
