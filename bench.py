@@ -359,7 +359,7 @@ def main():
         'config': {'workload': f'SG2 config-{"f" if args.channel_base == 32768 else "e"} {args.res}x{args.res} 2-ch, '
                                f'random-init G, batch={args.batch}/GPU, {args.latent_steps} latent steps, '
                                f'w_latent={args.w_latent:g} w_pix={args.w_pix:g} w_disc={args.w_disc:g} w_lpips={args.w_lpips:g} '
-                               f'(M_w={args.M_w}, M_x={args.M_x}), contraction={args.precision}' + (', operand scale from data maxima' if args.operand_scale == 'data' else '') + ', '
+                               f'(M_w={args.M_w}, M_x={args.M_x}), contraction={args.precision}' + (f', fp16 operand scale = {aug.latent_aug.engine.operand_scale}' + (f' (first batch: activations reach {aug.latent_aug.engine.calibration:.1e} of the clamp bound)' if getattr(aug.latent_aug.engine, 'calibration', None) is not None else '') if args.precision == 'f16x2' else '') + ', '
                                f'timed call = set_input + LatentAugment.forward + get_output, '
                                f'launch mode = {"eager" if args.no_graph else "captured step replayed (hipGraph)"}',
                    'global_batch': gb, 'parallelism': f'dp{world}'},

@@ -385,8 +385,8 @@ class LatentAug:
         if self._scale_mode == 'auto':      # once, on the first batch, before the step is captured
             mode = self.engine.calibrate_operand_scale(w)
             if mode == 'data':
-                print(f'[latentaugment_amd] forward fp16 operand scales taken from the data maxima: the latent gradient under the clamp-bound scale '
-                      f'differed by {self.engine.calibration:.1e} of its maximum on the first batch (small activations)')
+                print(f'[latentaugment_amd] forward fp16 operand scales taken from the data maxima: on the first batch the activations reach only '
+                      f'{self.engine.calibration:.1e} of the clamp bound (small activations; the a-priori scale needs 4.9e-04)')
             self._scale_mode = mode
         img = torch.empty([b, self.engine.img_channels, self.res, self.res], device=self.device, dtype=torch.float32)
         w_aug = torch.empty([b, self.num_ws, self.w_dim], device=self.device, dtype=torch.float32)
