@@ -94,6 +94,9 @@ def parse():
     p.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                    help="'gloo' + --force-device rehearses the multi-rank path on a 1-GPU box (collective staged through host)")
     p.add_argument('--force-device', type=int, default=-1, help='rehearsal only: every rank uses this device index')
+    p.add_argument('--force-dist', action='store_true',
+                   help='rehearsal only: with ONE rank under a launcher, still create the process group and take the sharded path '
+                        '(broadcast, shard, all_gather, barrier, max-reduce) -- the RCCL calls of the N-rank run on a 1-GPU box')
     return p.parse_args()
 
 
@@ -285,7 +288,11 @@ def main():
         local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if args.force_dist:
+        os.environ['LATENTAUG_FORCE_SHARDED'] = '1'
+        os.environ.setdefault('MASTER_PORT', '29533'); os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if args.dist_backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)      # nccl == RCCL on ROCm
@@ -326,7 +333,7 @@ def main():
         return aug.get_output()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -340,7 +347,7 @@ def main():
     barrier()
     elapsed = time.time() - t0
     assert out['A'].shape == (gb, 1, args.res, args.res)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev if args.dist_backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -370,7 +377,7 @@ def main():
         line['cpu_baseline'] = cpu_baseline(sd, meta, args)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -95,6 +95,15 @@ def shard_bounds(batch, world_size, rank):
     return lo, hi, per
 
 
+def sharded(group=None):
+    """True where forward() shards the batch over a process group: an initialised group of more than one rank.  (A group of ONE rank
+    takes the same path -- broadcast, shard, all_gather -- when LATENTAUG_FORCE_SHARDED=1: the RCCL rehearsal of a 1-GPU box.)"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get('LATENTAUG_FORCE_SHARDED') == '1'
+
+
 def gather_shards(local, per, batch, group=None):
     """ONE all_gather of equally padded shards -> the full batch on every rank (the reference gathers to gpu_ids[0])."""
     import torch.distributed as dist
@@ -192,7 +201,7 @@ class LatentAug:
         max_local = self.batch_size
         try:
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            if sharded(group):
                 max_local = (self.batch_size + dist.get_world_size(group) - 1) // dist.get_world_size(group)
         except (RuntimeError, ValueError):
             pass
@@ -476,7 +485,7 @@ class LatentAug:
         # criterion consumes it, but the draw is kept so the python RNG stream matches the reference's.
         self.crop_params = get_params(self.res, self.crop_size, self.preprocess)
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if sharded(self.group):
             B = w.shape[0]
             rank = dist.get_rank(self.group)
             lo, hi, per = shard_bounds(B, dist.get_world_size(self.group), rank)
@@ -548,7 +557,7 @@ class LatentAug:
     def forward_ganrand(self, z, noises=None):
         """reference :202-205: w_aug = G.mapping(z, c=None, truncation_psi); img = G.synthesis(w_aug)  (rand_aug mode)."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if sharded(self.group):
             # rand_aug with a process group: per-rank capacity is the shard (constructor), so the batch is sharded exactly as in
             # forward() -- rank 0's z is the batch's (the reference draws it once on the host, latent_aug.py:306-308), rank k maps and
             # synthesises samples [k*b, (k+1)*b), ONE all_gather returns image + latent to every rank
