@@ -55,6 +55,7 @@ CONTRACTION = {
                    'approximate mode)', mfma_per_product=3),
 }
 # launch-profiler classes (include/latentaug_hip.h, la_prof_end_classes)
+LAUNCH_MODES = {1: 'captured step replayed (hipGraph)', 0: 'eager', -1: 'eager (step capture refused by the runtime)'}
 CLASSES = ['conv_halo', 'conv_flat', 'conv_splitk', 'conv_f32', 'operand_prep', 'fir', 'seam_bwd', 'torgb_fwd', 'bank']
 CLASS_KERNELS = {
     'conv_halo': 'la_conv_bf16_halo_kernel (stride-1 3x3 layers >= 64^2, fp32 input read directly)',
@@ -368,7 +369,7 @@ def main():
                                f'w_latent={args.w_latent:g} w_pix={args.w_pix:g} w_disc={args.w_disc:g} w_lpips={args.w_lpips:g} '
                                f'(M_w={args.M_w}, M_x={args.M_x}), contraction={args.precision}' + (f', fp16 operand scale = {aug.latent_aug.engine.operand_scale}' + (f' (first batch: activations reach {aug.latent_aug.engine.calibration:.1e} of the clamp bound)' if getattr(aug.latent_aug.engine, 'calibration', None) is not None else '') if args.precision == 'f16x2' else '') + ', '
                                f'timed call = set_input + LatentAugment.forward + get_output, '
-                               f'launch mode = {"eager" if args.no_graph else "captured step replayed (hipGraph)"}',
+                               'launch mode = ' + LAUNCH_MODES[aug.latent_aug.graph_state],
                    'global_batch': gb, 'parallelism': f'dp{world}'},
     }
     if roof is not None:

@@ -283,6 +283,9 @@ int la_latent_opt_set_crop_pos(la_latent_opt* h, int x, int y);
  * after its first eager execution and replayed for every further step and batch of the same size -- the loop is ~230 short
  * launches per step and otherwise host-launch-bound at small batches.  0: every launch eager.  Results are identical. */
 int la_latent_opt_set_graph(la_latent_opt* h, int enable);
+/* 1: a captured step is being replayed; 0: eager launches (as asked / nothing run yet); -1: eager because the runtime refused the
+   capture of the step.  (No reference counterpart: the reference loop is eager PyTorch, util_latent_aug.py:240-300.) */
+int la_latent_opt_graph_state(const la_latent_opt* h);
 /* Per-step snapshots for the reference's verbose_log (util_latent_aug.py:292-295 snap_w / snap_img): device buffers (or NULL)
  * w_trace [steps][B][w_dim] = the optimised latent after every step, img_trace [steps][B][C][R][R] = the image synthesised in
  * every step.  While either is set the loop launches eagerly. */

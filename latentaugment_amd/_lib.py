@@ -108,6 +108,7 @@ SIGNATURES = {
     'la_latent_opt_set_lpips': (_I, [_P, _P, _P, _L, _I, _F, _F, _P, _Z]),
     'la_latent_opt_set_crop_pos': (_I, [_P, _I, _I]),
     'la_latent_opt_set_graph': (_I, [_P, _I]),
+    'la_latent_opt_graph_state': (_I, [_P]),
     'la_latent_opt_set_trace': (_I, [_P, _P, _P]),
     'la_latent_opt_set_grad_trace': (_I, [_P, _P]),
     'la_latent_opt_set_lpips_preproc': (_I, [_P, _P, _P, _I]),

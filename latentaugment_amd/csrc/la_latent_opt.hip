@@ -37,6 +37,7 @@ struct la_latent_opt {
     float* trace_dw;        // optional [steps][B][w_dim]: dL/dw of every step (la_latent_opt_set_grad_trace); forces eager launches
     int graph_mode;         // 0 eager, 1 replay a captured step (default)
     int graph_B;            // batch the captured step was built for (0: none)
+    int graph_refused;      // 1: stream capture / instantiation of the step failed once; the handle launches eagerly since
     hipGraph_t graph;
     hipGraphExec_t graph_exec;
     hipStream_t cap_stream; // capture needs a non-default stream; the replay goes to the caller's stream
@@ -139,9 +140,17 @@ extern "C" int la_latent_opt_invalidate_banks(la_latent_opt* h) {
     return LA_OK;
 }
 
+// 1: a captured step is instantiated and being replayed; 0: eager launches (as asked, or no batch has run yet); -1: eager because the
+// capture of the step was refused by the runtime (la_latent_opt_set_graph(h, 1) re-arms it)
+extern "C" int la_latent_opt_graph_state(const la_latent_opt* h) {
+    if (!h) return 0;
+    return h->graph_exec ? 1 : (h->graph_refused ? -1 : 0);
+}
+
 extern "C" int la_latent_opt_set_graph(la_latent_opt* h, int enable) {
     LA_CHECK_ARG(h, "latent_opt_set_graph: null handle");
     h->graph_mode = enable ? 1 : 0;
+    h->graph_refused = 0;
     if (!enable) drop_graph(h);
     return LA_OK;
 }
@@ -352,7 +361,7 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
             if (ok) ok = hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0) == hipSuccess;
         }
         if (ok) h->graph_B = B;
-        else { drop_graph(h); (void)hipGetLastError(); if (c.steps >= 2) h->graph_mode = 0; }
+        else { drop_graph(h); (void)hipGetLastError(); if (c.steps >= 2) { h->graph_mode = 0; h->graph_refused = 1; } }
     }
     for (int step = first_graph_step; step <= c.steps; ++step) {
         if (replay && h->graph_exec && h->graph_B == B) LA_HIP(hipGraphLaunch(h->graph_exec, stream));

@@ -540,6 +540,12 @@ class LatentAug:
         self._log_first_batch(losses, time.time() - t0, trace, fname)
         return img, w_aug
 
+    @property
+    def graph_state(self):
+        """1: the optimisation step is replayed from a captured hipGraph; 0: eager launches (`opt.hip_graph = False`, or no batch has
+        run yet); -1: eager because the runtime refused the capture."""
+        return int(self._lib.la_latent_opt_graph_state(self._h))
+
     __call__ = forward
 
     @property
