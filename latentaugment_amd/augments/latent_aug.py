@@ -124,11 +124,23 @@ class LatentAugment(BaseAugment):
         assert paths == data['B_paths'], 'paired modalities must come from the same slices'
         self.fname = paths
         self.real_A, self.real_B = data['A'], data['B']
-        self.real_AB = torch.cat([self.real_A, self.real_B], dim=1)
+
+    @property
+    def real_AB(self):
+        """The unaugmented pair as one [B,2,r,r] tensor (reference :189); joined on demand -- the augmenting branch never reads it."""
+        return torch.cat([self.real_A, self.real_B], dim=1)
 
     def get_output(self):
         """The augmented pair on the host, one [B,1,r,r] tensor per modality, with the paths handed in."""
-        both = self.real_AB_aug.detach().cpu()
+        both = self.real_AB_aug.detach()
+        if both.is_cuda:
+            # page-locked staging (torch's caching host allocator hands the block back once the caller drops the result): the
+            # copy of a full gathered batch runs at the PCIe rate instead of the pageable one, which every rank of an N-rank run
+            # pays N-fold -- each returns the WHOLE batch, as the reference's DataParallel gather does
+            host = torch.empty(both.shape, dtype=both.dtype, pin_memory=True)
+            host.copy_(both, non_blocking=True)
+            torch.cuda.synchronize(both.device)
+            both = host
         out = {}
         for key, ch in (('A', 0), ('B', 1)):
             plane = both[:, ch:ch + 1]
@@ -154,7 +166,7 @@ class LatentAugment(BaseAugment):
         u = random.random()                      # drawn in every phase, as in the reference: the python RNG stream stays aligned
         augment = u > self.p_thres and self.phase == 'train'
         if not augment:
-            self.real_AB_aug = torch.cat([self.real_A, self.real_B], dim=1)
+            self.real_AB_aug = self.real_AB
         elif self.rand_aug:
             z = self.sample_from_randn().to(self.device)
             self.real_AB_aug, self.w_AB_aug = self.latent_aug.forward_ganrand(z)

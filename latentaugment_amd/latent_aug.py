@@ -118,17 +118,36 @@ def gather_shards(local, per, batch, group=None):
     return out[:batch].to(dev)
 
 
-def broadcast_controls(crop_pos, group=None, device=None):
+def broadcast_controls(crop_pos, group=None, device=None, host_group=None):
     """Rank 0's per-forward host draws -- (crop x, crop y, 48-bit seed of the final-synthesis noise) -- to every rank of the
-    group.  Control plane only (three integers through the host); the data path keeps its single all_gather."""
+    group.  Control plane only (three integers through the host); the data path keeps its single all_gather.  `host_group`: a gloo
+    group over the same ranks.  Through an RCCL group the object broadcast reads its size back on the host, which waits for the
+    RCCL stream, which waits for everything this rank has queued: the previous batch drains before the next one is enqueued.  Over
+    the host group the ranks still meet here, but no GPU queue is involved and batches stay queued back to back."""
     import torch.distributed as dist
     ctl = [None]
     if dist.get_rank(group) == 0:
         ctl[0] = (int(crop_pos[0]), int(crop_pos[1]), random.getrandbits(48))
     src = dist.get_global_rank(group, 0) if group is not None else 0
+    if host_group is not None:
+        dist.broadcast_object_list(ctl, src=src, group=host_group, device=torch.device('cpu'))
+        return ctl[0]
     on_host = dist.get_backend(group) == 'gloo' or device is None
     dist.broadcast_object_list(ctl, src=src, group=group, device=torch.device('cpu') if on_host else device)
     return ctl[0]
+
+
+def host_control_group(group=None):
+    """A gloo group over the ranks of the default (RCCL) group, for broadcast_controls; None where the data group is gloo already, is
+    a sub-group (dist.new_group must be entered by EVERY process of the job, which only the default group guarantees here), or
+    LATENTAUG_CTL_DEVICE=1 asks for the device path.  Collective: every rank of the default group calls it at the same point (the
+    first sharded forward)."""
+    import torch.distributed as dist
+    if group is not None or dist.get_backend() == 'gloo' or os.environ.get('LATENTAUG_CTL_DEVICE') == '1':
+        return None
+    if not dist.is_gloo_available():
+        return None
+    return dist.new_group(backend='gloo')
 
 
 class InMemoryLatentCodes:
@@ -147,6 +166,7 @@ class LatentAug:
         self.save_dir = save_dir
         self.phase = phase
         self.group = group
+        self._ctl_group = None      # gloo companion of an RCCL group for the per-forward control broadcast (host_control_group)
         if not gpu_ids:
             raise _lib.LatentAugHipError(
                 'LatentAug (MI355X path) needs a GPU id in gpu_ids_aug; the CPU restatement lives in oracle/ and is '
@@ -491,16 +511,16 @@ class LatentAug:
             lo, hi, per = shard_bounds(B, dist.get_world_size(self.group), rank)
             # The reference draws ONE crop position per forward for the whole batch (:216) and one noise stream for the final
             # synthesis: rank 0's draws are the batch's (control plane: one tiny host-side broadcast of 3 integers; the data
-            # path still has exactly one collective).  Sample i's final noise is a function of (seed, i) only, so the gathered
-            # batch does not depend on how it was sharded.
-            cx, cy, noise_seed = broadcast_controls(self.crop_params['crop_pos'], self.group, self.device)
+            # path still has exactly one collective).  The final noise is a function of (seed, layer, global batch) only and a rank
+            # takes its rows of it, so the gathered batch does not depend on how it was sharded.
+            cx, cy, noise_seed = broadcast_controls(self.crop_params['crop_pos'], self.group, self.device, self._host_group())
             self._last_controls = (cx, cy, noise_seed)
             self.crop_params = {'crop_pos': (cx, cy)}
             if hi > lo:
                 if final_noises is not None:
                     fn = [t[lo:hi].contiguous() if t is not None else None for t in final_noises]
                 elif self._cfg.final_noise_mode == 2:
-                    fn = self.engine.make_noises(hi - lo, sample_seeds=[noise_seed + i for i in range(lo, hi)])
+                    fn = self.engine.make_noises(B, batch_seed=noise_seed, rows=(lo, hi))
                 else:
                     fn = None
                 if self._verbose_flag and rank == 0:
@@ -540,6 +560,11 @@ class LatentAug:
         self._log_first_batch(losses, time.time() - t0, trace, fname)
         return img, w_aug
 
+    def _host_group(self):
+        if self._ctl_group is None:      # once; False = none
+            self._ctl_group = host_control_group(self.group) or False
+        return self._ctl_group or None
+
     @property
     def graph_state(self):
         """1: the optimisation step is replayed from a captured hipGraph; 0: eager launches (`opt.hip_graph = False`, or no batch has
@@ -570,7 +595,7 @@ class LatentAug:
             B = z.shape[0]
             rank = dist.get_rank(self.group)
             lo, hi, per = shard_bounds(B, dist.get_world_size(self.group), rank)
-            _, _, noise_seed = broadcast_controls((0, 0), self.group, self.device)
+            _, _, noise_seed = broadcast_controls((0, 0), self.group, self.device, self._host_group())
             gloo = dist.get_backend(self.group) == 'gloo'
             zb = z.detach().to('cpu' if gloo else self.device, torch.float32).contiguous()
             dist.broadcast(zb, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
@@ -580,7 +605,7 @@ class LatentAug:
                 if noises is not None:
                     fn = [t[lo:hi].contiguous() if t is not None else None for t in noises]
                 elif self.final_noise_mode == 'random':
-                    fn = self.engine.make_noises(hi - lo, sample_seeds=[noise_seed + i for i in range(lo, hi)])
+                    fn = self.engine.make_noises(B, batch_seed=noise_seed, rows=(lo, hi))
                 else:
                     fn = None
                 img = self.engine.forward(ws, noise_mode=self.final_noise_mode, noises=fn)

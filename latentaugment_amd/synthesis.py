@@ -162,23 +162,25 @@ class SynthesisEngine:
     def handle(self):
         return self._h
 
-    def make_noises(self, batch, generator=None, sample_seeds=None):
+    def make_noises(self, batch, generator=None, batch_seed=None, rows=None):
         """Unit-variance noise tensors for noise_mode='random': one [B,res,res] per SynthesisLayer, None where the layer's
-        noise_strength is 0 (the term vanishes, nothing is drawn).  `sample_seeds` (one int per sample) makes sample i's noise
-        a function of its seed alone, so that a rank holding a shard of the batch draws what a single process would."""
+        noise_strength is 0 (the term vanishes, nothing is drawn).  With `batch_seed` the draw is a pure function of (seed, layer,
+        batch): one generator and one randn of the WHOLE batch per layer; `rows = (lo, hi)` returns samples lo..hi-1 of it, so that a
+        rank holding a shard of a batch of `batch` samples gets exactly the rows a single process would (one launch per layer,
+        whatever the shard: the per-sample generators of round 2 cost 2 launches per sample and layer on the host's critical path)."""
+        lo, hi = (0, batch) if rows is None else rows
+        assert 0 <= lo <= hi <= batch
         out = []
         for li, (r, ns) in enumerate(zip(self.layer_resolutions, self.noise_strengths)):
             if ns == 0.0:
                 out.append(None)
-            elif sample_seeds is None:
+            elif batch_seed is None:
+                assert rows is None
                 out.append(torch.randn([batch, r, r], device=self.device, generator=generator))
             else:
-                assert len(sample_seeds) == batch
-                t = torch.empty([batch, r, r], device=self.device)
-                for i, sd in enumerate(sample_seeds):
-                    g = torch.Generator(device=self.device).manual_seed((int(sd) * 64 + li) & 0x7FFFFFFFFFFFFFFF)
-                    t[i] = torch.randn([r, r], device=self.device, generator=g)
-                out.append(t)
+                g = torch.Generator(device=self.device).manual_seed((int(batch_seed) * 64 + li) & 0x7FFFFFFFFFFFFFFF)
+                t = torch.randn([batch, r, r], device=self.device, generator=g)
+                out.append(t if (lo, hi) == (0, batch) else t[lo:hi].contiguous())
         return out
 
     def noise_pointer_array(self, noises):
