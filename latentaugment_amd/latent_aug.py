@@ -137,7 +137,7 @@ def broadcast_controls(crop_pos, group=None, device=None, host_group=None):
     return ctl[0]
 
 
-def host_control_group(group=None):
+def host_control_group(group=None, device=None):
     """A gloo group over the ranks of the default (RCCL) group, for broadcast_controls; None where the data group is gloo already, is
     a sub-group (dist.new_group must be entered by EVERY process of the job, which only the default group guarantees here), or
     LATENTAUG_CTL_DEVICE=1 asks for the device path.  Collective: every rank of the default group calls it at the same point (the
@@ -147,7 +147,15 @@ def host_control_group(group=None):
         return None
     if not dist.is_gloo_available():
         return None
-    return dist.new_group(backend='gloo')
+    try:
+        g = dist.new_group(backend='gloo')
+    except Exception as e:       # (e.g. no usable network interface for gloo on this host)
+        print(f'[latentaugment_amd] no gloo control group ({type(e).__name__}: {e}); control broadcast stays on the device path')
+        g = None
+    # every rank must take the same path: agree over the data group that all of them got their host group
+    ok = torch.tensor([1 if g is not None else 0], device=device if device is not None else torch.device('cuda', torch.cuda.current_device()), dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return g if int(ok.item()) == 1 else None
 
 
 class InMemoryLatentCodes:
@@ -562,7 +570,7 @@ class LatentAug:
 
     def _host_group(self):
         if self._ctl_group is None:      # once; False = none
-            self._ctl_group = host_control_group(self.group) or False
+            self._ctl_group = host_control_group(self.group, self.device) or False
         return self._ctl_group or None
 
     @property
