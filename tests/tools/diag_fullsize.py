@@ -1,7 +1,7 @@
 """Dev tool: latent / image error of a full-size parity case against the float64 fixture, per contraction precision."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import test_hip_fullsize as T
 dev = torch.device('cuda', 0)

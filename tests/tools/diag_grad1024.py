@@ -1,7 +1,7 @@
 """Dev tool: per-ws-slot error of d(img.g)/d(ws) at 1024^2 (HIP per precision, and the CPU fp32 oracle) against the fp64 oracle."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from test_hip_synthesis import _oracle_grad
 from oracle import sg2_networks as nets

@@ -1,6 +1,6 @@
 """Diagnostic: d/dws at the config-f 512^2 shape -- HIP (f32, bf16x3) vs the oracle in fp32 and fp64."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from latentaugment_amd import synthetic
 from latentaugment_amd.synthesis import SynthesisEngine
 from oracle import sg2_networks as nets

@@ -1,13 +1,13 @@
 """Dev tool: graph replay vs eager, per criterion and per run index (which runs differ, by how much)."""
 import os, sys, types
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests'))
 from test_hip_synthesis import _opt, tiny_G, tiny_D
 from oracle import feature_net as fnets
 from oracle import latent_aug_ref as lar
 from latentaugment_amd.latent_aug import LatentAug
-gl = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'latent_loop.npz'))
+gl = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests', 'golden', 'latent_loop.npz'))
 dev = torch.device('cuda', 0)
 G, D = tiny_G(gl), tiny_D(gl)
 fnet = fnets.TinyFeatureNet(seed=5, crop=8)

@@ -1,7 +1,7 @@
 """Dev tool: first synthesis layer whose output diverges from the oracle (per-layer max error)."""
 import os, sys, ctypes as C
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from oracle import sg2_networks as nets
 from latentaugment_amd.synthesis import SynthesisEngine
