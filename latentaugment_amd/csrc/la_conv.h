@@ -128,6 +128,12 @@ size_t la_conv_split_pack_bytes(int M, int C, int ktaps);
 // a.in_q / a.acc_scale_x at it and advance a.ws / a.ws_bytes past it.  Callers that launch several phases over one input
 // call this once.  bf16: {hi | mid << 16, lo} (8 B / element);  fp16: per-sample power-of-two scale, {hi | lo << 16} (4 B).
 int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream);
+// Activation backward fused with the plane maxima of its result (pass 1 of the fp16 operand scale of the consuming contraction):
+// dx [B][C][HW] = dy * act'(yref) (dx may alias dy), pm [B][C][la_conv_act_grad_segments(HW)] -> LaConvArgs::in_pmax / in_pmax_nseg.
+// Replaces la_bias_act_grad_f32 (bias_act.py:170, grad = 1) where the result feeds a contraction.
+int la_conv_act_grad_segments(long HW);
+int la_conv_act_grad_pmax(const float* dy, const float* yref, float* dx, float* pm, int B, int C, long HW, int act, float alpha, float gain,
+                          float clamp, hipStream_t stream);
 int la_conv_xscale_from_pmax(const float* pmax, int nseg, const float* scale, int scale_stride, float mult, float* xscale, int B, int C,
                              hipStream_t stream);
 int la_absmax_bits(const float* w, long n, unsigned* amax_bits, hipStream_t stream);      // max |w| as a float bit pattern (zero it first)

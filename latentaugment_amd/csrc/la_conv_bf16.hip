@@ -194,6 +194,62 @@ __global__ __launch_bounds__(256) void la_plane_absmax_kernel(const float* __res
     if (threadIdx.x == 0) pm[((long)b * C + c) * ns + seg] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// Activation backward of the layer that produced `yref`, fused with pass 1 of the fp16 operand scale of the contraction that consumes
+// the result: dx = dy * act'(yref) and the segment maxima of |dx| in one sweep (the discriminator / feature-net backward passes ran
+// la_bias_act_grad_f32, la_plane_absmax_kernel and la_xscale_kernel for every backward contraction; now this kernel and
+// la_xscale_pmax_kernel).  Same grid and segment layout as la_plane_absmax_kernel; dx may alias dy.
+__global__ __launch_bounds__(256) void la_act_grad_pmax_kernel(const float* dy, const float* __restrict__ yref, float* dx,
+                                                              float* __restrict__ pm, int C, long HW, int ns, int act, float alpha,
+                                                              float gain, float clamp) {
+    __shared__ float red[4];
+    const int seg = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+    const long base = ((long)b * C + c) * HW;
+    const long per = ((HW + ns - 1) / ns + 3) & ~3l;
+    const long p0 = seg * per, p1 = p0 + per < HW ? p0 + per : HW;
+    float m = 0.f;
+    auto one = [&](float g, float y) { const float v = g * la_act_bwd_from_y(y, act, alpha, gain, clamp); m = fmaxf(m, fabsf(v)); return v; };
+    if (((((size_t)(dy + base)) | ((size_t)(yref + base)) | ((size_t)(dx + base)) | (size_t)(HW * 4)) & 15) == 0) {
+        const float4* g4 = reinterpret_cast<const float4*>(dy + base);
+        const float4* y4 = reinterpret_cast<const float4*>(yref + base);
+        float4* d4 = reinterpret_cast<float4*>(dx + base);
+        long q = p0 / 4 + threadIdx.x;
+        const long q1 = p1 / 4;
+        for (; q + 256 < q1; q += 512) {
+            const float4 ga = g4[q], gb = g4[q + 256], ya = y4[q], yb = y4[q + 256];
+            d4[q] = make_float4(one(ga.x, ya.x), one(ga.y, ya.y), one(ga.z, ya.z), one(ga.w, ya.w));
+            d4[q + 256] = make_float4(one(gb.x, yb.x), one(gb.y, yb.y), one(gb.z, yb.z), one(gb.w, yb.w));
+        }
+        for (; q < q1; q += 256) {
+            const float4 ga = g4[q], ya = y4[q];
+            d4[q] = make_float4(one(ga.x, ya.x), one(ga.y, ya.y), one(ga.z, ya.z), one(ga.w, ya.w));
+        }
+        for (long p = q1 * 4 + threadIdx.x; p < p1; p += 256) dx[base + p] = one(dy[base + p], yref[base + p]);
+    } else {
+        for (long p = p0 + threadIdx.x; p < p1; p += 256) dx[base + p] = one(dy[base + p], yref[base + p]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) pm[((long)b * C + c) * ns + seg] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+int la_conv_act_grad_segments(long HW) {
+    int ns = (int)(HW / 8192);
+    return ns < 1 ? 1 : (ns > PM_NS ? PM_NS : ns);
+}
+
+// dx [B][C][HW] = dy * act'(yref); pm [B][C][la_conv_act_grad_segments(HW)] = segment maxima of |dx| (-> LaConvArgs::in_pmax)
+int la_conv_act_grad_pmax(const float* dy, const float* yref, float* dx, float* pm, int B, int C, long HW, int act, float alpha, float gain,
+                          float clamp, hipStream_t stream) {
+    LA_CHECK_ARG(dy && yref && dx && pm && B >= 1 && C >= 1 && HW >= 1, "act_grad_pmax: bad arguments");
+    LA_CHECK_ARG(B <= 65535 && C <= 65535, "act_grad_pmax: grid too large");
+    const int ns = la_conv_act_grad_segments(HW);
+    hipLaunchKernelGGL(la_act_grad_pmax_kernel, dim3(ns, C, B), dim3(256), 0, stream, dy, yref, dx, pm, C, HW, ns, act, alpha, gain, clamp);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
 // per-sample power-of-two scale from the segment maxima: xscale[b] = pow2(max over the sample)
 __global__ __launch_bounds__(256) void la_xscale_kernel(const float* __restrict__ pm, float* __restrict__ xscale, int n) {
     __shared__ float red[4];

@@ -46,6 +46,7 @@ struct la_disc {
     DConv econv;                  // b4.conv: (C4 + 1) -> C4
     const float *fc_w, *fc_b, *out_w, *out_b;
     float *mb, *yc, *fc, *logits, *dlogits, *g_fc, *g_flat, *gA, *gB, *scrA, *scrB;
+    float* pm;              // plane maxima of the gradient entering a backward contraction (la_conv_act_grad_pmax)
     float fir[16];
     void* cws; size_t cws_bytes;
     float* xs_fwd;          // [maxB] constant fp16 operand scale of every FORWARD contraction input: with a clamp all of them are bounded
@@ -97,10 +98,12 @@ static int d_describe(la_disc* h, int R, int imgc, const int* channels, int maxB
 static size_t d_layout(la_disc* h, void* ws) {
     DCarver c{(char*)ws, 0};
     const size_t mb = h->maxB;
-    size_t gmax = 0, smax = 0, cw = 0;
+    size_t gmax = 0, smax = 0, cw = 0, pmax = 0;
     for (int k = 0; k < h->nblocks; ++k) {
         DBlock& b = h->blk[k];
         const size_t hw = (size_t)b.res * b.res, hq = hw / 4;
+        { const size_t p0 = mb * b.cin * la_conv_act_grad_segments((long)hw), p1 = mb * b.cout * la_conv_act_grad_segments((long)hq);
+          if (p0 > pmax) pmax = p0; if (p1 > pmax) pmax = p1; }
         dconv_layout(c, b.conv0); dconv_layout(c, b.conv1); dconv_layout(c, b.skip);
         if (k == 0) { b.xin = c.take(mb * b.cin * hw); b.frgb_wt = c.take((size_t)h->imgc * b.cin); }
         b.y0 = c.take(mb * b.cin * hw);
@@ -122,6 +125,7 @@ static size_t d_layout(la_disc* h, void* ws) {
     h->xs_fwd = c.take(mb);
     h->logits = c.take(mb); h->dlogits = c.take(mb); h->g_fc = c.take(mb * h->C4); h->g_flat = c.take(mb * (h->C4 + 1) * 16);
     h->gA = c.take(gmax); h->gB = c.take(gmax); h->scrA = c.take(smax); h->scrB = c.take(gmax);
+    h->pm = c.take(pmax);
     h->cws = c.take((cw + 3) / 4); h->cws_bytes = cw;
     return c.off;
 }
@@ -362,10 +366,10 @@ static void set_w(LaConvArgs& a, la_disc* h, const DConv& L, bool backward) {
 
 // dense conv (k = 3 pad 1, or k = 1) at one resolution, forward (with bias/act epilogue) or backward-data (plain)
 static int conv_same(la_disc* h, const DConv& L, bool backward, const float* in, float* out, int B, int res, int act, float gain,
-                     float clamp, const float* addend, float* out2, hipStream_t stream) {
+                     float clamp, const float* addend, float* out2, hipStream_t stream, const float* in_pmax = nullptr, int in_nseg = 0) {
     LaConvArgs a; cbase(a);
     set_w(a, h, L, backward);
-    a.in = in; a.out = out; a.B = B;
+    a.in = in; a.out = out; a.B = B; a.in_pmax = in_pmax; a.in_pmax_nseg = in_nseg;
     a.C = backward ? L.cout : L.cin; a.M = backward ? L.mb_ : L.cout;      // (padded channels of a backward come out as zeros)
     a.in_bstride = (long)a.C * res * res;
     a.Hin = a.Win = a.Hout = a.Wout = a.Gy = a.Gx = res;
@@ -473,16 +477,18 @@ extern "C" int la_disc_backward(la_disc* h, const float* dlogits, float* g_img, 
     for (int k = h->nblocks - 1; k >= 0; --k) {
         DBlock& b = h->blk[k];
         const int res = b.res, hq = res / 2;
-        const long nq = (long)B * b.cout * hq * hq, nf = (long)B * b.cin * res * res;
         // ---- conv1 branch: act' (gain 1, clamp*sqrt(1/2)) -> transposed stride-2 conv -> FIR adjoint (pad 1)
-        if ((rc = la_bias_act_grad_f32(g_sum, b.x1, h->scrB, nullptr, nq, 1, 1, LA_ACT_LRELU, 0.2f, sq2 * rs2,
-                                       h->clamp >= 0.f ? h->clamp * rs2 : -1.f, stream))) return rc;
+        // (every act' below also leaves the plane maxima of its result: the fp16 operand scale of the contraction that follows
+        //  then needs no absmax pass -- la_conv_act_grad_pmax)
+        const int nsq = la_conv_act_grad_segments((long)hq * hq), nsf = la_conv_act_grad_segments((long)res * res);
+        if ((rc = la_conv_act_grad_pmax(g_sum, b.x1, h->scrB, h->pm, B, b.cout, (long)hq * hq, LA_ACT_LRELU, 0.2f, sq2 * rs2,
+                                        h->clamp >= 0.f ? h->clamp * rs2 : -1.f, stream))) return rc;
         {
             LaConvArgs a; cbase(a);
             set_w(a, h, b.conv1, true);
             a.in = h->scrB; a.in_bstride = (long)b.cout * hq * hq; a.out = h->scrA;
             a.B = B; a.C = b.cout; a.M = b.cin; a.Hin = a.Win = hq; a.Hout = a.Wout = res + 1;
-            a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW;
+            a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW; a.in_pmax = h->pm; a.in_pmax_nseg = nsq;
             if (h->precision != LA_PREC_F32 && (rc = la_conv_prepare_input(a, stream))) return rc;   // split once for the four phases
             for (int py = 0; py < 2; ++py)
                 for (int px = 0; px < 2; ++px) {
@@ -496,11 +502,11 @@ extern "C" int la_disc_backward(la_disc* h, const float* dlogits, float* g_img, 
         }
         if ((rc = la_upfirdn2d_ex(h->scrA, other, B, b.cin, res + 1, res + 1, h->fir, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1.f, nullptr, stream))) return rc;
         // ---- conv0: act' then backward-data
-        if ((rc = la_bias_act_grad_f32(other, b.y0, other, nullptr, nf, 1, 1, LA_ACT_LRELU, 0.2f, sq2, h->clamp, stream))) return rc;
-        if ((rc = conv_same(h, b.conv0, true, other, h->scrA, B, res, 0, 0.f, 0.f, nullptr, nullptr, stream))) return rc;   // scrA >= B*cin*res^2
+        if ((rc = la_conv_act_grad_pmax(other, b.y0, other, h->pm, B, b.cin, (long)res * res, LA_ACT_LRELU, 0.2f, sq2, h->clamp, stream))) return rc;
+        if ((rc = conv_same(h, b.conv0, true, other, h->scrA, B, res, 0, 0.f, 0.f, nullptr, nullptr, stream, h->pm, nsf))) return rc;   // scrA >= B*cin*res^2
         // ---- skip branch: * sqrt(1/2) -> 1x1 adjoint -> FIR-down adjoint (up 2, pad (2,1,2,1), flipped), added to the conv branch
-        if ((rc = la_bias_act_grad_f32(g_sum, b.ysk, h->scrB, nullptr, nq, 1, 1, LA_ACT_LINEAR, 0.f, rs2, -1.f, stream))) return rc;
-        if ((rc = conv_same(h, b.skip, true, h->scrB, g_sum, B, hq, 0, 0.f, 0.f, nullptr, nullptr, stream))) return rc;       // reuse g_sum buffer: [B][cin][hq^2]
+        if ((rc = la_conv_act_grad_pmax(g_sum, b.ysk, h->scrB, h->pm, B, b.cout, (long)hq * hq, LA_ACT_LINEAR, 0.f, rs2, -1.f, stream))) return rc;
+        if ((rc = conv_same(h, b.skip, true, h->scrB, g_sum, B, hq, 0, 0.f, 0.f, nullptr, nullptr, stream, h->pm, nsq))) return rc;       // reuse g_sum buffer: [B][cin][hq^2]
         if ((rc = la_upfirdn2d_ex(g_sum, other, B, b.cin, hq, hq, h->fir, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1, 1, 1.f, h->scrA, stream))) return rc;
         // `other` now holds d/d(xin) of this block
         float* t = g_sum; g_sum = other; other = t;

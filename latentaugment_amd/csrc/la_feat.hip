@@ -34,6 +34,7 @@ struct la_feat {
     int nops, in_ch, in_res, maxN, F, precision;
     FOp op[FEAT_MAX_OPS];
     float *gA, *gB;
+    float* pm;           // plane maxima of the gradient entering a backward contraction (la_conv_act_grad_pmax)
     void* cws; size_t cws_bytes;
     const float* x_in;   // input of the last forward
     int lastN;
@@ -76,7 +77,7 @@ static int f_describe(la_feat* h, int nops, const la_feat_op* ops, int in_ch, in
 static size_t f_layout(la_feat* h, void* ws) {
     FCarver c{(char*)ws, 0};
     const size_t mn = h->maxN;
-    size_t gmax = mn * h->in_ch * (size_t)h->in_res * h->in_res, cw = 0;
+    size_t gmax = mn * h->in_ch * (size_t)h->in_res * h->in_res, cw = 0, pmax = 0;
     for (int k = 0; k < h->nops; ++k) {
         FOp& o = h->op[k];
         const size_t n_out = mn * o.cout * (size_t)o.res_out * o.res_out;
@@ -89,10 +90,13 @@ static size_t f_layout(la_feat* h, void* ws) {
             if (w > cw) cw = w;
             const size_t gin = mn * o.mb_ * (size_t)o.res_in * o.res_in;
             if (gin > gmax) gmax = gin;
+            const size_t pmn = mn * o.cout * (size_t)la_conv_act_grad_segments((long)o.res_out * o.res_out);
+            if (pmn > pmax) pmax = pmn;
         }
         if (o.kind != LA_FEAT_TAP) { o.y = c.take(n_out); if (n_out > gmax) gmax = n_out; }
     }
     h->gA = c.take(gmax); h->gB = c.take(gmax);
+    h->pm = c.take(pmax);
     h->cws = c.take((cw + 3) / 4); h->cws_bytes = cw;
     return c.off;
 }
@@ -242,13 +246,14 @@ static void fbase(LaConvArgs& a) {
     a.in_sy = a.in_sx = a.out_sy = a.out_sx = 1; a.clamp = -1.f; a.gain = 1.f; a.act = LA_ACT_LINEAR;
 }
 
-static int f_conv(la_feat* h, const FOp& o, bool backward, const float* in, float* out, int N, hipStream_t stream) {
+static int f_conv(la_feat* h, const FOp& o, bool backward, const float* in, float* out, int N, hipStream_t stream, const float* in_pmax = nullptr,
+                  int in_nseg = 0) {
     LaConvArgs a; fbase(a);
     a.wgt = backward ? o.wb : o.wf;
     a.precision = h->precision; a.wgt_bf16 = backward ? o.wqb : o.wqf;
     a.wgt_bf16_term_elems = la_conv_bf16_pack_elems(backward ? o.mb_ : o.cout, backward ? o.cout : o.cin, 9);
     a.ws = h->cws; a.ws_bytes = h->cws_bytes;
-    a.in = in; a.out = out; a.B = N;
+    a.in = in; a.out = out; a.B = N; a.in_pmax = in_pmax; a.in_pmax_nseg = in_nseg;
     a.C = backward ? o.cout : o.cin; a.M = backward ? o.mb_ : o.cout;
     const int res = o.res_in;
     a.in_bstride = (long)a.C * res * res;
@@ -310,10 +315,11 @@ extern "C" int la_feat_backward(la_feat* h, const float* gfeat, float* gx, hipSt
             have = true;
         } else if (o.kind == LA_FEAT_CONV_RELU) {
             LA_CHECK_ARG(have, "feat_backward: the op list must end with a tap");
-            const long n_out = (long)N * o.cout * HWo;
-            if ((rc = la_bias_act_grad_f32(g, o.y, g, nullptr, n_out, 1, 1, LA_ACT_RELU, 0.f, 1.f, -1.f, stream))) return rc;
+            // ReLU mask of this layer on the incoming gradient, with the plane maxima the fp16 operand scale of its backward
+            // contraction needs (one sweep instead of a mask pass + an absmax pass)
+            if ((rc = la_conv_act_grad_pmax(g, o.y, g, h->pm, N, o.cout, HWo, LA_ACT_RELU, 0.f, 1.f, -1.f, stream))) return rc;
             float* dst = (k == 0 && o.mb_ == o.cin) ? gx : other;
-            if ((rc = f_conv(h, o, true, g, dst, N, stream))) return rc;
+            if ((rc = f_conv(h, o, true, g, dst, N, stream, h->pm, la_conv_act_grad_segments(HWo)))) return rc;
             if (k == 0 && dst != gx) {
                 // padded backward channels (cin not a multiple of 4): copy the real ones out
                 const long HWi = (long)o.res_in * o.res_in;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Full-size golden vectors for BASELINE.json configs B, C, D, E -- made by RUNNING THE REFERENCE in the build container.
+"""Full-size golden vectors for BASELINE.json configs B, C, D, E (and F = B with the discriminator criterion) -- made by RUNNING THE
+REFERENCE in the build container.
 
-Run from the repo root:   python tests/golden/make_golden_fullsize.py [B C D E]
+Run from the repo root:   python tests/golden/make_golden_fullsize.py [B C D E F]
 Needs /root/reference (read-only).  Never runs on the GPU box; only tests/golden/fullsize_<cfg>.npz travels.
 
 Per config two CPU runs on identical seeded inputs (latentaugment_amd.synthetic, BASELINE.md "Synthetic inputs"):
@@ -141,5 +142,5 @@ def run(name):
 
 
 if __name__ == '__main__':
-    for n in (sys.argv[1:] or ['B', 'C', 'D', 'E']):
+    for n in (sys.argv[1:] or ['B', 'C', 'D', 'E', 'F']):
         run(n)

@@ -1,4 +1,5 @@
-"""Full-size parity of the HIP latent-optimisation loop on BASELINE.json configs B, C, D and E (`-m gpu`).
+"""Full-size parity of the HIP latent-optimisation loop on BASELINE.json configs B, C, D and E, and on F = B with the discriminator
+criterion (SURVEY 8(d)'s second run) (`-m gpu`).
 
 Each case runs the product (`LatentAug.run_local`, default `f16x2` contraction, `gemm` criteria) on the exact seeded
 workload of the config and compares with fixtures made by running the REFERENCE's `LatentAug.forward` on the CPU in
@@ -79,7 +80,7 @@ def _run_case(name, dev, precision='f16x2'):
 
 # slack of the per-step / gradient checks per config (the final-state checks take theirs from the test functions below)
 D_SLACK = 1.5
-STEP_SLACK = {'B': 1.5, 'C': 1.5, 'D': D_SLACK, 'E': 2.0}
+STEP_SLACK = {'B': 1.5, 'C': 1.5, 'D': D_SLACK, 'E': 2.0, 'F': 1.5}
 
 
 def _check_steps(name, c, fx, w_steps, g_steps, slack):
@@ -210,3 +211,11 @@ def test_config_e_all_criteria_pelvis_scale_vs_reference(dev):
     of the total latent movement (0.017 of 0.05) away from float64 in its worst entry, and which entries do so differs between
     any two float32 implementations.  The first step, evaluated at the same latent, pins every criterion to ~1e-6."""
     _check('E', *_run_case('E', dev), slack=2.0)
+
+
+def test_config_f_bench_workload_with_discriminator_vs_reference(dev):
+    """SURVEY 8(d)'s second run (`w_disc = 0.01` on the bench workload): SG2 config-f 256^2, B=8, banks M_w=1024 / M_x=256, the
+    discriminator at config-f width (512 channels up to 64^2) in the loss, 10 steps -- D forward, softplus criterion and D
+    backward-to-image at the size `bench.py --w-disc 0.01` times, against the reference's own float32 run and the float64 anchor
+    (config E covers D only at config-e width).  Measured: HIP 9.3e-6 rms from float64 after 10 steps, the reference's float32 3.0e-5."""
+    _check('F', *_run_case('F', dev), slack=1.5)
