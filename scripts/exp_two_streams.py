@@ -1,0 +1,82 @@
+"""Experiment: the bench batch as two half-batches (B = 4 each) on two HIP streams of ONE process, each half with its own loop /
+synthesis handles (no shared scratch), against the single B = 8 loop -- the half-batches are independent samples, so while one is
+in its latency-bound low-resolution layers the other can fill the chip.  Also checks that overlapping changes no bit of either
+half (round 2 saw wrong results when two streams of ONE synthesis handle overlapped)."""
+import os
+import random
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                                                                # noqa: E402
+from latentaugment_amd import synthetic                                     # noqa: E402
+from latentaugment_amd.latent_aug import LatentAug                          # noqa: E402
+
+dev = torch.device('cuda', 0)
+NG = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+sys.argv = ['bench.py']
+args = bench.apply_preset(bench.parse())
+sd, meta = synthetic.make_generator_state_dict(img_resolution=args.res, img_channels=2, channel_base=args.channel_base, seed=0)
+W, X = synthetic.make_banks(meta['num_ws'], res=args.res, M_w=args.M_w, M_x=args.M_x)
+w0 = synthetic.make_latents(8, seed=1).to(dev)
+
+
+def make(batch):
+    opt = bench.make_opt(args, 0, batch)
+    opt.final_noise_mode = 'const'
+    return LatentAug('train', opt, '/tmp', [0], generator=sd, banks={'W': W, 'X': X})
+
+
+full = make(8)
+parts = [make(8 // NG) for _ in range(NG)]
+streams = [torch.cuda.Stream(device=dev) for _ in range(NG)]
+random.seed(6)
+
+
+def run_full():
+    return full.run_local(w0, crop_pos=(0, 0))[:2]
+
+
+def run_parts(concurrent):
+    outs = []
+    per = 8 // NG
+    for k, (la, st) in enumerate(zip(parts, streams)):
+        with torch.cuda.stream(st if concurrent else torch.cuda.current_stream()):
+            if concurrent:
+                st.wait_stream(torch.cuda.default_stream(dev))
+            outs.append(la.run_local(w0[k * per:(k + 1) * per], crop_pos=(0, 0))[:2])
+        if not concurrent:
+            torch.cuda.synchronize()
+    if concurrent:
+        for st in streams:
+            torch.cuda.default_stream(dev).wait_stream(st)
+    return outs
+
+
+def timed(fn, n=6):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.time() - t0) / n
+
+
+t_full = timed(run_full)
+t_seq = timed(lambda: run_parts(False))
+t_con = timed(lambda: run_parts(True))
+print(f'one loop of 8: {1e3 * t_full:.1f} ms ({8 / t_full:.1f} images/s); {NG} loops of {8 // NG} one after the other: {1e3 * t_seq:.1f} ms '
+      f'({8 / t_seq:.1f}); on {NG} streams: {1e3 * t_con:.1f} ms ({8 / t_con:.1f} images/s)', flush=True)
+a = run_parts(False); torch.cuda.synchronize()
+a2 = run_parts(False); torch.cuda.synchronize()
+b = run_parts(True); torch.cuda.synchronize()
+b2 = run_parts(True); torch.cuda.synchronize()
+for k in range(NG):
+    print(f'part {k}: alone twice {float((a[k][1] - a2[k][1]).abs().max()):.3e}; overlapped twice {float((b[k][1] - b2[k][1]).abs().max()):.3e}', flush=True)
+for k in range(NG):
+    di = float((a[k][0] - b[k][0]).abs().max()); dw = float((a[k][1] - b[k][1]).abs().max())
+    print(f'part {k}: overlapped vs alone: max |d img| {di:.3e}, max |d w| {dw:.3e}', flush=True)
