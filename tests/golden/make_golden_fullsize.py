@@ -67,7 +67,9 @@ def moments(img):
 
 
 def run(name):
-    c = CONFIGS[name]
+    c = dict(CONFIGS[name])
+    if os.environ.get('FULLSIZE_STEPS'):      # a longer / shorter loop than fullsize_common states (the file name then says so)
+        c['steps'] = int(os.environ['FULLSIZE_STEPS'])
     t0 = time.time()
     sd, meta, G, D, fnet, W, X, fea, w0 = build_inputs(c)
     random.seed(CROP_SEED)
@@ -137,8 +139,9 @@ def run(name):
     out['o64_img_mom'] = moments(img64)
     e32 = np.abs(out['ref32_w'].astype(np.float64) - out['o64_w'])
     print(name, 'o64 done', f'{time.time() - t0:.0f}s', 'ref32-vs-o64 latent err max', e32.max(), 'rms', np.sqrt((e32 ** 2).mean()), flush=True)
-    np.savez_compressed(os.path.join(HERE, f'fullsize_{name}.npz'), **out)
-    print(name, 'saved', os.path.getsize(os.path.join(HERE, f'fullsize_{name}.npz')) // 1024, 'KB', flush=True)
+    fname = f'fullsize_{name}.npz' if not os.environ.get('FULLSIZE_STEPS') else f'fullsize_{name}_{c["steps"]}steps.npz'
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(name, 'saved', fname, os.path.getsize(os.path.join(HERE, fname)) // 1024, 'KB', flush=True)
 
 
 if __name__ == '__main__':
