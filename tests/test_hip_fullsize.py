@@ -191,9 +191,9 @@ def test_config_c_512_loop_vs_reference(dev):
 
 
 def test_config_d_1024_loop_vs_reference(dev):
-    """configs[3] per-GPU shape: config-f 1024^2, B=2, banks M_w=1024 / M_x=256, 10 steps of the 50-step loop (a float64 CPU run of
-    all 50 at 1024^2 takes hours; the per-step check above shows the error ratio over the steps that are run) with the default
-    f16x2 contraction (32-row halo tiles of the 32-channel layers included).
+    """configs[3] per-GPU shape: config-f 1024^2, B=2, banks M_w=1024 / M_x=256, ALL 50 steps of the loop (the float64 CPU run of the
+    fixture takes an hour on the build container's 8 cores; `FULLSIZE_STEPS=50 make_golden_fullsize.py D`), with the default f16x2
+    contraction (32-row halo tiles of the 32-channel layers included); the per-step check covers every one of the 50 steps.
 
     The style gradient is formed here as  sum_p x[p] * (W^T * gz)[p]  (data gradient first, 2x forward FLOPs per step) where the
     reference forms  sum_{o,k} W * (sum_p gz[p] x[p+k])  (weight gradient first, 3x).  Both are exact in real arithmetic; in
