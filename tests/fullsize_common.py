@@ -10,7 +10,7 @@ CONFIGS = {
     'D': dict(res=1024, channel_base=32768, batch=2, steps=50, M_w=1024, M_x=256, w_latent=0.001, w_pix=0.1, w_disc=0.0, w_lpips=0.0),
     'E': dict(res=256, channel_base=16384, batch=8, steps=20, M_w=6026, M_x=1572, w_latent=0.001, w_pix=0.1, w_disc=0.01, w_lpips=10.0),
     # SURVEY 8(d)'s second run: the bench workload (config B) with the discriminator criterion on -- D at config-f width, 256^2
-    'F': dict(res=256, channel_base=32768, batch=8, steps=10, M_w=1024, M_x=256, w_latent=0.001, w_pix=0.1, w_disc=0.01, w_lpips=0.0),
+    'F': dict(res=256, channel_base=32768, batch=8, steps=20, M_w=1024, M_x=256, w_latent=0.001, w_pix=0.1, w_disc=0.01, w_lpips=0.0),
 }
 CROP = 64          # crop_size_aug
 CROP_SEED = 6      # python `random` seed of the crop position
