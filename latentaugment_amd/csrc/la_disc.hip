@@ -250,7 +250,37 @@ __global__ __launch_bounds__(256) void la_mbstd_fwd_kernel(const float* __restri
     __shared__ float red[4];
     const int slot = blockIdx.x, M = N / G;
     const int CHW = C * HW;
+    // (only N / G workgroups run: four elements per thread and pass with all their group loads in flight, accumulated in the order of
+    //  the plain loop -- it was one exposed load latency per element and group member, 62 us)
     float acc = 0.f;
+    auto one = [&](const float (&xv)[8]) {      // (fixed trip counts: the arrays stay in registers)
+        float mean = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) if (g < G) mean += xv[g];
+        mean /= (float)G;
+        float var = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) if (g < G) { const float d = xv[g] - mean; var += d * d; }
+        return sqrtf(var / (float)G + 1e-8f);
+    };
+    if (G <= 8) {
+        int e = threadIdx.x;
+        for (; e + 3 * (int)blockDim.x < CHW; e += 4 * blockDim.x) {
+            float xv[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int g = 0; g < 8; ++g) xv[u][g] = g < G ? x[(long)(g * M + slot) * CHW + e + u * (int)blockDim.x] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += one(xv[u]);
+        }
+        for (; e < CHW; e += blockDim.x) {
+            float xv[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) xv[g] = g < G ? x[(long)(g * M + slot) * CHW + e] : 0.f;
+            acc += one(xv);
+        }
+    } else
     for (int e = threadIdx.x; e < CHW; e += blockDim.x) {
         float mean = 0.f;
         for (int g = 0; g < G; ++g) mean += x[(long)(g * M + slot) * CHW + e];
@@ -262,8 +292,16 @@ __global__ __launch_bounds__(256) void la_mbstd_fwd_kernel(const float* __restri
     const float stat = la_block_sum_256(acc, red) / (float)CHW;
     for (int g = 0; g < G; ++g) {
         const long n = g * M + slot;
-        for (int e = threadIdx.x; e < CHW; e += blockDim.x) y[n * (CHW + HW) + e] = x[n * CHW + e];
-        for (int e = threadIdx.x; e < HW; e += blockDim.x) y[n * (CHW + HW) + CHW + e] = stat;
+        int e = threadIdx.x;
+        for (; e + 3 * (int)blockDim.x < CHW; e += 4 * blockDim.x) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = x[n * CHW + e + u * (int)blockDim.x];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) y[n * (CHW + HW) + e + u * (int)blockDim.x] = v[u];
+        }
+        for (; e < CHW; e += blockDim.x) y[n * (CHW + HW) + e] = x[n * CHW + e];
+        for (int q = threadIdx.x; q < HW; q += blockDim.x) y[n * (CHW + HW) + CHW + q] = stat;
     }
 }
 
@@ -279,6 +317,47 @@ __global__ __launch_bounds__(256) void la_mbstd_bwd_kernel(const float* __restri
         gs += gy[(long)(g * M + slot) * ((long)CP * HW) + CHW + p];
     }
     const float gstat = la_block_sum_256(gs, red);
+    // (as in the forward kernel: two elements per thread and pass, their 2 x 2G loads in flight, same arithmetic per element)
+    auto elem = [&](int e, const float (&xv)[8], const float (&gv)[8]) {
+        float mean = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) if (g < G) mean += xv[g];
+        mean /= (float)G;
+        float var = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) if (g < G) { const float d = xv[g] - mean; var += d * d; }
+        const float sd = sqrtf(var / (float)G + 1e-8f);
+        const float k = gstat / ((float)CHW * (float)G * sd);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) if (g < G) gx[(long)(g * M + slot) * CHW + e] = gv[g] + k * (xv[g] - mean);
+    };
+    if (G <= 8) {
+        int e = threadIdx.x;
+        for (; e + (int)blockDim.x < CHW; e += 2 * blockDim.x) {
+            float xv[2][8], gv[2][8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const long n = g * M + slot;
+                    xv[u][g] = g < G ? x[n * CHW + e + u * (int)blockDim.x] : 0.f;
+                    gv[u][g] = g < G ? gy[n * ((long)CP * HW) + e + u * (int)blockDim.x] : 0.f;
+                }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) elem(e + u * (int)blockDim.x, xv[u], gv[u]);
+        }
+        for (; e < CHW; e += blockDim.x) {
+            float xv[8], gv[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const long n = g * M + slot;
+                xv[g] = g < G ? x[n * CHW + e] : 0.f;
+                gv[g] = g < G ? gy[n * ((long)CP * HW) + e] : 0.f;
+            }
+            elem(e, xv, gv);
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < CHW; e += blockDim.x) {
         float mean = 0.f;
         for (int g = 0; g < G; ++g) mean += x[(long)(g * M + slot) * CHW + e];
@@ -295,17 +374,20 @@ __global__ __launch_bounds__(256) void la_mbstd_bwd_kernel(const float* __restri
 }
 
 // gx[b][i] = wgain * sum_o g[b][o] * W[o][i]          (FullyConnectedLayer backward-data)
-// Workgroup = 64 consecutive i (coalesced rows of W) x 4 groups of output rows; every weight is read once for up to FCB samples,
+// Workgroup = FC_IL consecutive i (coalesced rows of W) x FC_NG groups of output rows; every weight is read once for up to FCB samples,
 // four rows in flight; the row groups are combined through LDS in a fixed order.  (Round 1: one thread per i and sample walking all
 // `out` rows alone: 112 us on the 8192 x 512 epilogue layer.)
 #define FCB 8
+#define FC_IL 32      // consecutive inputs per workgroup (one 128-byte segment of every weight row)
+#define FC_NG 8       // groups of output rows per workgroup (256 / FC_IL): 256 workgroups x 8 groups on the 8192-wide layer (round 2: 64 x 4,
+                      // i.e. half the workgroups and twice the rows per thread: 40 us for 16.8 MB)
 __global__ __launch_bounds__(256) void la_fc_bwd_kernel(const float* __restrict__ g, const float* __restrict__ W,
                                                        float* __restrict__ gx, int B, int in, int out, float wgain) {
-    __shared__ float comb[4][FCB][64];
-    const int il = threadIdx.x & 63, og = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + il;
+    __shared__ float comb[FC_NG][FCB][FC_IL];
+    const int il = threadIdx.x % FC_IL, og = threadIdx.x / FC_IL;
+    const int i = blockIdx.x * FC_IL + il;
     const int b0 = blockIdx.y * FCB;
-    const int per = (out + 3) / 4;
+    const int per = (out + FC_NG - 1) / FC_NG;
     const int o0 = og * per, o1 = o0 + per < out ? o0 + per : out;
     float acc[FCB];
 #pragma unroll
@@ -334,7 +416,12 @@ __global__ __launch_bounds__(256) void la_fc_bwd_kernel(const float* __restrict_
     if (og == 0 && i < in) {
 #pragma unroll
         for (int q = 0; q < FCB; ++q)
-            if (b0 + q < B) gx[(long)(b0 + q) * in + i] = ((comb[0][q][il] + comb[1][q][il]) + (comb[2][q][il] + comb[3][q][il])) * wgain;
+            if (b0 + q < B) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < FC_NG; ++k) t += comb[k][q][il];
+                gx[(long)(b0 + q) * in + i] = t * wgain;
+            }
     }
 }
 
@@ -463,7 +550,7 @@ extern "C" int la_disc_backward(la_disc* h, const float* dlogits, float* g_img, 
     hipLaunchKernelGGL(la_outfc_bwd_kernel, dim3(la_cdiv((long)B * C4, 256)), dim3(256), 0, stream, dl, h->out_w, h->g_fc, B, C4,
                        1.0f / sqrtf((float)C4));
     if ((rc = la_bias_act_grad_f32(h->g_fc, h->fc, h->g_fc, nullptr, (long)B * C4, 1, 1, LA_ACT_LRELU, 0.2f, sq2, -1.f, stream))) return rc;
-    hipLaunchKernelGGL(la_fc_bwd_kernel, dim3(la_cdiv(C4 * 16, 64), la_cdiv(B, FCB)), dim3(256), 0, stream, h->g_fc, h->fc_w, h->g_flat, B, C4 * 16,
+    hipLaunchKernelGGL(la_fc_bwd_kernel, dim3(la_cdiv(C4 * 16, FC_IL), la_cdiv(B, FCB)), dim3(256), 0, stream, h->g_fc, h->fc_w, h->g_flat, B, C4 * 16,
                        C4, 1.0f / sqrtf((float)(C4 * 16)));
     LA_CHECK_LAUNCH();
     if ((rc = la_bias_act_grad_f32(h->g_flat, h->yc, h->g_flat, nullptr, (long)B * C4 * 16, 1, 1, LA_ACT_LRELU, 0.2f, sq2, h->clamp, stream))) return rc;

@@ -192,9 +192,20 @@ __global__ __launch_bounds__(256) void la_tap_fwd_kernel(const float* __restrict
     const long n = blockIdx.y;
     const bool ok = p < HW;
     const float* fp = f + n * C * HW + p;
+    // (eight channel loads in flight per thread, summed in the channel order of the plain loop: at the 4x4 / 8x8 taps a thread walks
+    //  32 - 128 channels and the loop was one exposed load latency per channel, 40 - 60 us for 16 workgroups)
     float s = 0.f;
-    if (ok)
-        for (int c = cg; c < C; c += CG) { const float v = fp[(long)c * HW]; s += v * v; }
+    if (ok) {
+        int c = cg;
+        for (; c + 7 * CG < C; c += 8 * CG) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fp[(long)(c + k * CG) * HW];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k] * v[k];
+        }
+        for (; c < C; c += CG) { const float v = fp[(long)c * HW]; s += v * v; }
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     float tot = 0.f;
@@ -202,7 +213,15 @@ __global__ __launch_bounds__(256) void la_tap_fwd_kernel(const float* __restrict
     const float r = rsqrtf(tot + 1e-10f) * rsqrtf((float)HW);
     if (!ok) return;
     float* o = feat + n * F + off + p;
-    for (int c = cg; c < C; c += CG) o[(long)c * HW] = fp[(long)c * HW] * r * sqrtf(lin[c]);
+    int c = cg;
+    for (; c + 7 * CG < C; c += 8 * CG) {
+        float v[8], w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = fp[(long)(c + k * CG) * HW]; w[k] = lin[c + k * CG]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[(long)(c + k * CG) * HW] = v[k] * r * sqrtf(w[k]);
+    }
+    for (; c < C; c += CG) o[(long)c * HW] = fp[(long)c * HW] * r * sqrtf(lin[c]);
 }
 
 // tap backward: gf[k] (+)= r * (u_k - y_k * sum_c u_c y_c),  u_c = g_c * sqrt(lin_c)/sqrt(HW),  y_c = f_c * r   (same thread layout)
@@ -217,12 +236,21 @@ __global__ __launch_bounds__(256) void la_tap_bwd_kernel(const float* __restrict
     const float* gp = gfeat + n * F + off + p;
     const float a = rsqrtf((float)HW);
     float s = 0.f, d = 0.f;                       // sum f^2 and sum u_c f_c of this thread's channels
-    if (ok)
-        for (int c = cg; c < C; c += CG) {
+    if (ok) {
+        int c = cg;
+        for (; c + 7 * CG < C; c += 8 * CG) {      // (eight channels' loads in flight, summed in channel order: see la_tap_fwd_kernel)
+            float v[8], g[8], w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[k] = fp[(long)(c + k * CG) * HW]; g[k] = gp[(long)(c + k * CG) * HW]; w[k] = lin[c + k * CG]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s += v[k] * v[k]; d += g[k] * sqrtf(w[k]) * a * v[k]; }
+        }
+        for (; c < C; c += CG) {
             const float v = fp[(long)c * HW];
             s += v * v;
             d += gp[(long)c * HW] * sqrtf(lin[c]) * a * v;
         }
+    }
     red[0][threadIdx.x] = s; red[1][threadIdx.x] = d;
     __syncthreads();
     float st = 0.f, dt = 0.f;
@@ -231,7 +259,22 @@ __global__ __launch_bounds__(256) void la_tap_bwd_kernel(const float* __restrict
     const float dot = dt * r;                      // sum_c u_c y_c
     if (!ok) return;
     float* op = gf + n * C * HW + p;
-    for (int c = cg; c < C; c += CG) {
+    int c = cg;
+    for (; c + 7 * CG < C; c += 8 * CG) {
+        float fv[8], g[8], w[8], prev[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            fv[k] = fp[(long)(c + k * CG) * HW]; g[k] = gp[(long)(c + k * CG) * HW]; w[k] = lin[c + k * CG];
+            prev[k] = accumulate ? op[(long)(c + k * CG) * HW] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float u = g[k] * sqrtf(w[k]) * a, y = fv[k] * r;
+            const float v = r * (u - y * dot);
+            op[(long)(c + k * CG) * HW] = accumulate ? prev[k] + v : v;
+        }
+    }
+    for (; c < C; c += CG) {
         const float u = gp[(long)c * HW] * sqrtf(lin[c]) * a, y = fp[(long)c * HW] * r;
         const float v = r * (u - y * dot);
         op[(long)c * HW] = accumulate ? op[(long)c * HW] + v : v;

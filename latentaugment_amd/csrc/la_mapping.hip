@@ -72,9 +72,55 @@ __global__ void la_broadcast_truncate_kernel(const float* __restrict__ x, const 
     ws[i] = v;
 }
 
+// Wide rows (the discriminator's 8192 -> 512 epilogue layer: 16.8 MB of weights, B = 8): ONE output row per workgroup, its four waves
+// each a quarter of the row (two weight float4 and 2 x MB input float4 in flight per lane and step), quarters combined through LDS in a
+// fixed order.  With one wave per row (la_fc_kernel) 512 waves had 2 MB of loads in flight on the whole chip: 52 us = 0.3 TB/s.
+__global__ __launch_bounds__(256) void la_fc_wide_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int B, int in,
+                                                        int out, float wgain, float bgain, int act, float alpha, float gain) {
+    __shared__ float part[4][MB];
+    const int o = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float4* w4 = reinterpret_cast<const float4*>(W + (long)o * in);
+    const int n4 = in >> 2, per = (n4 + 3) / 4;
+    const int j0 = wave * per, j1 = j0 + per < n4 ? j0 + per : n4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b0 = 0; b0 < B; b0 += MB) {
+        float acc[MB];
+#pragma unroll
+        for (int q = 0; q < MB; ++q) acc[q] = 0.f;
+        for (int j = j0 + lane; j < j1; j += 128) {
+            const bool two = j + 64 < j1;
+            const float4 wa = w4[j], wb = two ? w4[j + 64] : z4;
+#pragma unroll
+            for (int q = 0; q < MB; ++q)
+                if (b0 + q < B) {
+                    const float4* x4 = reinterpret_cast<const float4*>(x + (long)(b0 + q) * in);
+                    const float4 xa = x4[j], xb = two ? x4[j + 64] : z4;
+                    acc[q] += (wa.x * xa.x + wa.y * xa.y) + (wa.z * xa.z + wa.w * xa.w) + (wb.x * xb.x + wb.y * xb.y) + (wb.z * xb.z + wb.w * xb.w);
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < MB; ++q) {
+            const float v = la_wave_sum(acc[q]);
+            if (lane == 0) part[wave][q] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < MB && b0 + (int)threadIdx.x < B) {
+            const int q = threadIdx.x;
+            const float v = (part[0][q] + part[1][q]) + (part[2][q] + part[3][q]);
+            y[(long)(b0 + q) * out + o] = la_act_fwd(v * wgain + (bias ? bias[o] * bgain : 0.f), act, alpha, gain, -1.f);
+        }
+        __syncthreads();
+    }
+}
+
 extern "C" int la_fc_f32(const float* x, const float* W, const float* bias, float* y, int B, int in, int out, float lr_mul,
                          int act, float alpha, float gain, hipStream_t stream) {
     LA_CHECK_ARG(x && W && y && B >= 1 && in >= 1 && out >= 1, "fc: bad arguments");
+    if (in >= 2048 && (in & 3) == 0 && ((((size_t)W) | ((size_t)x)) & 15) == 0)
+        hipLaunchKernelGGL(la_fc_wide_kernel, dim3(out), dim3(256), 0, stream, x, W, bias, y, B, in, out, lr_mul / sqrtf((float)in), lr_mul,
+                           act, alpha, gain);
+    else
     hipLaunchKernelGGL(la_fc_kernel, dim3(la_cdiv(out, 4)), dim3(256), 0, stream, x, W, bias, y, B, in, out,
                        lr_mul / sqrtf((float)in), lr_mul, act, alpha, gain);
     LA_CHECK_LAUNCH();
