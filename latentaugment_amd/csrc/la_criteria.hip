@@ -290,7 +290,18 @@ __global__ void la_latent_combine_kernel(const float* __restrict__ dws, const fl
     const long b = i / wdim;
     const int j = (int)(i - b * wdim);
     float acc = 0.f, cs = 0.f;
-    for (int l = 0; l < num_ws; ++l) {
+    int l = 0;
+    for (; l + 7 < num_ws; l += 8) {      // (eight slots' loads in flight, added in slot order)
+        float a[8], c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a[k] = dws ? dws[(b * num_ws + l + k) * wdim + j] : 0.f;
+            c[k] = colsumW ? colsumW[(long)(l + k) * wdim + j] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { if (dws) acc += a[k]; if (colsumW) cs += c[k]; }
+    }
+    for (; l < num_ws; ++l) {
         if (dws) acc += dws[(b * num_ws + l) * wdim + j];
         if (colsumW) cs += colsumW[(long)l * wdim + j];
     }

@@ -743,8 +743,17 @@ __global__ __launch_bounds__(256) void la_affine_bwd_sum_kernel(LaStyleTable t, 
     int c0 = 0;
     for (int l = 0; l < t.nlayers; ++l) {
         const int nc = (t.row_start[l + 1] - t.row_start[l] + AFF_ROWS - 1) / AFF_ROWS;
-        if (t.widx[l] == slot)
-            for (int c = c0; c < c0 + nc; ++c) acc += part[((long)c * B + b) * wdim + j];
+        if (t.widx[l] == slot) {      // (eight chunk loads in flight, added in chunk order: the loop was one exposed load latency per chunk)
+            int c = c0;
+            for (; c + 7 < c0 + nc; c += 8) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = part[((long)(c + k) * B + b) * wdim + j];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += v[k];
+            }
+            for (; c < c0 + nc; ++c) acc += part[((long)c * B + b) * wdim + j];
+        }
         c0 += nc;
     }
     dws[((long)b * num_ws + slot) * wdim + j] = acc * wgain;
