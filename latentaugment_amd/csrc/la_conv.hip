@@ -241,8 +241,26 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
         typedef float vf __attribute__((ext_vector_type(VEC)));
         auto ld = [](const float* p) { return *reinterpret_cast<const vf*>(p); };
         for (int g = tp * VEC; g < G; g += T * VEC) {
+            // (the slices' loads in flight eight at a time, added in slice order: with one load and one add per trip the pass was an
+            //  exposed L2 latency per slice -- up to 16 of them at the 4x4 and 8x8 layers)
             vf acc = ld(wsp + g);
-            for (int k = 1; k < a.ksplit; ++k) acc += ld(wsp + (long)k * slice + g);
+            int k = 1;
+            for (; k + 7 < a.ksplit; k += 8) {
+                vf p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = ld(wsp + (long)(k + u) * slice + g);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += p[u];
+            }
+            if (k + 3 < a.ksplit) {
+                vf p[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) p[u] = ld(wsp + (long)(k + u) * slice + g);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc += p[u];
+                k += 4;
+            }
+            for (; k < a.ksplit; ++k) acc += ld(wsp + (long)k * slice + g);
             const int gy = g / a.Gx, gx = g - gy * a.Gx;
             const long pos = (long)(gy * a.out_sy + a.out_oy) * wpitch + gx * a.out_sx + a.out_ox;
             float v[VEC];
