@@ -84,7 +84,16 @@ __device__ __forceinline__ float la_pow2_scale(float amax) {
 // la_pow2_scale(mult * its own max) -- positive floats order like unsigned ints, so an atomicMin on the bit pattern does it, the
 // result is the scale of the overall maximum whatever the arrival order, and the consumer just reads a float.  `seen` is an
 // earlier (possibly stale, i.e. larger) read of the slot: workgroups that cannot lower it skip the atomic.
+// A slot is a ROW of LA_XS_SUBS sub-slots per sample, each in a 128-byte line of its own (LA_XS_FAN floats per row): a producing
+// workgroup lowers the sub-slot picked by its id, the consumer takes the minimum of the row (la_xs_get) -- so that a launch of thousands
+// of short workgroups finishing together (the split-K finish pass, the seam kernel) spreads its atomics over 32 LINES per sample
+// instead of serialising on one (device-scope atomics execute at the memory side, one line at a time: round 2 measured the
+// single-address form at 21 -> 65 us and 158 -> 281 us for those two and kept a reduction launch for them; round 4 measured 32
+// sub-slots inside ONE line no better, +13 us / +40 us).  The minimum of the row is the scale of the overall maximum either way.
 #define LA_XS_INIT 0x71800000u
+#define LA_XS_SUBS 32
+#define LA_XS_LINE 32                          // floats per 128-byte line
+#define LA_XS_FAN (LA_XS_SUBS * LA_XS_LINE)    // floats per slot row
 __device__ __forceinline__ float la_xs_peek(const float* slot) {
     return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
@@ -92,6 +101,21 @@ __device__ __forceinline__ void la_xs_lower(float* slot, float seen, float mult,
     if (!(wg_max > 0.f)) return;
     const float s = la_pow2_scale(mult * wg_max);
     if (s < seen) atomicMin(reinterpret_cast<unsigned*>(slot), __float_as_uint(s));
+}
+// sub-slot of the calling workgroup inside a row (any spread will do; the multipliers keep neighbouring workgroups of every grid apart)
+// (returned as the float offset of the sub-slot inside the row)
+__device__ __forceinline__ int la_xs_sub(int salt = 0) { return (int)((blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z + (unsigned)salt) & (LA_XS_SUBS - 1)) * LA_XS_LINE; }
+// final per-sample scale: plain arrays [B] (fan <= 1: scales computed by a reduction launch or known a priori) or slot rows [B][LA_XS_FAN]
+__device__ __forceinline__ float la_xs_get(const float* p, int b, int fan) {
+    if (fan <= 1) return p[b];
+    const float* q = p + (long)b * LA_XS_FAN;
+    float v[LA_XS_SUBS];
+#pragma unroll
+    for (int i = 0; i < LA_XS_SUBS; ++i) v[i] = q[i * LA_XS_LINE];      // (all in flight: one round trip)
+    float m = v[0];
+#pragma unroll
+    for (int i = 1; i < LA_XS_SUBS; ++i) m = fminf(m, v[i]);
+    return m;
 }
 
 // activation ids follow the reference's cuda_idx (bias_act.py:20-30): 1 linear, 2 relu, 3 lrelu

@@ -66,9 +66,9 @@ struct LaConvArgs {
     int seam_act; float seam_alpha, seam_gain, seam_clamp;
     float* seam_ddn_part;    // [B][M][tiles_per_sample]
     float* seam_pmax;        // [B][M][tiles_per_sample] or null
-    float* seam_xs_out;      // [B] or null: fp16 operand scale of `out` for its consumer = pow2 scale of seam_xs_mult * max|out| over the
-    float seam_xs_mult;      //   sample, final when the launch has run: direct kernels lower the slot themselves (la_xs_lower, la_common.h; it must
-                             //   hold LA_XS_INIT before), the split-K form reduces seam_pmax (required as scratch) with one small launch
+    float* seam_xs_out;      // [B][LA_XS_FAN] or null: slot rows of the fp16 operand scale of `out` for its consumer = pow2 scale of
+    float seam_xs_mult;      //   seam_xs_mult * max|out| over the sample, final when the launch has run: every kernel form (direct epilogues,
+                             //   split-K finish pass) lowers the row itself (la_xs_lower, la_common.h; it must hold LA_XS_INIT before)
     // ... and, with seam_imgc > 0, the ToRGB backward of the block whose conv1 output xin is (la_seam_bwd_kernel<imgc>):
     //   g += sum_c seam_wrgb[c][m] * seam_srgb[b][m] * gr_c,  gr_c = seam_gimg[b][c][px] where |seam_rgbpre[b][c][px]| <= seam_rgb_clamp;
     //   seam_dweff_part[b][c][m][tile] = sum_px gr_c * y
@@ -97,7 +97,8 @@ struct LaConvArgs {
     const void* wgt_bf16;          // split pack (la_conv_split_pack_bytes): 3 bf16 terms, 2 fp16 terms, fp16 weight scale
     long wgt_bf16_term_elems;      // elements per term: slabs * ceil(C/32) * M * 32
     // LA_PREC_F16X2: acc is divided by xscale[b] * wscale (exact powers of two) before the epilogue; set by la_conv_prepare_input
-    const float* acc_scale_x;      // [B]
+    const float* acc_scale_x;      // [B] (acc_scale_fan <= 1), or slot rows [B][LA_XS_FAN] left by the producer of `in` (acc_scale_fan = LA_XS_FAN)
+    int acc_scale_fan;
     const float* acc_scale_w;      // [1]
     // Merged output phases (transposed stride-2 conv, 16-bit direct kernel only): nphase > 0 runs all phases in ONE launch,
     // blockIdx.z = phase * B + sample, each phase with its own grid / output offset / tap table (<= 4 taps).  One launch of

@@ -232,6 +232,9 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
     const float dm0 = (seam && a.seam_demod) ? a.seam_demod[(long)b * a.seam_demod_stride + m] : 1.f;
     const float b0 = (seam && a.seam_bias) ? a.seam_bias[m] : 0.f;
     float part = 0.f, dd = 0.f, mx = 0.f;
+    // (the sub-slot of the consumer's scale row this plane lowers, read early: the round trip hides under the slice loads)
+    float* xs_row = (seam && a.seam_xs_out && lane == 0 && (PPB > 1 || threadIdx.x == 0)) ? a.seam_xs_out + (long)b * LA_XS_FAN + la_xs_sub((int)(threadIdx.x >> 6) * 5) : nullptr;
+    const float xs_seen = xs_row ? la_xs_peek(xs_row) : 0.f;
     const int imgc = seam ? (a.seam_imgc < 4 ? a.seam_imgc : 4) : 0;
     float we[4] = {0.f, 0.f, 0.f, 0.f}, dwe[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < imgc; ++c) we[c] = a.seam_wrgb[(long)c * a.M + m] * a.seam_srgb[(long)b * a.seam_srgb_stride + m];
@@ -349,6 +352,8 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
 #pragma unroll
             for (int c = 0; c < 4; ++c) dwe[c] = (wdw[c][0] + wdw[c][1]) + (wdw[c][2] + wdw[c][3]);
         }
+        // operand scale of the output for its consumer: one atomic per plane (wave) on a sub-slot of the sample's row
+        if (xs_row) la_xs_lower(xs_row, xs_seen, a.seam_xs_mult, mx);
         if (tp < a.tiles_per_sample) {
             const long slot = ((long)b * a.M + m) * a.tiles_per_sample + tp;
             for (int c = 0; c < imgc; ++c)
@@ -378,7 +383,6 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
         LA_CHECK_ARG(a.tiles_per_sample == la_conv_tiles_per_sample(a.Gy, a.Gx), "conv: tiles_per_sample mismatch");
         LA_CHECK_ARG(a.out_sy == 1 && a.out_sx == 1 && a.out_oy == 0 && a.out_ox == 0, "conv: bwd epilogue needs dense output");
     }
-    LA_CHECK_ARG(!a.seam_xs_out || a.seam_pmax, "conv: seam_xs_out needs seam_pmax as scratch for the split-K form");
     int tiles = la_conv_tiles_per_sample(a.Gy, a.Gx);
     const int nphase = a.nphase;
     LA_CHECK_ARG(nphase >= 0 && nphase <= LA_CONV_MAX_PHASES, "conv: bad phase count");
@@ -422,6 +426,7 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
         pflops = 2.0 * a.B * gt * a.M * (double)a.C;
         pbytes = 4.0 * ((double)a.B * a.C * a.Hin * a.Win * (a.in_bstride ? 1.0 : 1.0 / a.B) + (double)a.B * a.M * gout + ntw * a.C * a.M);
     }
+    if (as.seam_xs_out) as.seam_pmax = nullptr;      // every kernel form lowers the consumer's slot row itself: no plane maxima
     as.splitk_ws = nullptr;
     long splitk_floats = 0;
     if (as.ws && as.ws_bytes >= sizeof(float)) {
@@ -460,17 +465,11 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
                 // one wave per (b, m) plane, four planes per workgroup, at every split-K size (<= 34x34): a whole workgroup per plane
                 // (the <1> form) measured 21 against 13 us on the 8 x 512 x 32^2 launches
                 hipLaunchKernelGGL(la_conv_splitk_finish_kernel<4>, dim3(la_cdiv(a.M, 4), a.B, nz), dim3(256), 0, stream, as);
-                // the consumer's operand scale (LaConvArgs::seam_xs_out): thousands of short finish workgroups lowering one slot per
-                // sample at the same moment serialise on it (measured 21 -> 65 us), so this form reduces the plane maxima instead
-                if (as.seam_xs_out && as.seam_ddn_part && as.epi == LA_EPI_BWD) {
-                    int rc = la_conv_xscale_from_pmax(as.seam_pmax, as.tiles_per_sample, nullptr, 0, as.seam_xs_mult, as.seam_xs_out, a.B, a.M, stream);
-                    if (rc) return rc;
-                }
+                // (the consumer's operand scale, LaConvArgs::seam_xs_out: the finish workgroups lower the sample's slot row themselves)
             }
         }
     }
     if (as.ksplit == 1) {
-        if (as.seam_xs_out) as.seam_pmax = nullptr;      // direct kernels lower the consumer's scale slot themselves: no plane maxima
         dim3 grid(tiles, mtiles, a.B * (nphase > 0 ? nphase : 1));
         if (bf) pcls = la_conv_bf16_uses_halo(as) ? LA_PC_CONV_HALO : LA_PC_CONV_FLAT;
         pslot = la_prof_open(pcls, pflops, pbytes, stream);

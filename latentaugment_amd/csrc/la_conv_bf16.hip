@@ -309,12 +309,12 @@ int la_conv_xscale_from_pmax(const float* pmax, int nseg, const float* scale, in
 template <bool F16>
 __global__ __launch_bounds__(256) void la_presplit_t_kernel(const float* __restrict__ in, long in_bstride,
                                                            const float* __restrict__ scale, int scale_stride,
-                                                           const float* __restrict__ xscale, unsigned* __restrict__ out, int C, long HW) {
+                                                           const float* __restrict__ xscale, int xs_fan, unsigned* __restrict__ out, int C, long HW) {
     constexpr int EW = F16 ? 1 : 2;                           // dwords per element
     __shared__ unsigned tile[EW][64][33];
     const int cc = blockIdx.y, b = blockIdx.z, nck = gridDim.y;
     const long p0 = (long)blockIdx.x * 64;
-    const float xs = F16 ? xscale[b] : 1.f;
+    const float xs = F16 ? la_xs_get(xscale, b, xs_fan) : 1.f;
     {
         const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
         const long p = p0 + px;
@@ -392,7 +392,7 @@ static int prepare_scale(LaConvArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(la_xscale_kernel, dim3(a.B), dim3(256), 0, stream, pm, xscale, a.C * ns);
     }
     LA_CHECK_LAUNCH();
-    a.acc_scale_x = xscale;
+    a.acc_scale_x = xscale; a.acc_scale_fan = 1;
     a.ws = base + hb;
     a.ws_bytes -= hb;
     return LA_OK;
@@ -441,12 +441,12 @@ int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
         if (rc) return rc;
         void* q = a.ws;
         hipLaunchKernelGGL(la_presplit_t_kernel<true>, pgrid, dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale, a.scale_stride,
-                           a.acc_scale_x, (unsigned*)q, a.C, HW);
+                           a.acc_scale_x, a.acc_scale_fan, (unsigned*)q, a.C, HW);
         a.in_q = q;
     } else {
         void* q = base + presplit_hdr_bytes(a.B, a.C);
         hipLaunchKernelGGL(la_presplit_t_kernel<false>, pgrid, dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale, a.scale_stride,
-                           (const float*)nullptr, (unsigned*)q, a.C, HW);
+                           (const float*)nullptr, 0, (unsigned*)q, a.C, HW);
         a.in_q = q;
     }
     LA_CHECK_LAUNCH();
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         for (int j = 0; j < NJ; ++j) {
             int bb = bz;
             if (SPLIT) { const int nidx = ntile * NT + (wn * NJ + j) * 32 + l31; bb = nidx < Ntot ? nidx / G : 0; }
-            const float inv = iw / a.acc_scale_x[bb];
+            const float inv = iw / la_xs_get(a.acc_scale_x, bb, a.acc_scale_fan);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         for (int t = 0; t < 8; ++t) ps_load(0, t, pre[t]);
         if constexpr (!M16) { load_a(0, 0, 0, acur[0]); load_a(0, 0, 1, acur[1]); }
         {
-            const float xs = F16 ? a.acc_scale_x[b] : 1.f;
+            const float xs = F16 ? la_xs_get(a.acc_scale_x, b, a.acc_scale_fan) : 1.f;
             for (int k = tid; k < nck * KCB; k += 256)
                 scl[k] = k < a.C ? (a.in_scale ? a.in_scale[(long)b * a.scale_stride + k] : 1.f) * xs : 0.f;
         }
@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         load_a(0, 0, 0, acur[0]);
         load_a(0, 0, 1, acur[1]);
         {      // per-channel factors: filled after the halo / weight loads were issued, so that the latencies overlap
-            const float xs = F16 ? a.acc_scale_x[b] : 1.f;
+            const float xs = F16 ? la_xs_get(a.acc_scale_x, b, a.acc_scale_fan) : 1.f;
             for (int k = tid; k < nck * KCB; k += 256)
                 scl[k] = k < a.C ? (a.in_scale ? a.in_scale[(long)b * a.scale_stride + k] : 1.f) * xs : 0.f;
         }
@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     // 16x16 tiles -> the 32x32 accumulator layout of the epilogue, through LDS (free after the loop's last barrier), two tile rows
     // at a time: image [wave][64 pixels][36 floats] (32 rows + 4 of padding), 16-byte writes and reads
     {
-        const float inv = 1.f / (a.acc_scale_w[0] * a.acc_scale_x[b]);
+        const float inv = 1.f / (a.acc_scale_w[0] * la_xs_get(a.acc_scale_x, b, a.acc_scale_fan));
         float* tb = reinterpret_cast<float*>(smem) + wid * (64 * 36);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -1545,7 +1545,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     }
   }
     if (F16) {
-        const float inv = 1.f / (a.acc_scale_w[0] * a.acc_scale_x[b]);
+        const float inv = 1.f / (a.acc_scale_w[0] * la_xs_get(a.acc_scale_x, b, a.acc_scale_fan));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll

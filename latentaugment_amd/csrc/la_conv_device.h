@@ -78,7 +78,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
             // fused seam of the layer that produced xin (see LaConvArgs): LDS rows 6, 7 = its demod / bias, 8.. = ddn partials,
             // 12.. = maxima (the 16-bit kernels' LDS is large enough; the fp32 kernel never sets seam_ddn_part)
             const bool seam = a.seam_ddn_part != nullptr && x0 != nullptr;
-            const float xs_seen = (seam && a.seam_xs_out) ? la_xs_peek(a.seam_xs_out + b) : 0.f;      // (early: its latency hides under the epilogue)
+            const float xs_seen = (seam && a.seam_xs_out) ? la_xs_peek(a.seam_xs_out + (long)b * LA_XS_FAN + la_xs_sub()) : 0.f;      // (early: its latency hides under the epilogue)
             // (activation backward from the saved output as straight-line selects with reciprocals: same values as
             //  la_act_bwd_from_y / la_act_inv up to the rounding of 1/gain, 1/alpha)
             const float s_pos = a.seam_gain, s_neg = a.seam_act == LA_ACT_LRELU ? a.seam_gain * a.seam_alpha : (a.seam_act == LA_ACT_RELU ? 0.f : a.seam_gain);
@@ -256,7 +256,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                         for (int k = tid; k < MT; k += 64) m = fmaxf(m, red[12][k]);
 #pragma unroll
                         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-                        if (tid == 0) la_xs_lower(a.seam_xs_out + b, xs_seen, a.seam_xs_mult, m);
+                        if (tid == 0) la_xs_lower(a.seam_xs_out + (long)b * LA_XS_FAN + la_xs_sub(), xs_seen, a.seam_xs_mult, m);
                     }
                 }
             }
@@ -381,7 +381,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
         const float* xin_b = a.xin ? a.xin + (long)b * a.xin_bstride : nullptr;
         const float* os_b = a.out_scale ? a.out_scale + (long)b * a.oscale_stride : nullptr;
         const bool seam = a.seam_ddn_part != nullptr && xin_b != nullptr;      // fused seam of the layer that produced xin (LaConvArgs)
-        const float xs_seen = (seam && a.seam_xs_out) ? la_xs_peek(a.seam_xs_out + b) : 0.f;
+        const float xs_seen = (seam && a.seam_xs_out) ? la_xs_peek(a.seam_xs_out + (long)b * LA_XS_FAN + la_xs_sub()) : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -472,7 +472,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                         if (m0 + k < a.M) m = fmaxf(m, red[12][k]);
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-                    if (tid == 0) la_xs_lower(a.seam_xs_out + b, xs_seen, a.seam_xs_mult, m);
+                    if (tid == 0) la_xs_lower(a.seam_xs_out + (long)b * LA_XS_FAN + la_xs_sub(), xs_seen, a.seam_xs_mult, m);
                 }
             }
         }

@@ -122,7 +122,7 @@ static size_t d_layout(la_disc* h, void* ws) {
     dconv_layout(c, h->econv);
     { size_t w = la_modconv_workspace_bytes((int)mb, h->C4 + 1, h->C4 + 1, 4, 0); if (w > cw) cw = w; }
     h->mb = c.take(mb * (h->C4 + 1) * 16); h->yc = c.take(mb * h->C4 * 16); h->fc = c.take(mb * h->C4);
-    h->xs_fwd = c.take(mb);
+    h->xs_fwd = c.take(mb * LA_XS_FAN);
     h->logits = c.take(mb); h->dlogits = c.take(mb); h->g_fc = c.take(mb * h->C4); h->g_flat = c.take(mb * (h->C4 + 1) * 16);
     h->gA = c.take(gmax); h->gB = c.take(gmax); h->scrA = c.take(smax); h->scrB = c.take(gmax);
     h->pm = c.take(pmax);
@@ -199,12 +199,16 @@ extern "C" int la_disc_create(int img_resolution, int img_channels, const int* c
     }
     if (rc) { free(h); return rc; }
     {   // bound 4 * clamp covers every forward input (see xs_fwd); the scale is the power of two that puts the bound in [2^14, 2^15)
-        float hx[256];
         int e = 0;
         frexpf(4.f * (conv_clamp > 0.f ? conv_clamp : 1.f), &e);
-        for (int i = 0; i < max_batch && i < 256; ++i) hx[i] = ldexpf(1.f, 15 - e);
-        LA_HIP(hipMemcpyAsync(h->xs_fwd, hx, sizeof(float) * (max_batch < 256 ? max_batch : 256), hipMemcpyHostToDevice, stream));
-        LA_HIP(hipStreamSynchronize(stream));      // (hx is a stack buffer)
+        const int nb = max_batch < 256 ? max_batch : 256;
+        float* hx = (float*)malloc(sizeof(float) * (size_t)nb * LA_XS_FAN);      // (slot rows: every sub-slot holds the constant)
+        if (!hx) { free(h); la_set_error("disc_create: out of host memory"); return LA_ERR_ARG; }
+        for (size_t i = 0; i < (size_t)nb * LA_XS_FAN; ++i) hx[i] = ldexpf(1.f, 15 - e);
+        const hipError_t ce = hipMemcpyAsync(h->xs_fwd, hx, sizeof(float) * (size_t)nb * LA_XS_FAN, hipMemcpyHostToDevice, stream);
+        const hipError_t se = hipStreamSynchronize(stream);
+        free(hx);
+        if (ce != hipSuccess || se != hipSuccess) { free(h); la_set_error("disc_create: copying the operand scales failed"); return LA_ERR_HIP; }
     }
     *out = h;
     return LA_OK;
@@ -468,7 +472,7 @@ static int conv_same(la_disc* h, const DConv& L, bool backward, const float* in,
     if (backward) { a.epi = LA_EPI_BWD; }
     else {
         a.epi = LA_EPI_FWD; a.bias = L.bias; a.act = act; a.alpha = 0.2f; a.gain = gain; a.clamp = clamp; a.addend = addend; a.out2 = out2;
-        if (h->precision == LA_PREC_F16X2 && h->clamp > 0.f && h->maxB <= 256) a.acc_scale_x = h->xs_fwd;      // bound-based scale: no absmax pass
+        if (h->precision == LA_PREC_F16X2 && h->clamp > 0.f && h->maxB <= 256) { a.acc_scale_x = h->xs_fwd; a.acc_scale_fan = LA_XS_FAN; }      // bound-based scale: no absmax pass
     }
     return la_conv_launch(a, stream);
 }
@@ -508,7 +512,7 @@ extern "C" int la_disc_forward(la_disc* h, const float* img, int B, hipStream_t 
             a.epi = LA_EPI_FWD; a.bias = b.conv1.bias; a.act = LA_ACT_LRELU; a.alpha = 0.2f; a.gain = sq2 * rs2;
             a.clamp = h->clamp >= 0.f ? h->clamp * rs2 : -1.f;
             a.addend = b.ysk; a.out2 = b.sum;
-            if (h->precision == LA_PREC_F16X2 && h->clamp > 0.f && h->maxB <= 256) a.acc_scale_x = h->xs_fwd;
+            if (h->precision == LA_PREC_F16X2 && h->clamp > 0.f && h->maxB <= 256) { a.acc_scale_x = h->xs_fwd; a.acc_scale_fan = LA_XS_FAN; }
             if ((rc = la_conv_launch(a, stream))) return rc;
         }
     }

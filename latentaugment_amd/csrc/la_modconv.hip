@@ -50,7 +50,7 @@ int la_modconv3x3_fwd_ex(const float* x, long x_bstride, const float* in_pmax, i
         a.rgb_imgc = rgb->imgc; a.rgb_w = rgb->w; a.rgb_s = rgb->s; a.rgb_s_stride = rgb->s_stride; a.rgb_bias = rgb->bias;
         a.rgb_skip = rgb->skip; a.rgb_pre = rgb->rgb_pre; a.rgb_img = rgb->img; a.rgb_clamp = rgb->clamp;
     }
-    if (precision == LA_PREC_F16X2) a.acc_scale_x = xscale;      // preset operand scale (bound-based): no absmax / plane-maxima pass
+    if (precision == LA_PREC_F16X2 && xscale) { a.acc_scale_x = xscale; a.acc_scale_fan = LA_XS_FAN; }      // preset operand scale (slot rows of the caller): no absmax / plane-maxima pass
     a.in = x; a.in_bstride = x_bstride; a.wgt = wf; a.out = y; a.in_pmax = in_pmax; a.in_pmax_nseg = in_nseg;
     a.in_scale = s; a.scale_stride = s_stride;
     a.ws = ws; a.ws_bytes = ws_bytes;
@@ -94,7 +94,7 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
     a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW;
     if (scratch_pitch > 0) { a.out_pitch = scratch_pitch; a.out_plane = (long)scratch_pitch * (res + 1); }      // padded (2h+1)-wide rows
     if (scratch_xhalf > 0) { a.out_sx = 1; a.Wout = scratch_pitch; }      // column-planar rows: phase px writes the contiguous run from px * xhalf
-    if (precision == LA_PREC_F16X2) a.acc_scale_x = xscale;      // preset operand scale (bound-based): no absmax pass
+    if (precision == LA_PREC_F16X2 && xscale) { a.acc_scale_x = xscale; a.acc_scale_fan = LA_XS_FAN; }      // preset operand scale (slot rows of the caller): no absmax pass
     if (precision != LA_PREC_F32) {
         // split the (modulated) input once for the four phase launches
         int rc = la_conv_prepare_input(a, stream);
@@ -166,7 +166,7 @@ int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, con
     a.B = B; a.C = cout; a.M = cin; a.Hin = a.Win = a.Hout = a.Wout = a.Gy = a.Gx = res;
     a.ntaps = 9;
     for (int t = 0; t < 9; ++t) { a.tap_dy[t] = 1 - t / 3; a.tap_dx[t] = 1 - t % 3; a.tap_w[t] = t; }
-    if (precision == LA_PREC_F16X2 && xscale) { a.acc_scale_x = xscale; a.in_pmax = nullptr; }      // preset operand scale
+    if (precision == LA_PREC_F16X2 && xscale) { a.acc_scale_x = xscale; a.acc_scale_fan = LA_XS_FAN; a.in_pmax = nullptr; }      // preset operand scale (slot rows)
     a.epi = LA_EPI_BWD;
     a.out_scale = s; a.oscale_stride = s_stride;
     a.xin = xin; a.xin_bstride = xin_bstride;
@@ -207,17 +207,18 @@ int la_modconv3x3_up2_bwd_ex(const float* gz, const float* gz_pmax, int gz_nseg,
         // fp16 mode with the plane maxima of gz at hand (left by the seam kernel): ONE pass turns gz into the contraction's
         // operand -- FIR adjoint (pad 2, flipped taps, gain 4; upfirdn2d.py:255-266) + operand scale + fp16 split + channel
         // interleave.  The scale comes from the bound |adjoint(gz)| <= 4 * sum(f) * max|gz| = 4 * max|gz| (see la_upfirdn2d.hip).
-        const float* xscale = xscale_in;      // (already final: the producer of gz lowered it with the same bound, la_modconv_up2_bwd_xs_mult)
+        const float* xscale = xscale_in;      // (slot rows, already final: the producer of gz lowered them with the same bound, la_modconv_up2_bwd_xs_mult)
+        int xs_fan = LA_XS_FAN;
         unsigned* q = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + 512);
         int rc;
         if (!xscale) {
             float* xs = static_cast<float*>(ws);
             if ((rc = la_conv_xscale_from_pmax(gz_pmax, gz_nseg, nullptr, 0, la_modconv_up2_bwd_xs_mult(fir_host), xs, B, cout, stream))) return rc;
-            xscale = xs;
+            xscale = xs; xs_fan = 1;
         }
-        if ((rc = la_fir4x4_adjoint_pack_f16(gz, q, xscale, B, cout, res, res, fir_host, 4.f, stream))) return rc;
+        if ((rc = la_fir4x4_adjoint_pack_f16(gz, q, xscale, xs_fan, B, cout, res, res, fir_host, 4.f, stream))) return rc;
         a.in = gz;                       // (not read: the launch takes its operand from in_q)
-        a.in_q = q; a.acc_scale_x = xscale;
+        a.in_q = q; a.acc_scale_x = xscale; a.acc_scale_fan = xs_fan;
         a.ws = static_cast<char*>(ws) + fused_need; a.ws_bytes = ws_bytes - fused_need;
         return la_conv_launch(a, stream);
     }

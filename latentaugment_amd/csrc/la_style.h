@@ -43,7 +43,7 @@ struct LaSeamArgs {
     const float* s_rgb; int s_stride;   // styles of the ToRGB layer (already * weight_gain)
     float* dweff_part;       // [B][imgc][C][slabs]
     float* pmax_out;         // optional [B][C][slabs]: partial max |gz| per plane (one per workgroup)
-    float* xs_out; float xs_mult;      // optional [B] (needs pmax_out): fp16 operand scale of gz for its consumer, pow2 scale of xs_mult * max|gz|
+    float* xs_out; float xs_mult;      // optional slot rows [B][LA_XS_FAN] (la_common.h): fp16 operand scale of gz for its consumer, pow2 scale of xs_mult * max|gz|
 };
 
 int la_pack_conv_weights(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps, hipStream_t,

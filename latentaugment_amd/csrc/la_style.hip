@@ -163,9 +163,12 @@ __global__ __launch_bounds__(256) void la_xscale_bound_kernel(LaDemodTable t, co
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        xs[(long)l * B + b] = la_pow2_scale(bound[l] * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
-        if (xs_bwd) xs_bwd[(long)l * B + b] = LA_XS_INIT;      // the backward pass's running operand scales start over (la_xs_lower)
+    // slot rows [l][b][LA_XS_FAN]: the bound-based forward scale in sub-slot 0 (the rest at LA_XS_INIT, i.e. neutral for the row minimum);
+    // the backward pass's running operand scales start over (la_xs_lower)
+    if (threadIdx.x < LA_XS_SUBS) {
+        const long o = ((long)l * B + b) * LA_XS_FAN + threadIdx.x * LA_XS_LINE;
+        xs[o] = threadIdx.x == 0 ? la_pow2_scale(bound[l] * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))) : __uint_as_float(LA_XS_INIT);
+        if (xs_bwd) xs_bwd[o] = LA_XS_INIT;
     }
 }
 
@@ -341,6 +344,8 @@ __global__ __launch_bounds__(256) void la_seam_bwd_kernel(LaSeamArgs a) {
 #pragma unroll
     for (int k = 0; k < IMGC; ++k) weff[k] = a.wrgb[k * a.C + c] * a.s_rgb[(long)b * a.s_stride + c];
     float ddn = 0.f, gmax = 0.f;
+    float* xs_row = a.xs_out ? a.xs_out + (long)b * LA_XS_FAN + la_xs_sub() : nullptr;
+    const float xs_seen = (xs_row && threadIdx.x == 0) ? la_xs_peek(xs_row) : 0.f;      // (early: its round trip hides under the stream)
     // activation backward from the saved output as straight-line selects with reciprocals (the same arithmetic as the seam fused into
     // the contraction epilogues, la_conv_device.h): la_act_bwd_from_y / la_act_inv up to the rounding of 1/gain, 1/alpha
     const float s_pos = a.gain, s_neg = a.act == LA_ACT_LRELU ? a.gain * a.alpha : (a.act == LA_ACT_RELU ? 0.f : a.gain);
@@ -399,14 +404,17 @@ __global__ __launch_bounds__(256) void la_seam_bwd_kernel(LaSeamArgs a) {
         *reinterpret_cast<float4*>(a.gz + plane + p) = gz;
         gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(gz.x), fabsf(gz.y)), fmaxf(fabsf(gz.z), fabsf(gz.w))));
     }
-    if (a.pmax_out) {
+    if (a.pmax_out || a.xs_out) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
         __syncthreads();
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gmax;
         __syncthreads();
         if (threadIdx.x == 0) {
-            a.pmax_out[((long)b * a.C + c) * gridDim.x + slab] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            if (a.pmax_out) a.pmax_out[((long)b * a.C + c) * gridDim.x + slab] = m;
+            // the consumer's fp16 operand scale: this workgroup's maximum lowers a sub-slot of the sample's row (la_common.h)
+            if (xs_row) la_xs_lower(xs_row, xs_seen, a.xs_mult, m);
         }
         __syncthreads();
     }
@@ -437,11 +445,6 @@ int la_seam_backward(const LaSeamArgs& a, int B, int imgc, hipStream_t stream) {
 #undef LAUNCH
     la_prof_close(pslot, stream);
     LA_CHECK_LAUNCH();
-    // the consumer's fp16 operand scale (thousands of short workgroups: a reduction launch, not la_xs_lower -- see la_conv_launch)
-    if (a.xs_out) {
-        LA_CHECK_ARG(a.pmax_out, "seam: xs_out needs pmax_out as scratch");
-        return la_conv_xscale_from_pmax(a.pmax_out, (int)grid.x, nullptr, 0, a.xs_mult, a.xs_out, B, a.C, stream);
-    }
     return LA_OK;
 }
 

@@ -57,8 +57,8 @@ struct la_synth {
                              // up-sampling layer's backward contraction of the block above
     float* pmax2;            // [maxB][cout][tiles]: plane maxima of an up-sampling layer's gz when its seam is fused into the epilogue of
                              // the conv1 backward contraction above it
-    float* xs_fwd;           // [nconv][B]: fp16 operand scales of the forward contractions (from the clamp bound, one launch per pass)
-    float* xs_bwd;           // [nconv][B]: running fp16 operand scales of the backward contractions' inputs, lowered by the producing kernels
+    float* xs_fwd;           // [nconv][B][LA_XS_FAN] slot rows: fp16 operand scales of the forward contractions (from the clamp bound, one launch per pass)
+    float* xs_bwd;           // [nconv][B][LA_XS_FAN] slot rows: running fp16 operand scales of the backward contractions' inputs, lowered by the producing kernels
     float* xs_bound;         // [nconv]: bound on |input| of conv layer k: max|const| for the first, conv_clamp for the rest
     int lastB;
     int precision;
@@ -159,8 +159,8 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
         }
         h->pmax3 = c.take(f3 ? f3 : 16);
     }
-    h->xs_fwd = c.take((size_t)h->nconv * mb);
-    h->xs_bwd = c.take((size_t)h->nconv * mb);
+    h->xs_fwd = c.take((size_t)h->nconv * mb * LA_XS_FAN);
+    h->xs_bwd = c.take((size_t)h->nconv * mb * LA_XS_FAN);
     h->xs_bound = c.take((size_t)h->nconv + 16);
     *need = c.off;
     return LA_OK;
@@ -367,14 +367,14 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
             if (!L.up) {
                 rc = la_modconv3x3_fwd_ex(x, x_bstride, x_pmax, x_nseg, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                           L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f, sq2,
-                                          h->clamp, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream, bound_scale ? h->xs_fwd + (long)ci * B : nullptr,
+                                          h->clamp, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream, bound_scale ? h->xs_fwd + (long)ci * B * LA_XS_FAN : nullptr,
                                           (fuse_rgb && q == nl - 1) ? &rf : nullptr);
                 x_pmax = nullptr;
             } else {
                 rc = la_modconv3x3_up2_fwd_ex(x, x_bstride, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                               L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f,
                                               sq2, h->clamp, h->fir, h->zT, L.y, (f16 && !bound_scale) ? h->pmax : nullptr, h->cws, h->cws_bytes, B, L.cin,
-                                              L.cout, res, stream, bound_scale ? h->xs_fwd + (long)ci * B : nullptr,
+                                              L.cout, res, stream, bound_scale ? h->xs_fwd + (long)ci * B * LA_XS_FAN : nullptr,
                                               zt_dense ? 0 : 2 * zt_xhalf(res), zt_dense ? 0 : zt_xhalf(res));      // (plane maxima come from the scalar FIR kernel only)
                 x_pmax = (f16 && !bound_scale) ? h->pmax : nullptr;
                 x_nseg = la_fir4x4_segments(res, res);
@@ -428,7 +428,7 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
     static const bool no_xs = getenv("LA_NO_XS_HANDOFF") != nullptr;      // dev knob
     const bool xs_hand = f16 && h->clamp > 0.f && !no_xs;
     const float up_mult = la_modconv_up2_bwd_xs_mult(h->fir);
-    auto xs_slot = [&](int conv_index) { return xs_hand ? h->xs_bwd + (long)conv_index * B : nullptr; };
+    auto xs_slot = [&](int conv_index) { return xs_hand ? h->xs_bwd + (long)conv_index * B * LA_XS_FAN : nullptr; };
     bool seam2_done = false;      // this block's conv1 seam was already applied by the epilogue of the up layer's backward above it
     for (int k = h->nblocks - 1; k >= 0; --k) {
         const int res = 4 << k;
@@ -449,8 +449,8 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
             s.ddn_part = L1.ddnp;
             s.g_img = gi; s.rgb_pre = T.rgb_pre; s.rgb_clamp = h->clamp; s.wrgb = T.weight;
             s.s_rgb = h->s_all + T.s_off; s.s_stride = h->S; s.dweff_part = T.dwep;
-            if (f16) s.pmax_out = h->pmax;      // the seam kernel leaves the plane maxima of gz for the contraction that follows
-            if (xs_hand) { s.xs_out = xs_slot(ci); s.xs_mult = 1.f; }
+            if (xs_hand) { s.xs_out = xs_slot(ci); s.xs_mult = 1.f; }      // the seam kernel lowers the slot row of the contraction that follows ...
+            else if (f16) s.pmax_out = h->pmax;                              // ... or leaves the plane maxima of gz for it
             if ((rc = la_seam_backward(s, B, h->imgc, stream))) return rc;
         }
         {
@@ -491,8 +491,8 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
             s.noise = L0.noise_used; s.noise_bstride = L0.noise_bstride; s.noise_strength = L0.noise_strength;
             s.act = LA_ACT_LRELU; s.alpha = 0.2f; s.gain = sqrtf(2.f); s.clamp = h->clamp;
             s.ddn_part = L0.ddnp;
-            if (f16) s.pmax_out = h->pmax;      // plane maxima of gz: bound for the operand scale of the fused FIR-adjoint + split pass
             if (xs_hand) { s.xs_out = xs_slot(ci); s.xs_mult = up_mult; }
+            else if (f16) s.pmax_out = h->pmax;      // plane maxima of gz: bound for the operand scale of the fused FIR-adjoint + split pass
             if ((rc = la_seam_backward(s, B, 0, stream))) return rc;
         }
         // ---- image gradient one level down: adjoint of upsample2d = FIR (flipped) + decimate 2, pad (1,1,1,1), gain 4

@@ -22,5 +22,5 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
 
 // FIR adjoint of an up-sampling layer written straight into the stride-2 backward contraction's operand format (fp16 mode):
 // q [B][ceil(C/32)][(H+1)*(W+1)][32 channels] = {h | l << 16} of xscale[b] * adjoint(in); see la_upfirdn2d.hip
-int la_fir4x4_adjoint_pack_f16(const float* in, unsigned* q, const float* xscale, int B, int C, int H, int W, const float* f_host,
+int la_fir4x4_adjoint_pack_f16(const float* in, unsigned* q, const float* xscale, int xs_fan, int B, int C, int H, int W, const float* f_host,
                                float gain, hipStream_t stream);

@@ -478,7 +478,8 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
 struct FirPackArgs {
     const float* in;       // [B][C][H][W], W % 4 == 0, 16-byte aligned planes
     unsigned* out;         // [B][nck][Hz*Wz][32]
-    const float* xscale;   // [B]
+    const float* xscale;   // [B], or slot rows [B][LA_XS_FAN] (xs_fan = LA_XS_FAN)
+    int xs_fan;
     int B, C, H, W, Hz, Wz, nck, pad;
     float f[16];           // effective correlation taps (flip and gain folded in)
 };
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void l
     const int b = blockIdx.z / a.nck, ck = blockIdx.z - b * a.nck;
     const int Xb = blockIdx.x * 64, Yb = blockIdx.y * 8;
     const int X0 = Xb + xg * 4, Y0 = Yb + rs * 4;
-    const float xs = a.xscale[b];
+    const float xs = la_xs_get(a.xscale, b, a.xs_fan);
     unsigned pk[4][4][4];                                 // [row][col][channel of the group]: {h | l << 16}
     const bool lo_ok = X0 - 4 >= 0, mid_ok = X0 < a.W, hi_ok = X0 + 4 < a.W;
 #pragma unroll
@@ -574,12 +575,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void l
 }
 
 // in [B][C][H][W] -> q [B][ceil(C/32)][(H+1)*(W+1)][32] packed fp16 pairs of  xscale[b] * (FIR adjoint of `in`)
-int la_fir4x4_adjoint_pack_f16(const float* in, unsigned* q, const float* xscale, int B, int C, int H, int W, const float* f_host,
+int la_fir4x4_adjoint_pack_f16(const float* in, unsigned* q, const float* xscale, int xs_fan, int B, int C, int H, int W, const float* f_host,
                                float gain, hipStream_t stream) {
     LA_CHECK_ARG(in && q && xscale && f_host, "fir_adjoint_pack: null pointer");
     LA_CHECK_ARG(W % 4 == 0 && (((size_t)in | (size_t)q) & 15) == 0, "fir_adjoint_pack: rows must be 16-byte aligned");
     FirPackArgs a;
-    a.in = in; a.out = q; a.xscale = xscale; a.B = B; a.C = C; a.H = H; a.W = W; a.Hz = H + 1; a.Wz = W + 1; a.nck = la_cdiv(C, 32);
+    a.in = in; a.out = q; a.xscale = xscale; a.xs_fan = xs_fan; a.B = B; a.C = C; a.H = H; a.W = W; a.Hz = H + 1; a.Wz = W + 1; a.nck = la_cdiv(C, 32);
     a.pad = 2;         // adjoint of pad (1,1,1,1): fw - 1 - pad = 2 per side (upfirdn2d.py:255-266)
     // adjoint = correlation with the flipped filter = flip_filter of the forward op negated; the forward (flip_filter = False)
     // correlates with the flipped taps, so the adjoint correlates with the taps as given
