@@ -79,7 +79,6 @@ def parse():
     p.add_argument('--latent-steps', type=int, default=20)
     p.add_argument('--res', type=int, default=256)
     p.add_argument('--channel-base', type=int, default=32768, help='32768 = config-f, 16384 = config-e')
-    p.add_argument('--criterion-mode', default='gemm', choices=['gemm', 'collapsed'])
     p.add_argument('--precision', default='f16x2', choices=['f32', 'f16x2', 'bf16x3', 'bf16x2'],
                    help='contraction arithmetic: exact fp32 MFMA, or fp32 operands split into 2 scaled fp16 / 3 bf16 / 2 bf16 terms '
                         'on the 16-bit MFMA (fp32 accumulate); f16x2 and bf16x3 have fp32-class error')
@@ -95,6 +94,9 @@ def parse():
     p.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                    help="'gloo' + --force-device rehearses the multi-rank path on a 1-GPU box (collective staged through host)")
     p.add_argument('--force-device', type=int, default=-1, help='rehearsal only: every rank uses this device index')
+    p.add_argument('--dev-build', action='store_true',
+                   help='measurement tooling only (scripts/): run on the development build of the library, which honours the LA_* '
+                        'environment switches; the line then says so')
     p.add_argument('--force-dist', action='store_true',
                    help='rehearsal only: with ONE rank under a launcher, still create the process group and take the sharded path '
                         '(broadcast, shard, all_gather, barrier, max-reduce) -- the RCCL calls of the N-rank run on a 1-GPU box')
@@ -115,7 +117,7 @@ def make_opt(args, local_rank, global_batch):
         img_resolution=args.res, batch_size=global_batch, modalities_aug='A,B', opt_num_epochs=args.latent_steps, opt_lr=0.01,
         truncation_psi=1.0, w_pix=args.w_pix, w_lpips=args.w_lpips, w_latent=args.w_latent, w_disc=args.w_disc, crop_size_aug=64,
         preprocess_aug='center_random_crop', soft_aug=False, alpha=1.0, verbose_log=False, rand_aug=False,
-        lower_bound_clip=False, p_thres=0.0, init_w='inv', criterion_mode=args.criterion_mode, final_noise_mode='random',
+        lower_bound_clip=False, p_thres=0.0, init_w='inv', final_noise_mode='random',
         precision=args.precision, hip_graph=not args.no_graph, operand_scale=args.operand_scale)
 
 
@@ -301,6 +303,8 @@ def main():
             dist.init_process_group('gloo')
 
     from latentaugment_amd import _lib, synthetic
+    if args.dev_build:
+        _lib.select_dev_build()
     from latentaugment_amd.augments import create_augment
     from latentaugment_amd.latent_aug import InMemoryLatentCodes
 
@@ -327,11 +331,18 @@ def main():
         aug = create_augment(opt)
     random.seed(6)
 
+    host_s = [0.0]
+
     def one_step():
         # the reference driver's loop body (backbone_latentaug.py:99-106)
+        t_a = time.time()
         aug.set_input(data)
+        t_b = time.time()
         aug.forward()
-        return aug.get_output()
+        t_c = time.time()
+        out = aug.get_output()
+        host_s[0] += (t_b - t_a) + (time.time() - t_c)      # set_input + get_output (device -> host copy of the whole gathered batch)
+        return out
 
     def barrier():
         if use_dist:
@@ -342,14 +353,36 @@ def main():
         one_step()
     lib = _lib.load()
     barrier()
+    host_s[0] = 0.0
+    aug.latent_aug.shard_timers = [] if use_dist else None      # (sharded forward: HIP events around this rank's loop and the gather)
     t0 = time.time()
     for _ in range(args.steps):
         out = one_step()
+    torch.cuda.synchronize()
+    local_elapsed = time.time() - t0                # this rank's own K steps, before it waits for the others
     barrier()
     elapsed = time.time() - t0
     assert out['A'].shape == (gb, 1, args.res, args.res)
+    multi = None
     if use_dist:
-        t = torch.tensor([elapsed], device=dev if args.dist_backend == 'nccl' else 'cpu', dtype=torch.float64)
+        # what a scaling curve below the ideal is made of (rank 0 prints it): every rank's own time for the K steps, the time of its
+        # shard's loop and of the one collective per step (device times between HIP events), the host part of the plugin protocol
+        tm = aug.latent_aug.shard_timers or []
+        loop_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in tm) / max(len(tm), 1)
+        gather_ms = sum(e1.elapsed_time(e2) for _, e1, e2 in tm) / max(len(tm), 1)
+        aug.latent_aug.shard_timers = None
+        cdev = dev if args.dist_backend == 'nccl' else 'cpu'
+        mine = torch.tensor([1e3 * local_elapsed / args.steps, loop_ms, gather_ms, 1e3 * host_s[0] / args.steps], device=cdev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu().numpy()
+        multi = {'per_rank_ms': {'max': float(allr[:, 0].max()), 'min': float(allr[:, 0].min()), 'all': [float(v) for v in allr[:, 0]]},
+                 'loop_ms': {'max': float(allr[:, 1].max()), 'min': float(allr[:, 1].min())},
+                 'gather_ms': {'max': float(allr[:, 2].max()), 'min': float(allr[:, 2].min())},
+                 'host_ms': {'max': float(allr[:, 3].max()), 'min': float(allr[:, 3].min())},
+                 'note': 'per_rank_ms: a rank\'s own wall time per step before the closing barrier; loop_ms / gather_ms: device time of its '
+                         'shard\'s optimisation loop and of the single all_gather per step (HIP events); host_ms: set_input + get_output'}
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     roof = None
@@ -367,11 +400,19 @@ def main():
         'config': {'workload': f'SG2 config-{"f" if args.channel_base == 32768 else "e"} {args.res}x{args.res} 2-ch, '
                                f'random-init G, batch={args.batch}/GPU, {args.latent_steps} latent steps, '
                                f'w_latent={args.w_latent:g} w_pix={args.w_pix:g} w_disc={args.w_disc:g} w_lpips={args.w_lpips:g} '
-                               f'(M_w={args.M_w}, M_x={args.M_x}), contraction={args.precision}' + (f', fp16 operand scale = {aug.latent_aug.engine.operand_scale}' + (f' (first batch: activations reach {aug.latent_aug.engine.calibration:.1e} of the clamp bound)' if getattr(aug.latent_aug.engine, 'calibration', None) is not None else '') if args.precision == 'f16x2' else '') + ', '
+                               f'(M_w={args.M_w}, M_x={args.M_x}), criteria gradients from bank column sums reduced once per handle (the '
+                               f"reference's pairwise-L2 GEMM over the banks runs only when loss scalars are requested: the API returns none), "
+                               f'contraction={args.precision}' + (f', fp16 operand scale = {aug.latent_aug.engine.operand_scale}' + (f' (first batch: activations reach {aug.latent_aug.engine.calibration:.1e} of the clamp bound)' if getattr(aug.latent_aug.engine, 'calibration', None) is not None else '') if args.precision == 'f16x2' else '') + ', '
                                f'timed call = set_input + LatentAugment.forward + get_output, '
                                'launch mode = ' + LAUNCH_MODES[aug.latent_aug.graph_state],
                    'global_batch': gb, 'parallelism': f'dp{world}'},
     }
+    if multi is not None:
+        line['multi_gpu'] = multi
+    else:
+        line['host_ms'] = 1e3 * host_s[0] / args.steps
+    if args.dev_build:
+        line['library'] = 'development build (liblatentaug_hip_dev.so): not a product measurement'
     if roof is not None:
         line['roofline'] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.preset == 'B' and args.w_disc == 0:

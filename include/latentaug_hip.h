@@ -9,7 +9,9 @@
  *   - all work is enqueued on `stream` (a hipStream_t, passed as void* from foreign code); no host<->device sync.
  *   - return 0 on success, negative on failure (LA_ERR_*); la_last_error() gives the thread's last message.
  *     This replaces the TORCH_CHECKs of the reference bindings (bias_act.cpp:35-51, upfirdn2d.cpp:19-40).
- *   - re-entrant: no global mutable state besides the thread-local error string (cf. bias_act.cpp:54,88).
+ *   - re-entrant: the only global mutable state is the thread-local error string (cf. bias_act.cpp:54,88), a once-per-device
+ *     "kernel attribute set" flag (atomic) and the opt-in launch profiler la_prof_* (off by default; ONE process-wide instance
+ *     that is not thread-safe: measurement runs only).  No kernel-variant switches, no environment variables (see la_prof_*).
  */
 #ifndef LATENTAUG_HIP_H
 #define LATENTAUG_HIP_H
@@ -293,6 +295,12 @@ int la_latent_opt_set_trace(la_latent_opt* h, float* w_trace, float* img_trace);
 /* dw_trace [steps][B][w_dim] (device, or NULL) = dL/dw of every step, L = -latent - pix - lpips + disc (util_latent_aug.py:270):
  * the tensor `loss.backward()` leaves in w_opt.grad (:275) before Adam consumes it.  While set the loop launches eagerly. */
 int la_latent_opt_set_grad_trace(la_latent_opt* h, float* dw_trace);
+/* verbose_log timers of the reference's first batch (time_latent / time_disc / time_pix / time_lpips / time_epoch,
+ * util_latent_aug.py:221-272): with the time trace on, a run that asks for the loss scalars brackets the criteria of every step with
+ * HIP events on the launch stream; la_latent_opt_get_times (after the stream has drained, or blocking) fills ms [steps][5] =
+ * {latent, disc, pix, lpips, epoch} in milliseconds.  A criterion's bracket holds its loss scalar and its gradient launches. */
+int la_latent_opt_set_time_trace(la_latent_opt* h, int enable);
+int la_latent_opt_get_times(la_latent_opt* h, float* ms);
 /* The banks handed to la_latent_opt_create / _set_lpips (register_buffer('W'/'X'/'fea_*'), util_latent_aug.py:137-171) must stay
  * IMMUTABLE for the life of the handle: their column sums are reduced once (both criterion modes) and every later gradient uses
  * them.  A caller that does rewrite bank contents in place calls this before the next la_latent_opt_run. */
@@ -332,8 +340,9 @@ int la_prof_end(double* total_ms, long* launches, double* flops, double* bytes);
 /* la_prof_set_stride(k): bracket a hashed 1-in-k sample of the launches instead of all of them (an event pair costs ~3 us on
  * the stream); la_prof_end then reports the sampled launches' ms / count / FLOPs / bytes, la_prof_total_launches() all of them. */
 int la_prof_set_stride(int stride);
-/* Development only: selects a kernel variant for in-process A/B timing (scripts/bench_layer.py --ab).  All knobs are 0 in the product. */
-int la_dev_knob_set(int id, int value);
+/* (The development build, `make dev` -> liblatentaug_hip_dev.so, additionally exports `la_dev_knob_set` (int id, int value -> int): it
+ *  selects kernel variants for in-process A/B timing by scripts/bench_layer.py --ab.  The product library has no such symbol, no
+ *  kernel-variant state and reads no LA_* environment variable.) */
 long la_prof_total_launches(void);
 /* Per kernel class (la_prof_num_classes() entries per array): 0 contraction / halo, 1 contraction / flat, 2 contraction /
  * split-K incl. its finish pass, 3 contraction / exact-fp32 MFMA, 4 operand preparation (plane maxima, pre-split copy),

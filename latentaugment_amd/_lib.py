@@ -111,12 +111,13 @@ SIGNATURES = {
     'la_latent_opt_graph_state': (_I, [_P]),
     'la_latent_opt_set_trace': (_I, [_P, _P, _P]),
     'la_latent_opt_set_grad_trace': (_I, [_P, _P]),
+    'la_latent_opt_set_time_trace': (_I, [_P, _I]),
+    'la_latent_opt_get_times': (_I, [_P, _P]),
     'la_latent_opt_set_lpips_preproc': (_I, [_P, _P, _P, _I]),
     'la_latent_opt_invalidate_banks': (_I, [_P]),
     'la_prof_begin': (_I, []),
     'la_prof_end': (_I, [_P, _P, _P, _P]),
     'la_prof_set_stride': (_I, [_I]),
-    'la_dev_knob_set': (_I, [_I, _I]),
     'la_prof_total_launches': (_L, []),
     'la_prof_num_classes': (_I, []),
     'la_prof_end_classes': (_I, [_P, _P, _P, _P, _I]),
@@ -124,6 +125,17 @@ SIGNATURES = {
 
 _lib = None
 LOADED_PATH = None
+DEV_LIB_PATH = os.path.join(_HERE, 'liblatentaug_hip_dev.so')      # `make -C latentaugment_amd/csrc dev`: measurement tools only
+_use_dev = False
+
+
+def select_dev_build():
+    """Measurement tools (scripts/) and the one test that compares two internal code paths call this BEFORE the first load():
+    the process then runs on the development build (kernel-variant knobs + LA_* environment switches).  The package never does."""
+    global _use_dev
+    if _lib is not None and not _use_dev:
+        raise LatentAugHipError('select_dev_build() must come before the library is first used')
+    _use_dev = True
 
 
 def load():
@@ -135,18 +147,21 @@ def load():
     # streams and allocations (loading ours first leaves two runtimes in the process and HIP calls fail with
     # "no ROCm-capable device is detected")
     import torch  # noqa: F401
-    path = os.environ.get('LATENTAUG_HIP_LIB') or LIB_PATH      # override: alternative builds for kernel experiments
+    path = DEV_LIB_PATH if _use_dev else LIB_PATH
     if not os.path.isfile(path):
         raise LatentAugHipError(
-            f'{path} not found: build it with `make -C latentaugment_amd/csrc` (or __graft_entry__.build()). '
+            f'{path} not found: build it with `make -C latentaugment_amd/csrc{" dev" if _use_dev else ""}` (or __graft_entry__.build()). '
             'There is no CPU fallback for the latent-augmentation hot path.')
     lib = C.CDLL(path)
     global LOADED_PATH
-    LOADED_PATH = os.path.realpath(path)      # what was actually dlopen'ed (tests check it is the in-tree build)
+    LOADED_PATH = os.path.realpath(path)      # what was actually dlopen'ed (tests check it is the in-tree product build)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if _use_dev:
+        lib.la_dev_knob_set.restype = _I
+        lib.la_dev_knob_set.argtypes = [_I, _I]
     _lib = lib
     return lib
 

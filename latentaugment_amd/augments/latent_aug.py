@@ -7,6 +7,7 @@ stats_time.  The optimisation runs on the MI355X through latentaugment_amd.laten
 Deliberate behavioural fixes: construction does not dereference `.module` (defect a); the batch is
 sized by len(fname), so a last partial batch works (defect h).
 """
+import os
 import random
 import time
 
@@ -14,6 +15,7 @@ import numpy as np
 import torch
 
 from .. import latent_aug as util_latent_aug
+from ..latent_aug import write_png_gray
 from .base_aug import BaseAugment
 
 
@@ -184,12 +186,16 @@ class LatentAugment(BaseAugment):
         self.stats_time.append(dt)
 
     def sanity_check(self):
+        """Shape / dtype checks around one forward, with the reference's two pictures (latent_aug.py:281-301): the first input pair as
+        `<name>.png` and the first augmented pair as `<name>aug.png` in save_dir."""
         for t in (self.real_A[0], self.real_B[0]):
             self.input_sanity_check(t)
+        visualize(self.real_A[0], self.real_B[0], _stem(self.fname[0]), self.save_dir)
         self.forward()
         out = self.get_output()
         for key in ('A', 'B'):
             self.output_sanity_check(out[key][0])
+        visualize(out['A'][0], out['B'][0], _stem(out['A_paths'][0]) + 'aug', self.save_dir)
 
     def sample_from_randn(self):
         return torch.randn([self.batch_size, self.z_dim])
@@ -203,3 +209,23 @@ class LatentAugment(BaseAugment):
         w = torch.from_numpy(np.ascontiguousarray(np.stack(rows)))
         assert w.shape == (len(fname), 1, self.w_dim)
         return w
+
+
+
+def _stem(path):
+    return os.path.splitext(os.path.basename(str(path)))[0]
+
+
+def visualize(imgA, imgB, img_name, save_dir):
+    """The reference's `visualize` (latent_aug.py:327-341): modality A | modality B side by side as `<save_dir>/<img_name>.png`, grey
+    levels stretched from the pair's minimum to its maximum as matplotlib's imshow does (8-bit PNG at the image's own resolution; the
+    reference renders the same array through a matplotlib figure at 400 dpi)."""
+    a = imgA.detach().cpu().numpy() if isinstance(imgA, torch.Tensor) else np.asarray(imgA)
+    b = imgB.detach().cpu().numpy() if isinstance(imgB, torch.Tensor) else np.asarray(imgB)
+    img = np.concatenate([a, b], axis=1) if a.ndim == 2 else np.concatenate([a[0], b[0]], axis=1)
+    img = img.astype(np.float64)
+    lo, hi = (float(np.nanmin(img)), float(np.nanmax(img))) if np.isfinite(img).any() else (0.0, 1.0)
+    grey = np.clip((np.nan_to_num(img, nan=lo) - lo) / (hi - lo if hi > lo else 1.0), 0.0, 1.0)
+    if save_dir:
+        os.makedirs(save_dir, exist_ok=True)
+        write_png_gray(os.path.join(save_dir, f'{img_name}.png'), np.round(grey * 255.0).astype(np.uint8))

@@ -42,7 +42,16 @@ void la_set_error(const char* msg);
 enum { LA_PC_CONV_HALO = 0, LA_PC_CONV_FLAT, LA_PC_CONV_SPLITK, LA_PC_CONV_F32, LA_PC_PRESPLIT, LA_PC_FIR, LA_PC_SEAM, LA_PC_TORGB,
        LA_PC_BANK, LA_PC_NCLASS };
 bool la_prof_enabled();      // profiler active: callers keep their launches eager
-int la_dev_knob(int id);     // kernel-variant selectors for in-process A/B measurements (la_dev_knob_set; all 0 in the product)
+// Development switches -- kernel-variant selectors for in-process A/B measurements (la_dev_knob_set) and LA_* environment switches --
+// exist in the DEVELOPMENT build only (make dev: -DLA_DEV, liblatentaug_hip_dev.so, used by scripts/).  The product library has
+// neither: every knob reads 0, no LA_* variable is looked at, la_dev_knob_set is not exported.
+#ifdef LA_DEV
+int la_dev_knob(int id);
+const char* la_dev_env(const char* name);      // getenv
+#else
+static inline int la_dev_knob(int) { return 0; }
+static inline const char* la_dev_env(const char*) { return nullptr; }
+#endif
 #define LA_KNOB_HALO_MF 0     // halo contraction form: 0 = default, 8 = round-2 form, else the MF bits of la_conv_bf16_halo_kernel
 #define LA_KNOB_HALO_MING 1   // dev: grids of fewer points than this go to split-K instead of the halo kernel (0 = 1157: up to 34x34)
 #define LA_KNOB_FLAT_MF 2     // flat / split-K contraction form: 0 = default (16x16x32 MFMA), 8 = 32x32x16

@@ -408,7 +408,7 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
     // 32-row tiles only exist for the halo kernel (the 32-channel layers of the 1024^2 generators)
     int MTsel = a.M >= 128 ? 128 : ((a.M <= 32 && bf && !a.in_q && la_conv_bf16_uses_halo(a)) ? 32 : 64);
     {   // dev knob (kernel experiments only): LA_FORCE_MT=64 runs the >= 128-row layers on 64-row tiles
-        static const int force_mt = []() { const char* e = getenv("LA_FORCE_MT"); return e ? atoi(e) : 0; }();
+        static const int force_mt = []() { const char* e = la_dev_env("LA_FORCE_MT"); return e ? atoi(e) : 0; }();
         if (force_mt == 64 && MTsel == 128) MTsel = 64;
     }
     const int mtiles = la_cdiv(a.M, MTsel);

@@ -1582,7 +1582,7 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
             attr_done[dev].store(true, std::memory_order_release);
         }
         // three-wave form for the fp16 x2 launches on 128-row tiles (see the kernel comment); dev knob LA_HALO_W3=0|1
-        static const int w3_knob = []() { const char* e = getenv("LA_HALO_W3"); return e ? atoi(e) : -1; }();
+        static const int w3_knob = []() { const char* e = la_dev_env("LA_HALO_W3"); return e ? atoi(e) : -1; }();
         const bool w3 = NTERM == 2 && MTsel == 128 && (w3_knob >= 0 ? w3_knob != 0 : true);
         if constexpr (FMT == FMT_F16X2) {
             // fp16 x2 launches on 128-row tiles with more than one chunk: the 16x16x32 / pixel-stationary form (MF 5, kernel comment).
@@ -1604,10 +1604,12 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
                     return LA_OK;
                 };
                 switch (mf) {
+#ifdef LA_DEV
                     case 1: return go(std::integral_constant<int, 1>{});
                     case 4: return go(std::integral_constant<int, 4>{});
+                    case 7: return go(std::integral_constant<int, 7>{});      // (loader ablation: wrong results, timing only)
+#endif
                     case 5: return go(std::integral_constant<int, 5>{});
-                    case 7: return go(std::integral_constant<int, 7>{});      // (loader ablation: wrong results)
                     default: break;
                 }
             }
@@ -1649,7 +1651,7 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
         return LA_OK;
     }
     // three-wave form of the 128-row fp16 x2 launches (kernel comment); dev knob LA_FLAT_W3=0|1
-    static const int f3_knob = []() { const char* e = getenv("LA_FLAT_W3"); return e ? atoi(e) : -1; }();
+    static const int f3_knob = []() { const char* e = la_dev_env("LA_FLAT_W3"); return e ? atoi(e) : -1; }();
     const bool f3 = FMT == FMT_F16X2  && MTsel == 128 && (f3_knob >= 0 ? f3_knob != 0 : true);
     constexpr int FW3 = (FMT == FMT_F16X2 ) ? 3 : 2;
     if constexpr (FMT == FMT_F16X2) {

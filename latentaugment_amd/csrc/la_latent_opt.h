@@ -34,6 +34,8 @@ int la_latent_opt_set_lpips(la_latent_opt* h, la_feat* f, const float* bankF, lo
 int la_latent_opt_set_crop_pos(la_latent_opt* h, int x, int y);
 int la_latent_opt_set_graph(la_latent_opt* h, int enable);
 int la_latent_opt_set_trace(la_latent_opt* h, float* w_trace, float* img_trace);
+int la_latent_opt_set_time_trace(la_latent_opt* h, int enable);
+int la_latent_opt_get_times(la_latent_opt* h, float* ms);
 int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const float* const* final_noises, float* img_out,
                       float* w_aug_out, float* losses_out, hipStream_t stream);
 }

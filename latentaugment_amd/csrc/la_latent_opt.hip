@@ -43,7 +43,11 @@ struct la_latent_opt {
     hipStream_t cap_stream; // capture needs a non-default stream; the replay goes to the caller's stream
     float* trace_w;         // optional [steps][B][w_dim]: the latent after every step (verbose_log snapshots); forces eager launches
     float* trace_img;       // optional [steps][B][C][R][R]: the image synthesised in every step
+    // optional per-criterion times of the verbose_log batch (la_latent_opt_set_time_trace): LA_TEV events per step on the launch stream
+    int time_trace, tev_steps;
+    hipEvent_t* tev;
 };
+#define LA_TEV 7      // step start | after synthesis | after latent | after pix | after disc | after lpips | step end
 
 static size_t al(size_t n) { return ((n * sizeof(float)) + 63) & ~(size_t)63; }
 
@@ -110,6 +114,7 @@ static void drop_graph(la_latent_opt* h) {
 extern "C" void la_latent_opt_destroy(la_latent_opt* h) {
     if (!h) return;
     drop_graph(h);
+    if (h->tev) { for (int i = 0; i < h->tev_steps * LA_TEV; ++i) (void)hipEventDestroy(h->tev[i]); free(h->tev); }
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     free(h->adam_tab_host);
     free(h);
@@ -119,6 +124,38 @@ extern "C" void la_latent_opt_destroy(la_latent_opt* h) {
 extern "C" int la_latent_opt_set_trace(la_latent_opt* h, float* w_trace, float* img_trace) {
     LA_CHECK_ARG(h, "latent_opt_set_trace: null handle");
     h->trace_w = w_trace; h->trace_img = img_trace;
+    return LA_OK;
+}
+
+// Per-criterion times of a run that asks for the loss scalars (the reference's verbose_log timers time_latent / time_disc / time_pix /
+// time_lpips / time_epoch, util_latent_aug.py:221-272): HIP events on the launch stream around the criteria of every step.  Here a
+// criterion's bracket holds its loss scalar AND its gradient launches (the reference's holds the forward only; its backward is inside
+// the untimed loss.backward()), time_epoch the whole step.  Read back with la_latent_opt_get_times after the stream has drained.
+extern "C" int la_latent_opt_set_time_trace(la_latent_opt* h, int enable) {
+    LA_CHECK_ARG(h, "latent_opt_set_time_trace: null handle");
+    if (enable && !h->tev && h->cfg.steps > 0) {
+        h->tev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * (size_t)h->cfg.steps * LA_TEV);
+        LA_CHECK_ARG(h->tev, "latent_opt_set_time_trace: out of host memory");
+        for (int i = 0; i < h->cfg.steps * LA_TEV; ++i) LA_HIP(hipEventCreate(&h->tev[i]));
+        h->tev_steps = h->cfg.steps;
+    }
+    h->time_trace = enable ? 1 : 0;
+    return LA_OK;
+}
+
+// ms [steps][5] = {time_latent, time_disc, time_pix, time_lpips, time_epoch} in milliseconds of the last run that recorded them
+// (waits for the events: call after the run's stream work is complete or let it block)
+extern "C" int la_latent_opt_get_times(la_latent_opt* h, float* ms) {
+    LA_CHECK_ARG(h && ms && h->tev, "latent_opt_get_times: no time trace recorded");
+    for (int s = 0; s < h->tev_steps; ++s) {
+        hipEvent_t* e = h->tev + (size_t)s * LA_TEV;
+        LA_HIP(hipEventSynchronize(e[LA_TEV - 1]));
+        float t[LA_TEV - 1];
+        for (int k = 0; k + 1 < LA_TEV; ++k) LA_HIP(hipEventElapsedTime(&t[k], e[k], e[k + 1]));
+        float* o = ms + (size_t)s * 5;
+        o[0] = t[1]; o[2] = t[2]; o[1] = t[3]; o[3] = t[4];
+        LA_HIP(hipEventElapsedTime(&o[4], e[0], e[LA_TEV - 1]));
+    }
     return LA_OK;
 }
 
@@ -282,14 +319,19 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     // one optimisation step; L = this step's row of loss scalars or null.  Everything it launches is independent of the step
     // number (the Adam bias corrections and the LPIPS window position are read from device memory), so the same launch
     // sequence can be captured once and replayed.
-    auto run_step = [&](float* L, hipStream_t st) -> int {
+    auto run_step = [&](float* L, hipStream_t st, int step_index = -1) -> int {
         int rc;
+        hipEvent_t* tev = (h->time_trace && h->tev && L && step_index >= 0 && step_index < h->tev_steps) ? h->tev + (size_t)step_index * LA_TEV : nullptr;
+        auto mark = [&](int k) { if (tev) (void)hipEventRecord(tev[k], st); };
+        mark(0);
         if ((rc = la_synth_forward(h->g, h->w_opt, wd, 0, B, c.loop_noise_mode, nullptr, nullptr, st))) return rc;
         const float* img = la_synth_image(h->g);
+        mark(1);
         if (L) {
             if (h->Mw && (rc = la_l2_mean_from_bank(h->bankW, h->Mw, (long)h->num_ws * wd, h->w_opt, B, wd, wd, h->yx, h->yy,
                                                     h->xx, lat_coef, L + 0, 0, st)))
                 return rc;
+            if (h->Mw) mark(2);
             if (h->Mx) {
                 if ((rc = la_center_crop_f32(img, h->xc, (long)B * h->imgc, h->R, cc, off, st))) return rc;
                 for (int ch = 0; ch < h->imgc; ++ch)
@@ -299,16 +341,19 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
             }
         }
         const float* dws = nullptr;
+        if (!L || !h->Mw) mark(2);      // (no latent criterion / no loss scalars: empty bracket)
         if (img_crit) {
             if (c.w_pix != 0.f &&
                 (rc = la_pix_grad(img, h->colsumX, h->g_img, B, h->imgc, h->R, cc, off, -2.f * pix_coef, (float)h->Mx, st)))
                 return rc;
+            mark(3);
             if (use_disc) {
                 // loss_disc = softplus(-D(x)).mean() * w_disc enters the total with a plus sign (:270)
                 if ((rc = la_disc_forward(h->d, img, B, st))) return rc;
                 if ((rc = la_disc_loss(h->d, c.w_disc, c.norm_batch, L ? L + 2 : nullptr, st))) return rc;
                 if ((rc = la_disc_backward(h->d, nullptr, h->g_img, c.w_pix != 0.f, st))) return rc;
             }
+            mark(4);
             if (use_lpips) {
                 // loss_lpips = mean_modes( sum_{m,n} |f_n - F_m|^2 / (n*m) ) * w_lpips, entering the total with a minus sign (:270)
                 const int N = h->imgc * B;
@@ -329,14 +374,17 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
                 if ((rc = la_crop_repeat_grad_ex3(h->l_gxc, h->g_img, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, h->crop_dev, 3, h->pre_scale, st)))
                     return rc;
             }
+            mark(5);
             if ((rc = la_synth_backward(h->g, h->g_img, h->dws, st))) return rc;
             dws = h->dws;
-        }
+        } else { mark(3); mark(4); mark(5); }
         if ((rc = la_latent_combine(dws, h->w_opt, h->Mw ? h->colsumW : nullptr, h->dw, B, h->num_ws, wd, -2.f * lat_coef,
                                     (float)h->Mw, st)))
             return rc;
         if ((rc = la_adam_step_tab(h->w_opt, h->dw, h->m, h->v, nw, c.lr, c.beta1, c.beta2, c.eps, h->adam_tab, h->step_ctr, st))) return rc;
-        return la_step_advance(h->step_ctr, st);
+        rc = la_step_advance(h->step_ctr, st);
+        mark(6);
+        return rc;
     };
 
     // Replay of a captured step.  The step is captured AFTER one eager execution with the same batch size (module loading,
@@ -366,7 +414,7 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     for (int step = first_graph_step; step <= c.steps; ++step) {
         if (replay && h->graph_exec && h->graph_B == B) LA_HIP(hipGraphLaunch(h->graph_exec, stream));
         else {
-            if ((rc = run_step(want_losses ? h->losses + (size_t)(step - 1) * 4 : nullptr, stream))) return rc;
+            if ((rc = run_step(want_losses ? h->losses + (size_t)(step - 1) * 4 : nullptr, stream, step - 1))) return rc;
             // verbose_log snapshots (util_latent_aug.py:292-295): the image synthesised in this step, the latent after its update
             if (h->trace_img)
                 LA_HIP(hipMemcpyAsync(h->trace_img + (size_t)(step - 1) * B * h->imgc * h->R * h->R, la_synth_image(h->g),

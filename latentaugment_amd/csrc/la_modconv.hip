@@ -31,7 +31,7 @@ static void fwd_shape(LaConvArgs& a, int precision, int B, int cin, int cout, in
 
 // one row tile of the halo kernel = all output channels (tiles of 128, 64 or -- for <= 32 channels -- 32 rows, la_conv_launch)
 bool la_modconv3x3_fwd_fuses_rgb(int precision, int B, int cin, int cout, int res) {
-    static const bool off = getenv("LA_NO_RGB_FUSE") != nullptr;      // dev knob
+    static const bool off = la_dev_env("LA_NO_RGB_FUSE") != nullptr;      // dev knob
     if (off || precision == LA_PREC_F32 || (cout != 128 && cout != 64 && cout != 32)) return false;
     LaConvArgs a; base_args(a);
     fwd_shape(a, precision, B, cin, cout, res);

@@ -1,6 +1,7 @@
 // Opt-in launch profiler (bench.py's roofline leg): HIP events bracket launches on the launch stream, accumulated per KERNEL
 // CLASS together with the algorithmic work of the bracketed launches.  Off by default; the only process-global state in the
-// library.  While it is on, the step loop launches eagerly (no graph replay) so that the brackets see every launch.
+// library (the development build adds its knobs).  While it is on, the step loop launches eagerly (no graph replay) so that the brackets
+// see every launch.
 #include <stdlib.h>
 #include "la_common.h"
 
@@ -16,8 +17,9 @@ static struct {
     unsigned seq;            // all bracketable launches seen since la_prof_begin
 } g_prof;
 
-// dev knobs: kernel-variant selectors so that two variants can be timed in interleaved rounds of ONE process (cdna_hip_programming.md
-// rule 24).  Every knob defaults to 0 = the shipped configuration.
+#ifdef LA_DEV
+// dev knobs (development build only): kernel-variant selectors so that two variants can be timed in interleaved rounds of ONE process
+// (cdna_hip_programming.md rule 24).  Every knob defaults to 0 = the shipped configuration.
 static int g_knob[LA_NKNOB];
 static const bool g_knob_env = []() {      // LA_DEV_KNOBS="id=value,id=value": initial knob values (development runs of whole test files)
     const char* e = getenv("LA_DEV_KNOBS");
@@ -33,11 +35,13 @@ static const bool g_knob_env = []() {      // LA_DEV_KNOBS="id=value,id=value": 
     return true;
 }();
 int la_dev_knob(int id) { return id >= 0 && id < LA_NKNOB ? g_knob[id] : 0; }
+const char* la_dev_env(const char* name) { return getenv(name); }
 extern "C" int la_dev_knob_set(int id, int value) {
     LA_CHECK_ARG(id >= 0 && id < LA_NKNOB, "dev_knob_set: unknown knob");
     g_knob[id] = value;
     return LA_OK;
 }
+#endif
 
 extern "C" int la_prof_set_stride(int stride) {
     LA_CHECK_ARG(stride >= 1 && stride <= 64, "prof: stride must be 1..64");

@@ -329,7 +329,7 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
     const bool f16 = h->precision == LA_PREC_F16X2;
     const bool bound_scale = f16 && h->clamp > 0.f && !h->data_scale;
     // scratch layout of the up layers: dense interleaved rows (plane maxima wanted: scalar FIR; dev knob LA_NO_ZT_PITCH) or column-planar
-    static const bool zt_knob_dense = getenv("LA_NO_ZT_PITCH") != nullptr;
+    static const bool zt_knob_dense = la_dev_env("LA_NO_ZT_PITCH") != nullptr;
     const bool zt_dense = (f16 && !bound_scale) || zt_knob_dense;
     // (also with data-based forward scales: the launch resets xs_bwd, the running scale slots of the backward pass)
     if (f16 && h->clamp > 0.f && (rc = la_xscale_from_bounds(h->dt, h->s_all, h->S, h->xs_bound, h->xs_fwd, B, stream, h->xs_bwd))) return rc;
@@ -417,15 +417,15 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
         c.ds_part = L.dsp; c.ddn_part = L.ddnp; c.d = h->d_all + L.d_off; c.s = h->s_all + L.s_off; c.wsq = L.wsq;
         c.ds_out = h->ds_all + L.s_off; c.ntiles = ntiles; c.nslabs = nslabs; c.cin = L.cin; c.cout = L.cout;
     };
-    static const bool no_fuse = getenv("LA_NO_SEAM_FUSE") != nullptr;      // dev knobs: A/B of the fused seams on one box
-    static const bool no_fuse2 = getenv("LA_NO_SEAM2_FUSE") != nullptr;
+    static const bool no_fuse = la_dev_env("LA_NO_SEAM_FUSE") != nullptr;      // dev knobs: A/B of the fused seams on one box
+    static const bool no_fuse2 = la_dev_env("LA_NO_SEAM2_FUSE") != nullptr;
     const bool f16 = h->precision == LA_PREC_F32 ? false : h->precision == LA_PREC_F16X2;
     // fp16 operand scales of the backward contractions: with a clamp (the forward pass then ran la_xscale_from_bounds, which also reset
     // xs_bwd) the direct contraction kernels, whose epilogues produce the next contraction's input, lower the consumer's slot
     // themselves (la_xs_lower): no plane maxima, no reduction launch between producer and consumer.  The split-K finish and the
     // seam kernel still reduce plane maxima with one small launch (inside la_conv_launch / la_seam_backward), into the same slot.
     // Without a clamp: plane maxima + la_xscale_pmax at the consumer as before.
-    static const bool no_xs = getenv("LA_NO_XS_HANDOFF") != nullptr;      // dev knob
+    static const bool no_xs = la_dev_env("LA_NO_XS_HANDOFF") != nullptr;      // dev knob
     const bool xs_hand = f16 && h->clamp > 0.f && !no_xs;
     const float up_mult = la_modconv_up2_bwd_xs_mult(h->fir);
     auto xs_slot = [&](int conv_index) { return xs_hand ? h->xs_bwd + (long)conv_index * B * LA_XS_FAN : nullptr; };

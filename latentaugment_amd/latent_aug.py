@@ -73,7 +73,8 @@ def write_curve_png(path, values, width=480, height=320, margin=24):
     x0, x1, y0, y1 = margin, width - margin - 1, margin, height - margin - 1
     img[y0, x0:x1 + 1] = img[y1, x0:x1 + 1] = 0
     img[y0:y1 + 1, x0] = img[y0:y1 + 1, x1] = 0
-    if v.size:
+    if v.size and np.isfinite(v).any():      # (an all-NaN / all-inf curve: frame only)
+        v = np.where(np.isfinite(v), v, np.nan)
         lo, hi = float(np.nanmin(v)), float(np.nanmax(v))
         span = hi - lo if hi > lo else 1.0
         xs = np.full(v.size, (x0 + x1) // 2) if v.size == 1 else np.round(x0 + 4 + (x1 - x0 - 8) * np.arange(v.size) / (v.size - 1)).astype(int)
@@ -462,7 +463,7 @@ class LatentAug:
         return img, w_aug, losses
 
     # ---- verbose_log artefacts of the first batch (reference :278-300, :620-655)
-    def _log_first_batch(self, losses, elapsed, trace, fname):
+    def _log_first_batch(self, losses, elapsed, trace, fname, times=None):
         import json
         import pickle
         L = losses.cpu().numpy()
@@ -472,9 +473,15 @@ class LatentAug:
             st = {name: float(L[e, col]) for name, col, wgt in active if wgt > 0}      # only the active criteria are logged (:233-268)
             st['loss'] = float(-L[e, 0] - L[e, 1] - L[e, 3] + L[e, 2])
             self.stats_loss[f'epoch_{e}'] = st
-            # the loop runs on the device without a host round trip per epoch: the batch time is spread evenly over the epochs
-            self.stats_time[f'epoch_{e}'] = {'time_epoch': elapsed / max(self.num_epochs, 1)}
-            desc = ''.join(f'{k} {v:<4.2f} ' for k, v in st.items()) + '||| ' + f"time_epoch {self.stats_time[f'epoch_{e}']['time_epoch']:<4.3f} "
+            # the loop runs on the device without a host round trip per epoch: the times are device times between HIP events around the
+            # criteria of the epoch (seconds, the reference's keys; a criterion's bracket holds its loss scalar and its gradient launches --
+            # the reference's the forward only, its backward sits in the untimed loss.backward()); without them the batch time spread evenly
+            if times is not None:
+                self.stats_time[f'epoch_{e}'] = {'time_latent': float(times[e, 0]), 'time_disc': float(times[e, 1]), 'time_pix': float(times[e, 2]),
+                                                 'time_lpips': float(times[e, 3]), 'time_epoch': float(times[e, 4])}
+            else:
+                self.stats_time[f'epoch_{e}'] = {'time_epoch': elapsed / max(self.num_epochs, 1)}
+            desc = ''.join(f'{k} {v:<4.2f} ' for k, v in st.items()) + '||| ' + ''.join(f'{k} {v:<4.3f} ' for k, v in self.stats_time[f'epoch_{e}'].items())
             print(f'epoch {e + 1:>4d}/{self.num_epochs}, {desc}')
         if self.save_dir and self.num_epochs > 0:
             os.makedirs(self.save_dir, exist_ok=True)
@@ -524,6 +531,10 @@ class LatentAug:
             cx, cy, noise_seed = broadcast_controls(self.crop_params['crop_pos'], self.group, self.device, self._host_group())
             self._last_controls = (cx, cy, noise_seed)
             self.crop_params = {'crop_pos': (cx, cy)}
+            timers = getattr(self, 'shard_timers', None)      # bench.py: [(start, loop done, gather done)] HIP events per forward
+            if timers is not None:
+                ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+                ev[0].record()
             if hi > lo:
                 if final_noises is not None:
                     fn = [t[lo:hi].contiguous() if t is not None else None for t in final_noises]
@@ -542,7 +553,12 @@ class LatentAug:
                 w_aug = torch.empty([0, self.num_ws, self.w_dim], device=self.device)
             # one collective per batch: image and latent packed into a single buffer
             flat = torch.cat([img.reshape(img.shape[0], -1), w_aug.reshape(w_aug.shape[0], -1)], dim=1)
+            if timers is not None:
+                ev[1].record()
             full = gather_shards(flat, per, B, self.group)
+            if timers is not None:
+                ev[2].record()
+                timers.append(ev)
             n_img = self.engine.img_channels * self.res * self.res
             img = full[:, :n_img].reshape(B, self.engine.img_channels, self.res, self.res)
             w_aug = full[:, n_img:].reshape(B, self.num_ws, self.w_dim)
@@ -560,12 +576,22 @@ class LatentAug:
         import time
         trace = {} if w.shape[0] == 1 else None
         torch.cuda.synchronize(self.device)
+        _lib.check(self._lib.la_latent_opt_set_time_trace(self._h, 1), 'la_latent_opt_set_time_trace')
         t0 = time.time()
-        img, w_aug, losses = self.run_local(w, final_noises, want_losses=True, trace=trace)
-        torch.cuda.synchronize(self.device)
+        try:
+            img, w_aug, losses = self.run_local(w, final_noises, want_losses=True, trace=trace)
+            torch.cuda.synchronize(self.device)
+            elapsed = time.time() - t0
+            times = None
+            if self.num_epochs > 0:      # per-criterion device times of every epoch (the reference's time_* keys, :221-272)
+                buf = (C.c_float * (5 * self.num_epochs))()
+                _lib.check(self._lib.la_latent_opt_get_times(self._h, buf), 'la_latent_opt_get_times')
+                times = np.asarray(buf, dtype=np.float64).reshape(self.num_epochs, 5) * 1e-3
+        finally:
+            _lib.check(self._lib.la_latent_opt_set_time_trace(self._h, 0), 'la_latent_opt_set_time_trace')
         if trace is not None:
             trace['w_in'] = w.detach().cpu().numpy()
-        self._log_first_batch(losses, time.time() - t0, trace, fname)
+        self._log_first_batch(losses, elapsed, trace, fname, times)
         return img, w_aug
 
     def _host_group(self):

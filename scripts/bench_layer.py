@@ -1,7 +1,8 @@
 """Dev tool: time one modulated 3x3 conv layer (forward, direct C-ABI call) on the GPU.
 
     python scripts/bench_layer.py --res 256 --cin 128 --cout 128 --batch 8 --prec 3 [--up] [--bwd]
-LATENTAUG_HIP_LIB=<path> selects an alternative build of the library (kernel experiments).
+Runs on the DEVELOPMENT build of the library (make -C latentaugment_amd/csrc dev): kernel-variant knobs (--ab) and LA_*
+environment switches exist there only.  --product times the product build instead (no --ab).
 """
 import argparse
 import os
@@ -28,7 +29,10 @@ def main():
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--va', type=int, default=0, help='knob value of arm A')
     ap.add_argument('--vb', type=int, default=1, help='knob value of arm B')
+    ap.add_argument('--product', action='store_true', help='time the product build (no knobs)')
     a = ap.parse_args()
+    if not a.product:
+        _lib.select_dev_build()
     lib = _lib.load()
     dev = torch.device('cuda:0')
     B, cin, cout, res = a.batch, a.cin, a.cout, a.res
@@ -115,7 +119,7 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
     flops = 2.0 * B * res * res * cin * cout * 9
-    print(f'{os.environ.get("LATENTAUG_HIP_LIB", "default")}: res {res} {cin}->{cout} B{B} prec {a.prec} up={a.up} bwd={a.bwd}: '
+    print(f'{"product" if a.product else "dev build"}: res {res} {cin}->{cout} B{B} prec {a.prec} up={a.up} bwd={a.bwd}: '
           f'{ms * 1e3:.1f} us/call, {flops / ms / 1e9:.1f} TF/s fp32-equivalent', flush=True)
 
 

@@ -38,8 +38,8 @@ def test_library_loaded_is_in_tree():
     lib = _lib.load()
     assert lib.la_abi_version() == 1
     assert os.path.dirname(_lib.LIB_PATH).endswith('latentaugment_amd')
-    # the path that was actually dlopen'ed is the in-tree build (LATENTAUG_HIP_LIB can redirect the load for kernel experiments:
-    # the parity suite must not run on such a redirect)
+    # the path that was actually dlopen'ed is the in-tree PRODUCT build (the development build, liblatentaug_hip_dev.so, is only ever
+    # loaded by scripts/ and by the child processes of one test: the parity suite itself must not run on it)
     assert _lib.LOADED_PATH == os.path.realpath(_lib.LIB_PATH), _lib.LOADED_PATH
     with open('/proc/self/maps') as f:
         mapped = {line.split()[-1] for line in f if 'liblatentaug_hip' in line}

@@ -34,6 +34,19 @@ def test_header_symbols_exported(lib):
     assert lib.la_abi_version() == 1
 
 
+def test_product_library_has_no_development_switches(lib):
+    """Kernel-variant knobs and LA_* environment switches exist in the development build (-DLA_DEV) only: the product library neither
+    exports la_dev_knob_set nor contains the names of the environment variables the development build reads."""
+    from latentaugment_amd import _lib
+    assert not hasattr(lib, 'la_dev_knob_set')
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    for name in (b'LA_DEV_KNOBS', b'LA_HALO_W3', b'LA_FLAT_W3', b'LA_FORCE_MT', b'LA_NO_XS_HANDOFF', b'LA_NO_SEAM_FUSE', b'LA_NO_RGB_FUSE',
+                 b'LA_NO_ZT_PITCH'):
+        assert name not in blob, name
+    src = open(os.path.join(ROOT, 'latentaugment_amd', '_lib.py')).read()
+    assert 'os.environ' not in src      # the loader takes no path from the environment
+
+
 def test_pure_host_entry_points(lib):
     assert lib.la_synth_num_ws(256) == 14 and lib.la_synth_num_ws(512) == 16 and lib.la_synth_num_ws(1024) == 18
     assert lib.la_synth_num_params(4) == 10 and lib.la_synth_num_params(256) == 94
