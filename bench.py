@@ -86,8 +86,6 @@ def parse():
     p.add_argument('--preset', default='B', choices=['B', 'E'],
                    help="B: BASELINE.json configs[1] (the metric's config). E: configs[4] per-GPU shape -- config-e 256^2, all four "
                         "criteria at the authors' weights (w_lpips 10, w_pix 0.1, w_latent 0.001, w_disc 0.01), Pelvis-scale banks")
-    p.add_argument('--operand-scale', default='auto', choices=['auto', 'bound', 'data'],
-                   help="f16x2: fp16 operand scale of the forward contractions: from the clamp bound, from the data maxima, or (default, as the plugin) calibrated once on the first batch")
     p.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured step')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true', help='skip the HIP-event leg (used under rocprofv3)')
@@ -118,7 +116,7 @@ def make_opt(args, local_rank, global_batch):
         truncation_psi=1.0, w_pix=args.w_pix, w_lpips=args.w_lpips, w_latent=args.w_latent, w_disc=args.w_disc, crop_size_aug=64,
         preprocess_aug='center_random_crop', soft_aug=False, alpha=1.0, verbose_log=False, rand_aug=False,
         lower_bound_clip=False, p_thres=0.0, init_w='inv', final_noise_mode='random',
-        precision=args.precision, hip_graph=not args.no_graph, operand_scale=args.operand_scale)
+        precision=args.precision, hip_graph=not args.no_graph)
 
 
 def cpu_model():
@@ -402,7 +400,7 @@ def main():
                                f'w_latent={args.w_latent:g} w_pix={args.w_pix:g} w_disc={args.w_disc:g} w_lpips={args.w_lpips:g} '
                                f'(M_w={args.M_w}, M_x={args.M_x}), criteria gradients from bank column sums reduced once per handle (the '
                                f"reference's pairwise-L2 GEMM over the banks runs only when loss scalars are requested: the API returns none), "
-                               f'contraction={args.precision}' + (f', fp16 operand scale = {aug.latent_aug.engine.operand_scale}' + (f' (first batch: activations reach {aug.latent_aug.engine.calibration:.1e} of the clamp bound)' if getattr(aug.latent_aug.engine, 'calibration', None) is not None else '') if args.precision == 'f16x2' else '') + ', '
+                               f'contraction={args.precision}' + (', fp16 operand scales from the data of every pass (lowered by the producing kernels)' if args.precision == 'f16x2' else '') + ', '
                                f'timed call = set_input + LatentAugment.forward + get_output, '
                                'launch mode = ' + LAUNCH_MODES[aug.latent_aug.graph_state],
                    'global_batch': gb, 'parallelism': f'dp{world}'},

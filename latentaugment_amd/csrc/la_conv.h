@@ -48,6 +48,11 @@ struct LaConvArgs {
     float alpha, gain, clamp;
     const float* addend;     // optional [B][M][Hout][Wout]: out2 = y + addend (residual sum), y itself still goes to `out`
     float* out2;
+    // LA_EPI_FWD, optional: the fp16 operand scale of this launch's output for the contraction that consumes it -- slot rows
+    // [B][LA_XS_FAN] (holding LA_XS_INIT before) that every producing workgroup lowers to pow2(mult[b] * its max |y|) (la_xs_lower,
+    // la_common.h; y = out2 where there is one); fwd_xs_mult [B] or null (1): e.g. max_c |style| of the consuming layer
+    float* fwd_xs_out;
+    const float* fwd_xs_mult;
     // LA_EPI_BWD:  out = acc * out_scale[b][m];  ds_part[b][m][tile] = sum_pixels acc * xin[b][m][pixel]
     const float* out_scale;
     int oscale_stride;

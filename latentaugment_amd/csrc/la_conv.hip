@@ -234,6 +234,9 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
     float part = 0.f, dd = 0.f, mx = 0.f;
     // (the sub-slot of the consumer's scale row this plane lowers, read early: the round trip hides under the slice loads)
     float* xs_row = (seam && a.seam_xs_out && lane == 0 && (PPB > 1 || threadIdx.x == 0)) ? a.seam_xs_out + (long)b * LA_XS_FAN + la_xs_sub((int)(threadIdx.x >> 6) * 5) : nullptr;
+    // (forward epilogue: the same for LaConvArgs::fwd_xs_out, one atomic per wave)
+    float ymax = 0.f;
+    if (a.epi == LA_EPI_FWD && a.fwd_xs_out && lane == 0) xs_row = a.fwd_xs_out + (long)b * LA_XS_FAN + la_xs_sub((int)(threadIdx.x >> 6) * 5);
     const float xs_seen = xs_row ? la_xs_peek(xs_row) : 0.f;
     const int imgc = seam ? (a.seam_imgc < 4 ? a.seam_imgc : 4) : 0;
     float we[4] = {0.f, 0.f, 0.f, 0.f}, dwe[4] = {0.f, 0.f, 0.f, 0.f};
@@ -280,8 +283,11 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
                     if (a.addend) ad = ld(a.addend + o2);
                     vf w;
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) w[e] = v[e] + ad[e];
+                    for (int e = 0; e < VEC; ++e) { w[e] = v[e] + ad[e]; ymax = fmaxf(ymax, fabsf(w[e])); }
                     *reinterpret_cast<vf*>(a.out2 + o2) = w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) ymax = fmaxf(ymax, fabsf(v[e]));
                 }
             } else if (a.epi == LA_EPI_BWD) {
                 vf y = 0.f;
@@ -329,6 +335,11 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
                           (al & 15) == 0 && (a_in.nphase == 0 || (a_in.ph[blockIdx.z].ws_off & 3) == 0);
         if (vec4) run(std::integral_constant<int, 4>{});
         else run(std::integral_constant<int, 1>{});
+    }
+    if (a.epi == LA_EPI_FWD && a.fwd_xs_out) {      // (uniform; PPB == 1: every wave of the plane lowers its own sub-slot)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+        if (xs_row) la_xs_lower(xs_row, xs_seen, a.fwd_xs_mult ? a.fwd_xs_mult[b] : 1.f, ymax);
     }
     if (a.epi == LA_EPI_BWD && (a.ds_part || seam)) {
         part = la_wave_sum(part);

@@ -301,6 +301,10 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
         }
         float* o2 = (fwd && a.out2) ? a.out2 + ((long)b * a.M + m0 + mw) * HWo : nullptr;
         const float* ad = (o2 && a.addend) ? a.addend + ((long)b * a.M + m0 + mw) * HWo : nullptr;
+        // operand scale of the output for its consumer (LaConvArgs::fwd_xs_out): this workgroup's max |y| lowers a sub-slot of the row
+        float* fxs_row = (fwd && a.fwd_xs_out) ? a.fwd_xs_out + (long)b * LA_XS_FAN + la_xs_sub() : nullptr;
+        const float fxs_seen = (fxs_row && tid == 0) ? la_xs_peek(fxs_row) : 0.f;      // (early: the round trip hides under the stores)
+        float ymax = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -317,7 +321,8 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                         v = fminf(fmaxf(v, -cl), cl);
                     }
                     o0[(long)mr * HWo + np[j]] = v;
-                    if (o2) o2[(long)mr * HWo + np[j]] = v + (ad ? ad[(long)mr * HWo + np[j]] : 0.f);
+                    if (o2) { const float v2 = v + (ad ? ad[(long)mr * HWo + np[j]] : 0.f); o2[(long)mr * HWo + np[j]] = v2; ymax = fmaxf(ymax, fabsf(v2)); }
+                    else ymax = fmaxf(ymax, fabsf(v));
                     if (rgbc > 0) {
 #pragma unroll
                         for (int c = 0; c < RGB_MAXC; ++c)
@@ -350,6 +355,14 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                 if (a.rgb_clamp >= 0.f) t = fminf(fmaxf(t, -a.rgb_clamp), a.rgb_clamp);
                 a.rgb_img[pos] = t + (a.rgb_skip ? a.rgb_skip[pos] : 0.f);
             }
+        }
+        if (fwd && a.fwd_xs_out) {      // (block-uniform)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+            __syncthreads();              // (the row tables / ToRGB partials of this tile are done with)
+            if (lane == 0) red[0][wid] = ymax;
+            __syncthreads();
+            if (tid == 0) la_xs_lower(fxs_row, fxs_seen, a.fwd_xs_mult ? a.fwd_xs_mult[b] : 1.f, fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])));
         }
         return;
     }
@@ -489,6 +502,9 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
         for (int j = 0; j < NJ; ++j)
             if (pix_ok[j]) nz[j] = a.noise[(long)b * a.noise_bstride + npos[j]] * a.noise_strength;
     }
+    float* fxs_row = (fwd && a.fwd_xs_out) ? a.fwd_xs_out + (long)b * LA_XS_FAN + la_xs_sub() : nullptr;
+    const float fxs_seen = (fxs_row && tid == 0) ? la_xs_peek(fxs_row) : 0.f;
+    float ymax = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -508,9 +524,19 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                 out_b[(long)m * HWout + npos[j]] = v;
                 if (fwd && a.out2) {
                     const long o2 = ((long)b * a.M + m) * HWout + npos[j];
-                    a.out2[o2] = v + (a.addend ? a.addend[o2] : 0.f);
+                    v += a.addend ? a.addend[o2] : 0.f;
+                    a.out2[o2] = v;
                 }
+                ymax = fmaxf(ymax, fabsf(v));
             }
         }
+    }
+    if (fwd && a.fwd_xs_out) {      // (block-uniform)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+        __syncthreads();
+        if (lane == 0) red[0][wid] = ymax;
+        __syncthreads();
+        if (tid == 0) la_xs_lower(fxs_row, fxs_seen, a.fwd_xs_mult ? a.fwd_xs_mult[b] : 1.f, fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])));
     }
 }

@@ -19,12 +19,15 @@ bool la_modconv3x3_fwd_fuses_rgb(int precision, int B, int cin, int cout, int re
 int la_modconv3x3_fwd_ex(const float* x, long x_bstride, const float* in_pmax, int in_nseg, const float* wf, const void* wq, int precision, const float* s,
                          int s_stride, const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                          const float* bias, int act, float alpha, float gain, float clamp, float* y, void* ws, size_t ws_bytes, int B,
-                         int cin, int cout, int res, hipStream_t stream, const float* xscale = nullptr, const LaRgbFuse* rgb = nullptr);
+                         int cin, int cout, int res, hipStream_t stream, const float* xscale = nullptr, const LaRgbFuse* rgb = nullptr,
+                         float* xs_out = nullptr, const float* xs_mult = nullptr);
+// xs_out / xs_mult (optional): the operand scale of y for the contraction that consumes it (LaConvArgs::fwd_xs_out / fwd_xs_mult)
 int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
                              const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                              const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
                              float* scratch, float* y, float* y_pmax, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
-                             hipStream_t stream, const float* xscale = nullptr, int scratch_pitch = 0, int scratch_xhalf = 0);
+                             hipStream_t stream, const float* xscale = nullptr, int scratch_pitch = 0, int scratch_xhalf = 0,
+                             float* xs_out = nullptr, const float* xs_mult = nullptr);
 // scratch_pitch / scratch_xhalf (floats; both 0 = dense (res+1)-wide rows, or both set): COLUMN-PLANAR rows of the transposed-conv
 // intermediate -- the even output columns of a row at [0, res/2 + 1), the odd ones from scratch_xhalf on (a multiple of 4,
 // scratch_pitch >= scratch_xhalf + res/2) -- so that every output phase of the transposed conv stores contiguous runs and the FIR

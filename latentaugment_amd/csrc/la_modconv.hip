@@ -41,9 +41,11 @@ bool la_modconv3x3_fwd_fuses_rgb(int precision, int B, int cin, int cout, int re
 int la_modconv3x3_fwd_ex(const float* x, long x_bstride, const float* in_pmax, int in_nseg, const float* wf, const void* wq, int precision, const float* s,
                          int s_stride, const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                          const float* bias, int act, float alpha, float gain, float clamp, float* y, void* ws, size_t ws_bytes, int B,
-                         int cin, int cout, int res, hipStream_t stream, const float* xscale, const LaRgbFuse* rgb) {
+                         int cin, int cout, int res, hipStream_t stream, const float* xscale, const LaRgbFuse* rgb, float* xs_out,
+                         const float* xs_mult) {
     LA_CHECK_ARG(x && wf && y, "modconv_fwd: null pointer");
     LaConvArgs a; base_args(a);
+    a.fwd_xs_out = xs_out; a.fwd_xs_mult = xs_mult;
     if (rgb) {
         LA_CHECK_ARG(rgb->imgc >= 1 && rgb->imgc <= 4 && rgb->w && rgb->s && rgb->rgb_pre && rgb->img && la_modconv3x3_fwd_fuses_rgb(precision, B, cin, cout, res),
                      "modconv_fwd: this launch cannot carry the fused ToRGB (la_modconv3x3_fwd_fuses_rgb)");
@@ -77,7 +79,7 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
                              const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                              const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
                              float* scratch, float* y, float* y_pmax, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
-                             hipStream_t stream, const float* xscale, int scratch_pitch, int scratch_xhalf) {
+                             hipStream_t stream, const float* xscale, int scratch_pitch, int scratch_xhalf, float* xs_out, const float* xs_mult) {
     LA_CHECK_ARG(x && wf && y && scratch && fir_host, "modconv_up2_fwd: null pointer");
     LA_CHECK_ARG(scratch_pitch == 0 || scratch_pitch >= res + 1, "modconv_up2_fwd: scratch pitch smaller than a row");
     LA_CHECK_ARG((scratch_xhalf == 0 && scratch_pitch == 0) || (scratch_xhalf >= res / 2 + 1 && scratch_pitch >= scratch_xhalf + res / 2),
@@ -132,7 +134,7 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
     // FIR with pad (1,1,1,1) and gain up^2 = 4 (conv2d_resample.py:119-126), then the layer epilogue
     return la_upfirdn2d_modconv_epilogue(scratch, y, B, cout, res + 1, res + 1, fir_host, 4, 4, 1, 1, 1, 1, 4.f, d, d_stride,
                                          noise, noise_bstride, noise_strength, bias, act, alpha, gain, clamp, stream, y_pmax,
-                                         scratch_pitch, (long)scratch_pitch * (res + 1), scratch_xhalf);
+                                         scratch_pitch, (long)scratch_pitch * (res + 1), scratch_xhalf, xs_out, xs_mult);
 }
 
 extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,

@@ -51,8 +51,10 @@ int la_pack_conv_weights(const float* w, float* wf, float* wb, float* wsq, int c
 int la_affine_forward(const LaStyleTable& t, const float* ws, long ws_bstride, long ws_lstride, int B, int wdim,
                       float* s_all, hipStream_t);
 // xs[l][b] = power-of-two fp16 operand scale of conv layer l's forward contraction from the bound  bound[l] * max_i |s[b][i]|
-int la_xscale_from_bounds(const LaDemodTable& t, const float* s_all, int s_stride, const float* bound, float* xs, int B, hipStream_t,
-                          float* xs_bwd = nullptr);      // xs_bwd [nlayers][B] (optional): reset to LA_XS_INIT for the backward pass (la_common.h)
+// start of a pass: resets the slot rows xs [nlayers][B][LA_XS_FAN] (layer 0: the scale of the constant input `cst`, cst_n floats) and
+// xs_bwd (optional) and writes xs_mult [nlayers][B] = max_i |style| of every layer (la_style.hip)
+int la_xscale_from_bounds(const LaDemodTable& t, const float* s_all, int s_stride, const float* cst, int cst_n, float* xs, float* xs_mult, int B,
+                          hipStream_t, float* xs_bwd = nullptr);
 int la_demod_forward(const LaDemodTable& t, const float* s_all, int s_stride, int B, float* d_all, hipStream_t);
 int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_stride, const float* bias,
                      const float* skip, float* rgb_pre, float* img, int B, int C, int imgc, int H, int W, float clamp,

@@ -147,33 +147,40 @@ int la_demod_forward(const LaDemodTable& t, const float* s_all, int s_stride, in
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// fp16 operand scales of the FORWARD contractions of every conv layer in one launch: the input of layer l is the clamped output
-// of layer l-1 (|x| <= conv_clamp; layer 0: the constant input, |x| <= max|const|), so  |x * s| <= bound_l * max_i |s[b][i]|
-// is known as soon as the styles are -- no pass over the activations (plane maxima / absmax kernels) is needed.  A bound
-// instead of the exact maximum only moves the absolute floor of the 2-term fp16 split (see la_upfirdn2d.hip).
+// Start of a pass (fp16 x2 mode), one launch: the slot rows of every conv layer's fp16 operand scales are reset -- forward rows
+// xs_fwd [l][b][LA_XS_FAN] and backward rows xs_bwd to LA_XS_INIT -- and what the producers need to lower the forward rows is laid out:
+// xs_mult [l][b] = max_i |s[b][i]| of layer l (the input of layer l is x * s, so |x * s| <= max|x| * max|s|: the producer of x lowers
+// row l to pow2(xs_mult * its max |x|), la_xs_lower).  Layer 0 reads the constant input, which no kernel of the pass produces: its
+// row gets pow2(max|const| * max|s|) here (max|const| reduced from the tensor itself every pass: no stale bound if a caller
+// rewrites the parameter in place).  Every scale is therefore derived from the DATA of this pass -- there is no a-priori bound and
+// no calibration (round 3 kept conv_clamp * max|s| for the forward rows and checked once, on the first batch, that it was tight enough).
 __global__ __launch_bounds__(256) void la_xscale_bound_kernel(LaDemodTable t, const float* __restrict__ s_all, int s_stride,
-                                                             const float* __restrict__ bound, float* __restrict__ xs, int B,
-                                                             unsigned* __restrict__ xs_bwd) {
-    __shared__ float red[4];
+                                                             const float* __restrict__ cst, int cst_n, float* __restrict__ xs,
+                                                             float* __restrict__ xs_mult, int B, unsigned* __restrict__ xs_bwd) {
+    __shared__ float red[4], red2[4];
     const int l = blockIdx.x, b = blockIdx.y;
     const float* sp = s_all + (long)b * s_stride + t.s_off[l];
-    float m = 0.f;
+    float m = 0.f, mc = 0.f;
     for (int i = threadIdx.x; i < t.cin[l]; i += 256) m = fmaxf(m, fabsf(sp[i]));
+    if (l == 0) for (int i = threadIdx.x; i < cst_n; i += 256) mc = fmaxf(mc, fabsf(cst[i]));
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); mc = fmaxf(mc, __shfl_xor(mc, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m; red2[threadIdx.x >> 6] = mc; }
     __syncthreads();
-    // slot rows [l][b][LA_XS_FAN]: the bound-based forward scale in sub-slot 0 (the rest at LA_XS_INIT, i.e. neutral for the row minimum);
-    // the backward pass's running operand scales start over (la_xs_lower)
+    const float smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float cmax = fmaxf(fmaxf(red2[0], red2[1]), fmaxf(red2[2], red2[3]));
+    if (threadIdx.x == 0) xs_mult[(long)l * B + b] = smax;
     if (threadIdx.x < LA_XS_SUBS) {
         const long o = ((long)l * B + b) * LA_XS_FAN + threadIdx.x * LA_XS_LINE;
-        xs[o] = threadIdx.x == 0 ? la_pow2_scale(bound[l] * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))) : __uint_as_float(LA_XS_INIT);
+        xs[o] = (l == 0 && threadIdx.x == 0) ? la_pow2_scale(cmax * smax) : __uint_as_float(LA_XS_INIT);
         if (xs_bwd) xs_bwd[o] = LA_XS_INIT;
     }
 }
 
-int la_xscale_from_bounds(const LaDemodTable& t, const float* s_all, int s_stride, const float* bound, float* xs, int B, hipStream_t stream, float* xs_bwd) {
-    hipLaunchKernelGGL(la_xscale_bound_kernel, dim3(t.nlayers, B), dim3(256), 0, stream, t, s_all, s_stride, bound, xs, B, reinterpret_cast<unsigned*>(xs_bwd));
+int la_xscale_from_bounds(const LaDemodTable& t, const float* s_all, int s_stride, const float* cst, int cst_n, float* xs, float* xs_mult, int B,
+                          hipStream_t stream, float* xs_bwd) {
+    hipLaunchKernelGGL(la_xscale_bound_kernel, dim3(t.nlayers, B), dim3(256), 0, stream, t, s_all, s_stride, cst, cst_n, xs, xs_mult, B,
+                       reinterpret_cast<unsigned*>(xs_bwd));
     LA_CHECK_LAUNCH();
     return LA_OK;
 }

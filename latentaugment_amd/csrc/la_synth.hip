@@ -59,10 +59,9 @@ struct la_synth {
                              // the conv1 backward contraction above it
     float* xs_fwd;           // [nconv][B][LA_XS_FAN] slot rows: fp16 operand scales of the forward contractions (from the clamp bound, one launch per pass)
     float* xs_bwd;           // [nconv][B][LA_XS_FAN] slot rows: running fp16 operand scales of the backward contractions' inputs, lowered by the producing kernels
-    float* xs_bound;         // [nconv]: bound on |input| of conv layer k: max|const| for the first, conv_clamp for the rest
+    float* xs_mult;          // [nconv][B]: max_i |style| of every conv layer = what the producer of its input multiplies its max |x| with
     int lastB;
     int precision;
-    int data_scale;          // 1: forward fp16 operand scales from the data maxima (absmax / plane-maxima passes) instead of the clamp bound
     float* final_img;   // where the last forward put the full-resolution image
 };
 
@@ -161,7 +160,7 @@ static int layout(la_synth* h, void* workspace, size_t cap, size_t* need) {
     }
     h->xs_fwd = c.take((size_t)h->nconv * mb * LA_XS_FAN);
     h->xs_bwd = c.take((size_t)h->nconv * mb * LA_XS_FAN);
-    h->xs_bound = c.take((size_t)h->nconv + 16);
+    h->xs_mult = c.take((size_t)h->nconv * mb + 16);
     *need = c.off;
     return LA_OK;
 }
@@ -277,15 +276,6 @@ extern "C" int la_synth_create(int img_resolution, int img_channels, int w_dim, 
         T.affine_w = params[p++]; T.affine_b = params[p++]; T.weight = params[p++]; T.bias = params[p++];
         h->st.aw[T.style_idx] = T.affine_w; h->st.ab[T.style_idx] = T.affine_b;
     }
-    {   // input bounds of the forward contractions: |const| <= its maximum (reduced once, here), every later layer's input is a
-        // clamped layer output (|y| <= conv_clamp).  Without a clamp the data-dependent scale path is used instead.
-        float hb[2 * MAX_BLOCKS];
-        for (int k = 0; k < h->nconv; ++k) hb[k] = h->clamp > 0.f ? h->clamp : 0.f;
-        LA_HIP(hipMemcpyAsync(h->xs_bound, hb, sizeof(float) * h->nconv, hipMemcpyHostToDevice, stream));
-        LA_HIP(hipMemsetAsync(h->xs_bound, 0, sizeof(float), stream));
-        if ((rc = la_absmax_bits(h->cst, (long)h->channels[0] * 16, reinterpret_cast<unsigned*>(h->xs_bound), stream))) { free(h); return rc; }
-        LA_HIP(hipStreamSynchronize(stream));      // (hb is a stack buffer)
-    }
     h->lastB = 0;
     *out = h;
     return LA_OK;
@@ -300,12 +290,11 @@ extern "C" int la_synth_set_precision(la_synth* h, int precision) {
     return LA_OK;
 }
 extern "C" int la_synth_get_precision(const la_synth* h) { return h ? h->precision : -1; }
-// fp16 operand scale of the FORWARD contractions (f16x2 mode): 0 (default) from the a-priori bound conv_clamp * max|style| -- no pass
-// over the data; float32-class while a tensor reaches at least ~2^-16 of that bound somewhere -- or 1 from the data maxima (two
-// more short passes per layer, no such limit; what a generator without conv_clamp always gets).
+// Kept for ABI compatibility (rounds 1-3 selected between an a-priori bound and data maxima for the fp16 operand scale of the forward
+// contractions): since round 4 every forward scale is derived from the data of the pass by the kernel that produces the tensor
+// (la_xscale_bound_kernel, la_style.hip) -- there is nothing to select, the launch sequence does not depend on this call.
 extern "C" int la_synth_set_operand_scale(la_synth* h, int from_data) {
-    LA_CHECK_ARG(h && (from_data == 0 || from_data == 1), "synth_set_operand_scale: 0 (bound) or 1 (data)");
-    h->data_scale = from_data;
+    LA_CHECK_ARG(h && (from_data == 0 || from_data == 1), "synth_set_operand_scale: 0 or 1");
     return LA_OK;
 }
 
@@ -327,17 +316,16 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
     if ((rc = la_demod_forward(h->dt, h->s_all, h->S, B, h->d_all, stream))) return rc;
     h->lastB = B;
     const bool f16 = h->precision == LA_PREC_F16X2;
-    const bool bound_scale = f16 && h->clamp > 0.f && !h->data_scale;
-    // scratch layout of the up layers: dense interleaved rows (plane maxima wanted: scalar FIR; dev knob LA_NO_ZT_PITCH) or column-planar
-    static const bool zt_knob_dense = la_dev_env("LA_NO_ZT_PITCH") != nullptr;
-    const bool zt_dense = (f16 && !bound_scale) || zt_knob_dense;
-    // (also with data-based forward scales: the launch resets xs_bwd, the running scale slots of the backward pass)
-    if (f16 && h->clamp > 0.f && (rc = la_xscale_from_bounds(h->dt, h->s_all, h->S, h->xs_bound, h->xs_fwd, B, stream, h->xs_bwd))) return rc;
+    // scratch layout of the up layers: column-planar rows (dev knob LA_NO_ZT_PITCH: dense interleaved rows + the scalar FIR kernel)
+    static const bool zt_dense = la_dev_env("LA_NO_ZT_PITCH") != nullptr;
+    // fp16 operand scales: the slot rows of every layer start the pass at LA_XS_INIT; the kernel that PRODUCES a layer's input lowers
+    // that layer's row (forward: xs_fwd, la_xs_lower with max|style| of the consuming layer; backward: xs_bwd)
+    if (f16 && (rc = la_xscale_from_bounds(h->dt, h->s_all, h->S, h->cst, h->channels[0] * 16, h->xs_fwd, h->xs_mult, B, stream, h->xs_bwd))) return rc;
+    auto fwd_row = [&](int conv_index) { return (f16 && conv_index < h->nconv) ? h->xs_fwd + (long)conv_index * B * LA_XS_FAN : nullptr; };
+    auto fwd_mult = [&](int conv_index) { return (f16 && conv_index < h->nconv) ? h->xs_mult + (long)conv_index * B : nullptr; };
     int ci = 0;
     const float* x = h->cst;
     long x_bstride = 0;
-    const float* x_pmax = nullptr;      // plane maxima of x when its producer (the FIR epilogue of an up-sampling layer) left them
-    int x_nseg = 0;
     for (int k = 0; k < h->nblocks; ++k) {
         const int res = 4 << k;
         const int nl = (k == 0) ? 1 : 2;
@@ -365,19 +353,16 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
             rf.imgc = h->imgc; rf.w = T.weight; rf.s = h->s_all + T.s_off; rf.s_stride = h->S; rf.bias = T.bias; rf.skip = skip;
             rf.rgb_pre = T.rgb_pre; rf.img = rgb_dst; rf.clamp = h->clamp;
             if (!L.up) {
-                rc = la_modconv3x3_fwd_ex(x, x_bstride, x_pmax, x_nseg, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
+                rc = la_modconv3x3_fwd_ex(x, x_bstride, nullptr, 0, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                           L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f, sq2,
-                                          h->clamp, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream, bound_scale ? h->xs_fwd + (long)ci * B * LA_XS_FAN : nullptr,
-                                          (fuse_rgb && q == nl - 1) ? &rf : nullptr);
-                x_pmax = nullptr;
+                                          h->clamp, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream, fwd_row(ci),
+                                          (fuse_rgb && q == nl - 1) ? &rf : nullptr, fwd_row(ci + 1), fwd_mult(ci + 1));
             } else {
                 rc = la_modconv3x3_up2_fwd_ex(x, x_bstride, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                               L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f,
-                                              sq2, h->clamp, h->fir, h->zT, L.y, (f16 && !bound_scale) ? h->pmax : nullptr, h->cws, h->cws_bytes, B, L.cin,
-                                              L.cout, res, stream, bound_scale ? h->xs_fwd + (long)ci * B * LA_XS_FAN : nullptr,
-                                              zt_dense ? 0 : 2 * zt_xhalf(res), zt_dense ? 0 : zt_xhalf(res));      // (plane maxima come from the scalar FIR kernel only)
-                x_pmax = (f16 && !bound_scale) ? h->pmax : nullptr;
-                x_nseg = la_fir4x4_segments(res, res);
+                                              sq2, h->clamp, h->fir, h->zT, L.y, nullptr, h->cws, h->cws_bytes, B, L.cin,
+                                              L.cout, res, stream, fwd_row(ci),
+                                              zt_dense ? 0 : 2 * zt_xhalf(res), zt_dense ? 0 : zt_xhalf(res), fwd_row(ci + 1), fwd_mult(ci + 1));
             }
             if (rc) return rc;
             x = L.y; x_bstride = (long)L.cout * res * res;
@@ -420,13 +405,12 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
     static const bool no_fuse = la_dev_env("LA_NO_SEAM_FUSE") != nullptr;      // dev knobs: A/B of the fused seams on one box
     static const bool no_fuse2 = la_dev_env("LA_NO_SEAM2_FUSE") != nullptr;
     const bool f16 = h->precision == LA_PREC_F32 ? false : h->precision == LA_PREC_F16X2;
-    // fp16 operand scales of the backward contractions: with a clamp (the forward pass then ran la_xscale_from_bounds, which also reset
-    // xs_bwd) the direct contraction kernels, whose epilogues produce the next contraction's input, lower the consumer's slot
-    // themselves (la_xs_lower): no plane maxima, no reduction launch between producer and consumer.  The split-K finish and the
-    // seam kernel still reduce plane maxima with one small launch (inside la_conv_launch / la_seam_backward), into the same slot.
-    // Without a clamp: plane maxima + la_xscale_pmax at the consumer as before.
-    static const bool no_xs = la_dev_env("LA_NO_XS_HANDOFF") != nullptr;      // dev knob
-    const bool xs_hand = f16 && h->clamp > 0.f && !no_xs;
+    // fp16 operand scales of the backward contractions: the kernels whose epilogues produce a contraction's input (direct contraction
+    // kernels, split-K finish pass, seam kernel) lower the consumer's slot row themselves (la_xs_lower; la_synth_forward reset the
+    // rows): no plane maxima, no reduction launch between producer and consumer.  Dev knob LA_NO_XS_HANDOFF: plane maxima +
+    // la_xscale_pmax at the consumer.
+    static const bool no_xs = la_dev_env("LA_NO_XS_HANDOFF") != nullptr;
+    const bool xs_hand = f16 && !no_xs;
     const float up_mult = la_modconv_up2_bwd_xs_mult(h->fir);
     auto xs_slot = [&](int conv_index) { return xs_hand ? h->xs_bwd + (long)conv_index * B * LA_XS_FAN : nullptr; };
     bool seam2_done = false;      // this block's conv1 seam was already applied by the epilogue of the up layer's backward above it

@@ -16,7 +16,10 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
                                   int fh, int fw, int padx0, int padx1, int pady0, int pady1, float fir_gain,
                                   const float* demod, int demod_stride, const float* noise, long noise_bstride,
                                   float noise_strength, const float* bias, int act, float alpha, float gain,
-                                  float clamp, hipStream_t stream, float* pmax = nullptr, int in_pitch = 0, long in_plane = 0, int in_xhalf = 0);
+                                  float clamp, hipStream_t stream, float* pmax = nullptr, int in_pitch = 0, long in_plane = 0, int in_xhalf = 0,
+                                  float* xs_out = nullptr, const float* xs_mult = nullptr);
+// xs_out / xs_mult (optional): slot rows [B][LA_XS_FAN] of the fp16 operand scale of `out` for the contraction that consumes it
+// (la_common.h): lowered by the producing workgroups to pow2(xs_mult[b] * max |out|)
 // in_pitch / in_plane (floats, 0 = dense): padded row pitch / plane stride of `in` (multiples of 4 select the vector kernel)
 // in_xhalf (> 0, needs in_pitch): column-planar rows -- even columns of the image at [0, ceil(Win/2)), odd columns from in_xhalf on
 

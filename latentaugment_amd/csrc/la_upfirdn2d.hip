@@ -22,6 +22,8 @@ struct FirArgs {
     float* pmax;                 // optional [P][la_fir4x4_segments(Hout, Wout)]: partial max |out| per plane, 4x4 stride-1 kernel only
     int in_pitch; long in_plane; // 0 = dense; row pitch / plane stride of `in` in floats (vector kernel: multiples of 4)
     int in_xhalf;                // > 0: COLUMN-PLANAR rows -- the even columns of a row at [0, ceil(Win/2)), the odd ones from in_xhalf on
+    float* xs_out;               // optional (4x4 stride-1 kernels): slot rows [B][LA_XS_FAN] of the fp16 operand scale of `out` for the
+    const float* xs_mult;        //   contraction that consumes it: every wave lowers its sample's row to pow2(xs_mult[b] * its max |out|)
 };
 
 __global__ __launch_bounds__(256) void la_upfirdn2d_kernel(FirArgs a) {
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void la_fir4x4_s1_kernel(FirArgs a) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * FIR_ROWS;
     const bool live = x < a.Wout && y0 < a.Hout;
-    if (!live && !a.pmax) return;                       // (with plane maxima, dead lanes wait for the wave reduction)
+    if (!live && !a.pmax && !a.xs_out) return;          // (with plane maxima / a scale slot, dead lanes wait for the reduction)
     const long HWin = (long)a.Hin * a.Win, HWout = (long)a.Hout * a.Wout;
     float f[16];
 #pragma unroll
@@ -130,15 +132,22 @@ __global__ __launch_bounds__(256) void la_fir4x4_s1_kernel(FirArgs a) {
     for (int p = blockIdx.z; p < a.P; p += gridDim.z) {
         float mx = 0.f;
         if (live) mx = la_fir4x4_plane<EPI>(a, f, xok, p, x, y0, ix0, iy0, HWin, HWout);
-        if (a.pmax) {      // one partial maximum per (plane, workgroup): plain store, reduced by the consumer (no atomics)
+        if (a.pmax || a.xs_out) {      // one partial maximum per (plane, workgroup): plain store, reduced by the consumer (no atomics) ...
             __shared__ float wmax[4];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
             __syncthreads();
             if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
             __syncthreads();
-            if (threadIdx.x == 0)
-                a.pmax[(long)p * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (threadIdx.x == 0) {
+                const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+                if (a.pmax) a.pmax[(long)p * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] = m;
+                if (a.xs_out) {      // ... or lowers a sub-slot of the sample's scale row for the consuming contraction (FirArgs::xs_out)
+                    const int bs = p / a.C;
+                    float* row = a.xs_out + (long)bs * LA_XS_FAN + la_xs_sub(p);
+                    la_xs_lower(row, la_xs_peek(row), a.xs_mult ? a.xs_mult[bs] : 1.f, m);
+                }
+            }
         }
     }
 }
@@ -154,7 +163,7 @@ static int fir_fill(FirArgs& a, const float* in, float* out, int B, int C, int H
     LA_CHECK_ARG(upW >= fw && upH >= fh, "upfirdn2d: upsampled image smaller than the filter");
     *Wout = (upW - fw + dnx) / dnx;   // upfirdn2d.cpp:35-36
     *Hout = (upH - fh + dny) / dny;
-    a.in = in; a.out = out; a.P = B * C; a.C = C; a.pmax = nullptr;
+    a.in = in; a.out = out; a.P = B * C; a.C = C; a.pmax = nullptr; a.xs_out = nullptr; a.xs_mult = nullptr;
     a.in_pitch = Win; a.in_plane = (long)Hin * Win; a.in_xhalf = 0;
     a.Hin = Hin; a.Win = Win; a.Hout = *Hout; a.Wout = *Wout;
     a.upx = upx; a.upy = upy; a.dnx = dnx; a.dny = dny; a.padx0 = padx0; a.pady0 = pady0;
@@ -181,83 +190,110 @@ static int fir_fill(FirArgs& a, const float* in, float* out, int B, int C, int H
 // registers) 147 us; the same kernel on column-interleaved rows with three 16-byte loads per row 127 us.
 template <int EPI, int ROWS>
 __global__ __launch_bounds__(256) void la_fir4x4_s1p_kernel(FirArgs a, float4 fx, float4 fy) {
+    __shared__ unsigned smx[64];                   // xs_out: max |out| per sample of this workgroup (bit patterns: non-negative floats order like unsigned ints)
     const int w4 = a.Wout >> 2;
     const int strips = (a.Hout + ROWS - 1) / ROWS;
     const int per_plane = w4 * strips;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int p = (int)(gid / per_plane);
-    if (p >= a.P) return;
-    const int within = (int)(gid - (long)p * per_plane);
-    const int strip = within / w4, xg = within - strip * w4;
-    const int x0 = xg * 4, q2 = xg * 2, y0 = strip * ROWS;
-    const long HWout = (long)a.Hout * a.Wout;
-    const int ne = (a.Win + 1) >> 1, no = a.Win >> 1;
-    const bool okm = q2 > 0, oke = q2 + 2 < ne, oko = q2 + 2 < no;
-    struct Row { float2 e, o; float om1, e2, o2; };
-    const float* ip = a.in + (long)p * a.in_plane + q2;
-    auto load_row = [&](int iy) {
-        Row r;
-        r.e = r.o = make_float2(0.f, 0.f);
-        r.om1 = r.e2 = r.o2 = 0.f;
-        if (iy >= 0 && iy < a.Hin) {
-            const float* rp = ip + (long)iy * a.in_pitch;
-            r.e = *reinterpret_cast<const float2*>(rp);
-            r.o = *reinterpret_cast<const float2*>(rp + a.in_xhalf);
-            if (okm) r.om1 = rp[a.in_xhalf - 1];
-            if (oke) r.e2 = rp[2];
-            if (oko) r.o2 = rp[a.in_xhalf + 2];
-        }
-        return r;
-    };
-    auto hpass = [&](const Row& r) {
-        // image columns x0 - 1 .. x0 + 5
-        const float c[7] = {r.om1, r.e.x, r.o.x, r.e.y, r.o.y, r.e2, r.o2};
-        float4 h;
-        h.x = fx.x * c[0] + fx.y * c[1] + fx.z * c[2] + fx.w * c[3];
-        h.y = fx.x * c[1] + fx.y * c[2] + fx.z * c[3] + fx.w * c[4];
-        h.z = fx.x * c[2] + fx.y * c[3] + fx.z * c[4] + fx.w * c[5];
-        h.w = fx.x * c[3] + fx.y * c[4] + fx.z * c[5] + fx.w * c[6];
-        return h;
-    };
-    float dm = 1.f, bv = 0.f;
-    const int b = p / a.C;
-    if (EPI == 1) {
-        const int c = p - b * a.C;
-        if (a.demod) dm = a.demod[(long)b * a.demod_stride + c];
-        if (a.bias) bv = a.bias[c];
+    const bool live = p < a.P;
+    if (!live && !a.xs_out) return;
+    const int b = (live ? p : a.P - 1) / a.C;
+    float omax = 0.f;
+    if (a.xs_out) {
+        if (threadIdx.x < 64) smx[threadIdx.x] = 0u;
+        __syncthreads();
     }
-    const float* nzp = (EPI == 1 && a.noise) ? a.noise + (long)b * a.noise_bstride : nullptr;
-    const Row r0 = load_row(y0 - 1), r1 = load_row(y0), r2 = load_row(y0 + 1);
-    Row n0 = load_row(y0 + 2), n1 = load_row(y0 + 3);
-    float4 h0 = hpass(r0), h1 = hpass(r1), h2 = hpass(r2);
-    const int y1 = y0 + ROWS < a.Hout ? y0 + ROWS : a.Hout;
-#pragma unroll 4
-    for (int y = y0; y < y1; ++y) {
-        const float4 h3 = hpass(n0);
-        n0 = n1;
-        n1 = load_row(y + 4);
-        float4 o;
-        o.x = fy.x * h0.x + fy.y * h1.x + fy.z * h2.x + fy.w * h3.x;
-        o.y = fy.x * h0.y + fy.y * h1.y + fy.z * h2.y + fy.w * h3.y;
-        o.z = fy.x * h0.z + fy.y * h1.z + fy.z * h2.z + fy.w * h3.z;
-        o.w = fy.x * h0.w + fy.y * h1.w + fy.z * h2.w + fy.w * h3.w;
-        h0 = h1; h1 = h2; h2 = h3;
-        const long pos = (long)y * a.Wout + x0;
-        if (EPI == 1) {
-            float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (nzp) {
-                nz = *reinterpret_cast<const float4*>(nzp + pos);
-                nz.x *= a.noise_strength; nz.y *= a.noise_strength; nz.z *= a.noise_strength; nz.w *= a.noise_strength;
+    if (live) {
+        const int within = (int)(gid - (long)p * per_plane);
+        const int strip = within / w4, xg = within - strip * w4;
+        const int x0 = xg * 4, q2 = xg * 2, y0 = strip * ROWS;
+        const long HWout = (long)a.Hout * a.Wout;
+        const int ne = (a.Win + 1) >> 1, no = a.Win >> 1;
+        const bool okm = q2 > 0, oke = q2 + 2 < ne, oko = q2 + 2 < no;
+        struct Row { float2 e, o; float om1, e2, o2; };
+        const float* ip = a.in + (long)p * a.in_plane + q2;
+        auto load_row = [&](int iy) {
+            Row r;
+            r.e = r.o = make_float2(0.f, 0.f);
+            r.om1 = r.e2 = r.o2 = 0.f;
+            if (iy >= 0 && iy < a.Hin) {
+                const float* rp = ip + (long)iy * a.in_pitch;
+                r.e = *reinterpret_cast<const float2*>(rp);
+                r.o = *reinterpret_cast<const float2*>(rp + a.in_xhalf);
+                if (okm) r.om1 = rp[a.in_xhalf - 1];
+                if (oke) r.e2 = rp[2];
+                if (oko) r.o2 = rp[a.in_xhalf + 2];
             }
-            o.x = la_act_fwd(o.x * dm + bv + nz.x, a.act, a.alpha, a.gain, a.clamp);
-            o.y = la_act_fwd(o.y * dm + bv + nz.y, a.act, a.alpha, a.gain, a.clamp);
-            o.z = la_act_fwd(o.z * dm + bv + nz.z, a.act, a.alpha, a.gain, a.clamp);
-            o.w = la_act_fwd(o.w * dm + bv + nz.w, a.act, a.alpha, a.gain, a.clamp);
-        } else if (a.addend) {
-            const float4 ad = *reinterpret_cast<const float4*>(a.addend + (long)p * HWout + pos);
-            o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+            return r;
+        };
+        auto hpass = [&](const Row& r) {
+            // image columns x0 - 1 .. x0 + 5
+            const float c[7] = {r.om1, r.e.x, r.o.x, r.e.y, r.o.y, r.e2, r.o2};
+            float4 h;
+            h.x = fx.x * c[0] + fx.y * c[1] + fx.z * c[2] + fx.w * c[3];
+            h.y = fx.x * c[1] + fx.y * c[2] + fx.z * c[3] + fx.w * c[4];
+            h.z = fx.x * c[2] + fx.y * c[3] + fx.z * c[4] + fx.w * c[5];
+            h.w = fx.x * c[3] + fx.y * c[4] + fx.z * c[5] + fx.w * c[6];
+            return h;
+        };
+        float dm = 1.f, bv = 0.f;
+        if (EPI == 1) {
+            const int c = p - b * a.C;
+            if (a.demod) dm = a.demod[(long)b * a.demod_stride + c];
+            if (a.bias) bv = a.bias[c];
         }
-        *reinterpret_cast<float4*>(a.out + (long)p * HWout + pos) = o;
+        const float* nzp = (EPI == 1 && a.noise) ? a.noise + (long)b * a.noise_bstride : nullptr;
+        const Row r0 = load_row(y0 - 1), r1 = load_row(y0), r2 = load_row(y0 + 1);
+        Row n0 = load_row(y0 + 2), n1 = load_row(y0 + 3);
+        float4 h0 = hpass(r0), h1 = hpass(r1), h2 = hpass(r2);
+        const int y1 = y0 + ROWS < a.Hout ? y0 + ROWS : a.Hout;
+#pragma unroll 4
+        for (int y = y0; y < y1; ++y) {
+            const float4 h3 = hpass(n0);
+            n0 = n1;
+            n1 = load_row(y + 4);
+            float4 o;
+            o.x = fy.x * h0.x + fy.y * h1.x + fy.z * h2.x + fy.w * h3.x;
+            o.y = fy.x * h0.y + fy.y * h1.y + fy.z * h2.y + fy.w * h3.y;
+            o.z = fy.x * h0.z + fy.y * h1.z + fy.z * h2.z + fy.w * h3.z;
+            o.w = fy.x * h0.w + fy.y * h1.w + fy.z * h2.w + fy.w * h3.w;
+            h0 = h1; h1 = h2; h2 = h3;
+            const long pos = (long)y * a.Wout + x0;
+            if (EPI == 1) {
+                float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (nzp) {
+                    nz = *reinterpret_cast<const float4*>(nzp + pos);
+                    nz.x *= a.noise_strength; nz.y *= a.noise_strength; nz.z *= a.noise_strength; nz.w *= a.noise_strength;
+                }
+                o.x = la_act_fwd(o.x * dm + bv + nz.x, a.act, a.alpha, a.gain, a.clamp);
+                o.y = la_act_fwd(o.y * dm + bv + nz.y, a.act, a.alpha, a.gain, a.clamp);
+                o.z = la_act_fwd(o.z * dm + bv + nz.z, a.act, a.alpha, a.gain, a.clamp);
+                o.w = la_act_fwd(o.w * dm + bv + nz.w, a.act, a.alpha, a.gain, a.clamp);
+            } else if (a.addend) {
+                const float4 ad = *reinterpret_cast<const float4*>(a.addend + (long)p * HWout + pos);
+                o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+            }
+            *reinterpret_cast<float4*>(a.out + (long)p * HWout + pos) = o;
+            omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+        }
+    }
+    if (a.xs_out) {
+        // operand scale of `out` for its consumer (FirArgs::xs_out): per-sample maxima of the workgroup through LDS (the workgroup's 256
+        // work items are consecutive planes, i.e. a handful of consecutive samples), then one thread per sample lowers a sub-slot of
+        // that sample's row
+        const int b0 = (int)(((long)blockIdx.x * 256) / per_plane) / a.C;      // first sample of the workgroup
+        const int bi = b - b0;
+        if (live && omax > 0.f) {
+            if (bi < 64) atomicMax(&smx[bi], __float_as_uint(omax));
+            else { float* row = a.xs_out + (long)b * LA_XS_FAN + la_xs_sub(threadIdx.x); la_xs_lower(row, la_xs_peek(row), a.xs_mult ? a.xs_mult[b] : 1.f, omax); }
+        }
+        __syncthreads();
+        const int bt = b0 + (int)threadIdx.x;
+        if (threadIdx.x < 64 && smx[threadIdx.x] != 0u && bt * a.C < a.P) {
+            float* row = a.xs_out + (long)bt * LA_XS_FAN + la_xs_sub();
+            la_xs_lower(row, la_xs_peek(row), a.xs_mult ? a.xs_mult[bt] : 1.f, __uint_as_float(smx[threadIdx.x]));
+        }
     }
 }
 
@@ -450,7 +486,8 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
                                   int fh, int fw, int padx0, int padx1, int pady0, int pady1, float fir_gain,
                                   const float* demod, int demod_stride, const float* noise, long noise_bstride,
                                   float noise_strength, const float* bias, int act, float alpha, float gain,
-                                  float clamp, hipStream_t stream, float* pmax, int in_pitch, long in_plane, int in_xhalf) {
+                                  float clamp, hipStream_t stream, float* pmax, int in_pitch, long in_plane, int in_xhalf, float* xs_out,
+                                  const float* xs_mult) {
     FirArgs a; int ho, wo;
     int rc = fir_fill(a, in, out, B, C, Hin, Win, f_host, fh, fw, 1, 1, 1, 1, padx0, padx1, pady0, pady1, 0, fir_gain,
                       &ho, &wo);
@@ -460,6 +497,8 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
     if (fw == 4 && fh == 4) a.pmax = pmax;
     else LA_CHECK_ARG(!pmax, "upfirdn2d: plane maxima are produced by the 4x4 stride-1 kernel only");
     if (in_pitch > 0) { a.in_pitch = in_pitch; a.in_plane = in_plane; a.in_xhalf = in_xhalf; }
+    LA_CHECK_ARG(!xs_out || (fw == 4 && fh == 4), "upfirdn2d: the operand-scale hand-over exists for the 4x4 stride-1 kernels only");
+    a.xs_out = xs_out; a.xs_mult = xs_mult;
     return fir_launch(a, stream);
 }
 

@@ -236,12 +236,8 @@ class LatentAug:
             pass
         max_local = int(getattr(opt, 'max_local_batch', 0) or max_local)
         self.engine = SynthesisEngine.from_generator(generator, self.device, max_local, precision=self.precision)
-        # fp16 operand scale of the forward contractions (synthesis.py): 'bound' = from conv_clamp * max|style|, no pass over the data;
-        # 'data' = from the data maxima; 'auto' (default) = calibrated once on the first batch (SynthesisEngine.calibrate_operand_scale):
-        # 'bound' unless the generator's activations sit too far below their clamp bound for it
-        self._scale_mode = getattr(opt, 'operand_scale', 'auto')
-        if self._scale_mode in ('bound', 'data'):
-            self.engine.set_operand_scale(self._scale_mode)
+        # (opt.operand_scale of rounds 2-3 -- 'auto' | 'bound' | 'data' -- is accepted and ignored: every fp16 operand scale is derived
+        #  from the data of each pass by the producing kernels now, batch by batch; there is no calibration to freeze)
         assert self.engine.img_resolution == self.res, 'opt.img_resolution does not match the generator'
         assert self.engine.img_channels == len(self.modalities), 'one image channel per modality expected'
         self.num_ws, self.w_dim = self.engine.num_ws, self.engine.w_dim
@@ -420,12 +416,6 @@ class LatentAug:
         w = w.to(device=self.device, dtype=torch.float32).contiguous()
         b = w.shape[0]
         assert w.ndim == 3 and w.shape[1:] == (1, self.w_dim)
-        if self._scale_mode == 'auto':      # once, on the first batch, before the step is captured
-            mode = self.engine.calibrate_operand_scale(w)
-            if mode == 'data':
-                print(f'[latentaugment_amd] forward fp16 operand scales taken from the data maxima: on the first batch the activations reach only '
-                      f'{self.engine.calibration:.1e} of the clamp bound (small activations; the a-priori scale needs 4.9e-04)')
-            self._scale_mode = mode
         img = torch.empty([b, self.engine.img_channels, self.res, self.res], device=self.device, dtype=torch.float32)
         w_aug = torch.empty([b, self.num_ws, self.w_dim], device=self.device, dtype=torch.float32)
         losses = torch.zeros([max(self.num_epochs, 1), 4], device=self.device) if want_losses else None

@@ -95,17 +95,16 @@ class SynthesisEngine:
         self._lib = lib
         self.set_precision(precision)
 
-    def set_operand_scale(self, mode):
-        """f16x2 mode: 'bound' (default) takes the fp16 operand scale of the forward contractions from conv_clamp * max|style| -- no
-        pass over the data, float32-class while a layer's activations reach ~2^-16 of that bound (O(1e-2)) somewhere; 'data' takes it
-        from the data maxima (slower, no such limit)."""
-        _lib.check(self._lib.la_synth_set_operand_scale(self._h, {'bound': 0, 'data': 1}[mode]), 'la_synth_set_operand_scale')
-        self.operand_scale = mode
+    # fp16 operand scales (f16x2 mode): since round 4 every forward contraction's scale is derived from the DATA of the pass by the kernel
+    # that produces its input (la_style.hip: la_xscale_bound_kernel; la_common.h: slot rows) -- no a-priori bound, no calibration, nothing
+    # to select.  `operand_scale` is kept as a read-only description for log lines.
+    operand_scale = 'data (producer-lowered slot rows)'
 
     def operand_headroom(self, ws):
-        """Smallest ratio, over the 3x3 layers after the first and the samples of `ws`, between the data maximum of a forward fp16
-        operand, max|x*s|, and the a-priori bound the 'bound' scale is derived from, conv_clamp * max|s| (la_synth.hip: xs_bound;
-        the first layer's bound is max|const|, exact).  One forward pass of `ws`; read from the stored layer outputs and styles."""
+        """Diagnostic: smallest ratio, over the 3x3 layers after the first and the samples of `ws`, between the data maximum of a
+        forward fp16 operand, max|x*s|, and conv_clamp * max|s| -- how far a generator's activations sit below their clamp bound (rounds
+        2-3 derived the forward scales from that bound and needed this ratio >= 2^-11; the product no longer depends on it).  One
+        forward pass of `ws`; read from the stored layer outputs and styles."""
         ws = ws.to(self.device, torch.float32).contiguous()
         self.forward(ws, noise_mode='const')
         b = ws.shape[0]
@@ -119,22 +118,6 @@ class SynthesisEngine:
             ratio = min(ratio, float(r.min()))
             off += cins[k]
         return ratio
-
-    def calibrate_operand_scale(self, ws, min_ratio=2.0 ** -11):
-        """Choose between the two fp16 operand scales of the forward contractions from the data itself, once, on the first real batch.
-        The split-fp16 pair resolves an operand to 2^-39 / r of its maximum, r = (data maximum) / (bound the scale came from): at
-        r >= 2^-15 that is float32 rounding.  The latent GRADIENT is the sensitive quantity (measured: 7e-4 of its maximum at
-        r ~ 2^-19, proportional to 1/r, against ~3e-6 of float32 noise; tests/test_hip_synthesis.py and DESIGN §6), so the
-        a-priori bound is kept only where every layer has r >= 2^-11 -- activations reaching conv_clamp/2048 = 0.125 at the
-        reference's clamp of 256; a trained or default-initialised generator sits at 2^-8 .. 2^-5 -- and the engine stays on 'data'
-        (plane maxima, +6 % time) otherwise.  (Rounds of comparing the two modes' gradients directly were tried first and do not
-        separate: float32 summation noise of the 65536-pixel reduction alone is 4e-5 of the gradient maximum at 256^2.)"""
-        if self.precision != 'f16x2' or self.conv_clamp <= 0:
-            return getattr(self, 'operand_scale', 'bound')
-        ratio = self.operand_headroom(ws)
-        self.calibration = ratio
-        self.set_operand_scale('bound' if ratio >= min_ratio else 'data')       # (NaN anywhere: 'data')
-        return self.operand_scale
 
     def set_precision(self, precision):
         """'f32' exact fp32 MFMA | 'f16x2' scaled split-fp16, 3 MFMAs (fp32-class error) | 'bf16x3' split-bf16, 6 MFMAs
