@@ -34,7 +34,11 @@ struct la_feat {
     int nops, in_ch, in_res, maxN, F, precision;
     FOp op[FEAT_MAX_OPS];
     float *gA, *gB;
-    float* pm;           // plane maxima of the gradient entering a backward contraction (la_conv_act_grad_pmax)
+    float* pm;           // plane maxima of the gradient entering a backward contraction (la_conv_act_grad_pmax: exact-fp32 / fallback path)
+    // fp16 operand scales as slot rows lowered by the producing kernels (la_common.h): xs_f [nops][maxN][LA_XS_FAN] for the input of every
+    // forward conv but the first, xs_b for the (masked) gradient entering every backward conv; seam_scr: scratch for the demod-gradient
+    // partials the fused activation backward of the contraction epilogues writes (unused here: these convs have no demodulation)
+    float *xs_f, *xs_b, *seam_scr;
     void* cws; size_t cws_bytes;
     const float* x_in;   // input of the last forward
     int lastN;
@@ -97,6 +101,16 @@ static size_t f_layout(la_feat* h, void* ws) {
     }
     h->gA = c.take(gmax); h->gB = c.take(gmax);
     h->pm = c.take(pmax);
+    h->xs_f = c.take((size_t)h->nops * mn * LA_XS_FAN); h->xs_b = c.take((size_t)h->nops * mn * LA_XS_FAN);
+    {
+        size_t sc = 16;
+        for (int k = 0; k < h->nops; ++k)
+            if (h->op[k].kind == LA_FEAT_CONV_RELU) {
+                const size_t n = mn * (size_t)h->op[k].cout * la_conv_tiles_per_sample(h->op[k].res_in, h->op[k].res_in);
+                if (n > sc) sc = n;
+            }
+        h->seam_scr = c.take(sc);
+    }
     h->cws = c.take((cw + 3) / 4); h->cws_bytes = cw;
     return c.off;
 }
@@ -225,8 +239,12 @@ __global__ __launch_bounds__(256) void la_tap_fwd_kernel(const float* __restrict
 }
 
 // tap backward: gf[k] (+)= r * (u_k - y_k * sum_c u_c y_c),  u_c = g_c * sqrt(lin_c)/sqrt(HW),  y_c = f_c * r   (same thread layout)
+// mask != 0: the tapped activation is the ReLU output of the conv in front of the tap, and the result is the gradient entering that
+// conv's backward contraction: the ReLU mask (f > 0) is applied to the SUM (incoming gradient + this tap's) here, and xs_row (slot rows
+// [N][LA_XS_FAN], la_common.h) receives the fp16 operand scale of the result -- no separate activation-backward / plane-maxima sweep.
 __global__ __launch_bounds__(256) void la_tap_bwd_kernel(const float* __restrict__ f, const float* __restrict__ lin, const float* __restrict__ gfeat,
-                                                          float* __restrict__ gf, int C, int HW, long F, long off, int PL, int accumulate) {
+                                                          float* __restrict__ gf, int C, int HW, long F, long off, int PL, int accumulate, int mask,
+                                                          float* __restrict__ xs_row) {
     __shared__ float red[2][256];
     const int pl = threadIdx.x % PL, cg = threadIdx.x / PL, CG = 256 / PL;
     const int p = blockIdx.x * PL + pl;
@@ -257,27 +275,49 @@ __global__ __launch_bounds__(256) void la_tap_bwd_kernel(const float* __restrict
     for (int g = 0; g < CG; ++g) { st += red[0][g * PL + pl]; dt += red[1][g * PL + pl]; }
     const float r = rsqrtf(st + 1e-10f);
     const float dot = dt * r;                      // sum_c u_c y_c
-    if (!ok) return;
-    float* op = gf + n * C * HW + p;
-    int c = cg;
-    for (; c + 7 * CG < C; c += 8 * CG) {
-        float fv[8], g[8], w[8], prev[8];
+    float omax = 0.f;
+    if (ok) {
+        float* op = gf + n * C * HW + p;
+        int c = cg;
+        for (; c + 7 * CG < C; c += 8 * CG) {
+            float fv[8], g[8], w[8], prev[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            fv[k] = fp[(long)(c + k * CG) * HW]; g[k] = gp[(long)(c + k * CG) * HW]; w[k] = lin[c + k * CG];
-            prev[k] = accumulate ? op[(long)(c + k * CG) * HW] : 0.f;
+            for (int k = 0; k < 8; ++k) {
+                fv[k] = fp[(long)(c + k * CG) * HW]; g[k] = gp[(long)(c + k * CG) * HW]; w[k] = lin[c + k * CG];
+                prev[k] = accumulate ? op[(long)(c + k * CG) * HW] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float u = g[k] * sqrtf(w[k]) * a, y = fv[k] * r;
+                float v = r * (u - y * dot);
+                if (accumulate) v += prev[k];
+                if (mask && !(fv[k] > 0.f)) v = 0.f;
+                op[(long)(c + k * CG) * HW] = v;
+                omax = fmaxf(omax, fabsf(v));
+            }
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float u = g[k] * sqrtf(w[k]) * a, y = fv[k] * r;
-            const float v = r * (u - y * dot);
-            op[(long)(c + k * CG) * HW] = accumulate ? prev[k] + v : v;
+        for (; c < C; c += CG) {
+            const float fv = fp[(long)c * HW];
+            const float u = gp[(long)c * HW] * sqrtf(lin[c]) * a, y = fv * r;
+            float v = r * (u - y * dot);
+            if (accumulate) v += op[(long)c * HW];
+            if (mask && !(fv > 0.f)) v = 0.f;
+            op[(long)c * HW] = v;
+            omax = fmaxf(omax, fabsf(v));
         }
     }
-    for (; c < C; c += CG) {
-        const float u = gp[(long)c * HW] * sqrtf(lin[c]) * a, y = fp[(long)c * HW] * r;
-        const float v = r * (u - y * dot);
-        op[(long)c * HW] = accumulate ? op[(long)c * HW] + v : v;
+    if (xs_row) {      // (uniform) this workgroup's maximum lowers a sub-slot of sample n's row
+        __syncthreads();
+        red[0][threadIdx.x] = omax;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[0][threadIdx.x] = fmaxf(red[0][threadIdx.x], red[0][threadIdx.x + o]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            float* row = xs_row + n * LA_XS_FAN + la_xs_sub();
+            la_xs_lower(row, la_xs_peek(row), 1.f, red[0][0]);
+        }
     }
 }
 
@@ -289,8 +329,11 @@ static void fbase(LaConvArgs& a) {
     a.in_sy = a.in_sx = a.out_sy = a.out_sx = 1; a.clamp = -1.f; a.gain = 1.f; a.act = LA_ACT_LINEAR;
 }
 
+// slot-row hand-over of the fp16 operand scales (f16x2 mode): xs_in = rows of this launch's input (null: absmax / plane-maxima passes),
+// xs_out = rows the epilogue lowers for the contraction that consumes the output (forward: the next conv's; backward: those of the conv
+// whose ReLU output `mask_y` is -- the epilogue then also applies that ReLU's mask to the outgoing gradient, LaConvArgs::seam_*)
 static int f_conv(la_feat* h, const FOp& o, bool backward, const float* in, float* out, int N, hipStream_t stream, const float* in_pmax = nullptr,
-                  int in_nseg = 0) {
+                  int in_nseg = 0, const float* xs_in = nullptr, float* xs_out = nullptr, const float* mask_y = nullptr) {
     LaConvArgs a; fbase(a);
     a.wgt = backward ? o.wb : o.wf;
     a.precision = h->precision; a.wgt_bf16 = backward ? o.wqb : o.wqf;
@@ -305,8 +348,15 @@ static int f_conv(la_feat* h, const FOp& o, bool backward, const float* in, floa
     for (int t = 0; t < 9; ++t) {
         a.tap_dy[t] = backward ? 1 - t / 3 : t / 3 - 1; a.tap_dx[t] = backward ? 1 - t % 3 : t % 3 - 1; a.tap_w[t] = t;
     }
-    if (backward) a.epi = LA_EPI_BWD;
-    else { a.epi = LA_EPI_FWD; a.bias = o.bias; a.act = LA_ACT_RELU; a.gain = 1.f; }
+    if (xs_in) { a.acc_scale_x = xs_in; a.acc_scale_fan = LA_XS_FAN; a.in_pmax = nullptr; }
+    if (backward) {
+        a.epi = LA_EPI_BWD;
+        if (mask_y) {      // activation backward of the layer below, fused (its saved output is the epilogue's xin)
+            a.xin = mask_y; a.xin_bstride = (long)a.M * res * res; a.tiles_per_sample = la_conv_tiles_per_sample(res, res);
+            a.seam_ddn_part = h->seam_scr; a.seam_act = LA_ACT_RELU; a.seam_alpha = 0.f; a.seam_gain = 1.f; a.seam_clamp = -1.f;
+            a.seam_xs_out = xs_out; a.seam_xs_mult = 1.f;
+        }
+    } else { a.epi = LA_EPI_FWD; a.bias = o.bias; a.act = LA_ACT_RELU; a.gain = 1.f; a.fwd_xs_out = xs_out; }
     return la_conv_launch(a, stream);
 }
 
@@ -315,11 +365,23 @@ extern "C" int la_feat_forward(la_feat* h, const float* x, int N, float* feat_ou
     LA_CHECK_ARG(N >= 1 && N <= h->maxN, "feat_forward: batch exceeds max_batch");
     const float* cur = x;
     int rc;
+    // fp16 x2 mode: every conv's epilogue lowers the slot rows of the NEXT conv's operand scale (a pool in between only shrinks the
+    // maximum; taps do not touch the activation), so only the first conv -- whose input no kernel of this engine produces -- runs the
+    // absmax / scale passes
+    const bool slots = h->precision == LA_PREC_F16X2 && !la_dev_env("LA_NO_FEAT_SLOTS");      // (dev knob: the round-3 passes)
+    if (slots) LA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->xs_f), (int)LA_XS_INIT, (size_t)h->nops * h->maxN * LA_XS_FAN, stream));
+    auto rows = [&](float* base, int op) { return base + (size_t)op * h->maxN * LA_XS_FAN; };
+    bool first_conv = true;
     for (int k = 0; k < h->nops; ++k) {
         FOp& o = h->op[k];
         const int HWo = o.res_out * o.res_out;
         if (o.kind == LA_FEAT_CONV_RELU) {
-            if ((rc = f_conv(h, o, false, cur, o.y, N, stream))) return rc;
+            int nxt = -1;
+            for (int q = k + 1; q < h->nops; ++q) if (h->op[q].kind == LA_FEAT_CONV_RELU) { nxt = q; break; }
+            if ((rc = f_conv(h, o, false, cur, o.y, N, stream, nullptr, 0, (slots && !first_conv) ? rows(h->xs_f, k) : nullptr,
+                             (slots && nxt >= 0) ? rows(h->xs_f, nxt) : nullptr)))
+                return rc;
+            first_conv = false;
             cur = o.y;
         } else if (o.kind == LA_FEAT_TAP) {
             const int pl = tap_lanes(HWo);
@@ -345,6 +407,14 @@ extern "C" int la_feat_backward(la_feat* h, const float* gfeat, float* gx, hipSt
     float* other = h->gB;
     bool have = false;
     int rc;
+    // fp16 x2 mode: the ReLU mask of conv k and the operand scale of the masked gradient come from the kernel that WRITES that gradient
+    // last -- the tap behind conv k (la_tap_bwd_kernel, mask fused), or the backward contraction of conv k+1 when it follows directly
+    // (its epilogue applies the mask of its xin = y_k, LaConvArgs::seam_*) -- instead of an activation-backward sweep with plane maxima
+    // and a scale-reduction launch per conv.  `masked`: g already carries op k's mask and its slot rows are final.
+    const bool slots = h->precision == LA_PREC_F16X2 && !la_dev_env("LA_NO_FEAT_SLOTS");      // (dev knob: the round-3 passes)
+    if (slots) LA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->xs_b), (int)LA_XS_INIT, (size_t)h->nops * h->maxN * LA_XS_FAN, stream));
+    auto rows = [&](float* base, int op) { return base + (size_t)op * h->maxN * LA_XS_FAN; };
+    bool masked = false;
     for (int k = h->nops - 1; k >= 0; --k) {
         FOp& o = h->op[k];
         // activation feeding op k
@@ -353,16 +423,31 @@ extern "C" int la_feat_backward(la_feat* h, const float* gfeat, float* gx, hipSt
         const int HWo = o.res_out * o.res_out;
         if (o.kind == LA_FEAT_TAP) {
             const int pl = tap_lanes(HWo);
+            // (the tap's input is the output of the conv right in front of it: this launch is the last writer of that conv's gradient)
+            const bool fuse = slots && k > 0 && h->op[k - 1].kind == LA_FEAT_CONV_RELU;
             hipLaunchKernelGGL(la_tap_bwd_kernel, dim3(la_cdiv(HWo, pl), N), dim3(256), 0, stream, act_in, o.lin, gfeat, g, o.cout, HWo,
-                               (long)h->F, o.feat_off, pl, have ? 1 : 0);
+                               (long)h->F, o.feat_off, pl, have ? 1 : 0, fuse ? 1 : 0, fuse ? rows(h->xs_b, k - 1) : (float*)nullptr);
             have = true;
+            masked = fuse;
         } else if (o.kind == LA_FEAT_CONV_RELU) {
             LA_CHECK_ARG(have, "feat_backward: the op list must end with a tap");
-            // ReLU mask of this layer on the incoming gradient, with the plane maxima the fp16 operand scale of its backward
-            // contraction needs (one sweep instead of a mask pass + an absmax pass)
-            if ((rc = la_conv_act_grad_pmax(g, o.y, g, h->pm, N, o.cout, HWo, LA_ACT_RELU, 0.f, 1.f, -1.f, stream))) return rc;
             float* dst = (k == 0 && o.mb_ == o.cin) ? gx : other;
-            if ((rc = f_conv(h, o, true, g, dst, N, stream, h->pm, la_conv_act_grad_segments(HWo)))) return rc;
+            // the conv below, if it feeds this one directly: this contraction's epilogue masks its gradient and lowers its slot rows
+            const bool below = slots && k > 0 && h->op[k - 1].kind == LA_FEAT_CONV_RELU && o.mb_ == o.cin && dst != gx;
+            if (masked) {
+                if ((rc = f_conv(h, o, true, g, dst, N, stream, nullptr, 0, rows(h->xs_b, k), below ? rows(h->xs_b, k - 1) : nullptr,
+                                 below ? h->op[k - 1].y : nullptr)))
+                    return rc;
+            } else {
+                // ReLU mask of this layer on the incoming gradient, with the plane maxima the fp16 operand scale of its backward
+                // contraction needs (one sweep instead of a mask pass + an absmax pass): exact-fp32 / bf16 modes, op lists without
+                // a tap or a conv right behind this conv
+                if ((rc = la_conv_act_grad_pmax(g, o.y, g, h->pm, N, o.cout, HWo, LA_ACT_RELU, 0.f, 1.f, -1.f, stream))) return rc;
+                if ((rc = f_conv(h, o, true, g, dst, N, stream, h->pm, la_conv_act_grad_segments(HWo), nullptr, below ? rows(h->xs_b, k - 1) : nullptr,
+                                 below ? h->op[k - 1].y : nullptr)))
+                    return rc;
+            }
+            masked = below;
             if (k == 0 && dst != gx) {
                 // padded backward channels (cin not a multiple of 4): copy the real ones out
                 const long HWi = (long)o.res_in * o.res_in;
@@ -378,6 +463,7 @@ extern "C" int la_feat_backward(la_feat* h, const float* gfeat, float* gx, hipSt
             hipLaunchKernelGGL(la_pool2_bwd_kernel, dim3(la_cdiv(planes * HWo, 256)), dim3(256), 0, stream, act_in, g, other, o.res_in,
                                planes, o.kind == LA_FEAT_MAXPOOL2);
             float* t = g; g = other; other = t;
+            masked = false;
         }
     }
     LA_CHECK_LAUNCH();
