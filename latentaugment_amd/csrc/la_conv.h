@@ -29,6 +29,13 @@ struct LaConvArgs {
     const float* in_scale;   // [B][scale_stride] or null: modulate-on-load  x * s[b][c]
     long in_bstride;
     int scale_stride;
+    // Launch input = in * act'(in_mask_y) * in_gain, applied while the pre-split copy is made (16-bit flat / split-K launches only: the
+    // activation backward in front of a backward contraction without a sweep of its own, bias_act.py:170 with grad = 1).  in_mask_y:
+    // saved output of the activation, same shape as `in`, or null (factor in_gain only; 0 is read as 1).  The operand scale must then
+    // be preset (acc_scale_x) from a bound of the product, e.g. max |in| * max slope.
+    const float* in_mask_y;
+    int in_mask_act; float in_mask_alpha, in_mask_gain, in_mask_clamp;
+    float in_gain;
     int B, C, M, Hin, Win, Hout, Wout;
     int Gy, Gx;              // output grid per sample handled by this launch
     int in_sy, in_sx;

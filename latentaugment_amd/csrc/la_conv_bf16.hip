@@ -306,10 +306,12 @@ int la_conv_xscale_from_pmax(const float* pmax, int nseg, const float* scale, in
 // bf16: 8 B per element {h | m<<16, l}.  Channels past C are zeros.  The flat kernel's gather thread (pixel, 16-channel half) then reads its
 // operand as 64 / 128 contiguous bytes (4 / 8 dwordx4) instead of 16 strided dwords, and a stride-2 gather wastes no sectors.
 // One workgroup = 32 channels x 64 pixels, transposed through LDS.
+struct LaInMask { const float* y; int act; float alpha, gain, clamp, in_gain; };      // LaConvArgs::in_mask_* / in_gain
 template <bool F16>
 __global__ __launch_bounds__(256) void la_presplit_t_kernel(const float* __restrict__ in, long in_bstride,
                                                            const float* __restrict__ scale, int scale_stride,
-                                                           const float* __restrict__ xscale, int xs_fan, unsigned* __restrict__ out, int C, long HW) {
+                                                           const float* __restrict__ xscale, int xs_fan, unsigned* __restrict__ out, int C, long HW,
+                                                           LaInMask mk) {
     constexpr int EW = F16 ? 1 : 2;                           // dwords per element
     __shared__ unsigned tile[EW][64][33];
     const int cc = blockIdx.y, b = blockIdx.z, nck = gridDim.y;
@@ -322,7 +324,12 @@ __global__ __launch_bounds__(256) void la_presplit_t_kernel(const float* __restr
         for (int i = 0; i < 8; ++i) {
             const int cl = cg * 8 + i, c = cc * KCB + cl;
             float v = 0.f;
-            if (c < C && p < HW) v = in[(long)b * in_bstride + (long)c * HW + p] * ((scale ? scale[(long)b * scale_stride + c] : 1.f) * xs);
+            if (c < C && p < HW) {
+                const long o = (long)b * in_bstride + (long)c * HW + p;
+                v = in[o] * ((scale ? scale[(long)b * scale_stride + c] : 1.f) * xs);
+                if (mk.y) v *= la_act_bwd_from_y(mk.y[o], mk.act, mk.alpha, mk.gain, mk.clamp);
+                v *= mk.in_gain;
+            }
             if (F16) {
                 const _Float16 h = (_Float16)v;
                 const _Float16 l = (_Float16)(v - (float)h);
@@ -401,6 +408,7 @@ static int prepare_scale(LaConvArgs& a, hipStream_t stream) {
 // can this launch use the halo kernel?  dense stride-1 3x3 taps within +-1, grid = whole 4x32 tiles, above the split-K sizes
 bool la_conv_bf16_uses_halo(const LaConvArgs& a) {
     if (a.precision == LA_PREC_F32 || a.in_q) return false;
+    if (a.in_mask_y || (a.in_gain != 0.f && a.in_gain != 1.f)) return false;      // (an input mask is applied by the pre-split copy)
     if (a.in_sy != 1 || a.in_sx != 1 || a.out_sy != 1 || a.out_sx != 1 || a.out_oy != 0 || a.out_ox != 0) return false;
     if ((a.Gx & 31) != 0 || (a.Gy & 3) != 0 || a.Gy != a.Hout || a.Gx != a.Wout || a.ntaps != 9) return false;
     // Grids up to 34x34 stay on the split-K path (la_conv.hip SPLITK_MAX_G).  Round 3 measured the 32x32 layers (512 -> 512, K = 4608) on
@@ -436,17 +444,19 @@ int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
     char* base = static_cast<char*>(a.ws);
     const size_t ws_bytes = a.ws_bytes;
     const dim3 pgrid((unsigned)la_cdiv(HW, 64), (unsigned)la_cdiv(a.C, KCB), (unsigned)a.B);
+    const LaInMask mk{a.in_mask_y, a.in_mask_act, a.in_mask_alpha, a.in_mask_gain, a.in_mask_clamp, a.in_gain != 0.f ? a.in_gain : 1.f};
+    LA_CHECK_ARG((!a.in_mask_y && mk.in_gain == 1.f) || a.acc_scale_x || a.precision != LA_PREC_F16X2, "conv: an input mask needs a preset operand scale");
     if (a.precision == LA_PREC_F16X2) {
         int rc = prepare_scale(a, stream);
         if (rc) return rc;
         void* q = a.ws;
         hipLaunchKernelGGL(la_presplit_t_kernel<true>, pgrid, dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale, a.scale_stride,
-                           a.acc_scale_x, a.acc_scale_fan, (unsigned*)q, a.C, HW);
+                           a.acc_scale_x, a.acc_scale_fan, (unsigned*)q, a.C, HW, mk);
         a.in_q = q;
     } else {
         void* q = base + presplit_hdr_bytes(a.B, a.C);
         hipLaunchKernelGGL(la_presplit_t_kernel<false>, pgrid, dim3(256), 0, stream, a.in, a.in_bstride, a.in_scale, a.scale_stride,
-                           (const float*)nullptr, 0, (unsigned*)q, a.C, HW);
+                           (const float*)nullptr, 0, (unsigned*)q, a.C, HW, mk);
         a.in_q = q;
     }
     LA_CHECK_LAUNCH();

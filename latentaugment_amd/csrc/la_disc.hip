@@ -49,6 +49,8 @@ struct la_disc {
     float* pm;              // plane maxima of the gradient entering a backward contraction (la_conv_act_grad_pmax)
     float fir[16];
     void* cws; size_t cws_bytes;
+    float* xs_b;            // backward slot rows [2 * nblocks][maxB][LA_XS_FAN] (la_common.h): fp16 operand scales of the gradient entering a block
+                            // (lowered by the up-2 FIR that produces it) and of the masked gradient entering conv0's backward (lowered by the FIR adjoint)
     float* xs_fwd;          // [maxB] constant fp16 operand scale of every FORWARD contraction input: with a clamp all of them are bounded
                             // (clamped layer outputs, residual sums <= 2 * clamp / sqrt(2), FIR outputs <= their input, |std| <= max|x|)
     int precision, lastB, mbstd_group;
@@ -123,6 +125,7 @@ static size_t d_layout(la_disc* h, void* ws) {
     { size_t w = la_modconv_workspace_bytes((int)mb, h->C4 + 1, h->C4 + 1, 4, 0); if (w > cw) cw = w; }
     h->mb = c.take(mb * (h->C4 + 1) * 16); h->yc = c.take(mb * h->C4 * 16); h->fc = c.take(mb * h->C4);
     h->xs_fwd = c.take(mb * LA_XS_FAN);
+    h->xs_b = c.take((size_t)2 * DMAX_BLOCKS * mb * LA_XS_FAN);
     h->logits = c.take(mb); h->dlogits = c.take(mb); h->g_fc = c.take(mb * h->C4); h->g_flat = c.take(mb * (h->C4 + 1) * 16);
     h->gA = c.take(gmax); h->gB = c.take(gmax); h->scrA = c.take(smax); h->scrB = c.take(gmax);
     h->pm = c.take(pmax);
@@ -457,10 +460,13 @@ static void set_w(LaConvArgs& a, la_disc* h, const DConv& L, bool backward) {
 
 // dense conv (k = 3 pad 1, or k = 1) at one resolution, forward (with bias/act epilogue) or backward-data (plain)
 static int conv_same(la_disc* h, const DConv& L, bool backward, const float* in, float* out, int B, int res, int act, float gain,
-                     float clamp, const float* addend, float* out2, hipStream_t stream, const float* in_pmax = nullptr, int in_nseg = 0) {
+                     float clamp, const float* addend, float* out2, hipStream_t stream, const float* in_pmax = nullptr, int in_nseg = 0,
+                     const float* xs_rows = nullptr, float in_gain = 1.f) {
     LaConvArgs a; cbase(a);
     set_w(a, h, L, backward);
     a.in = in; a.out = out; a.B = B; a.in_pmax = in_pmax; a.in_pmax_nseg = in_nseg;
+    if (xs_rows) { a.acc_scale_x = xs_rows; a.acc_scale_fan = LA_XS_FAN; a.in_pmax = nullptr; }      // slot rows left by the producer of `in`
+    a.in_gain = in_gain;
     a.C = backward ? L.cout : L.cin; a.M = backward ? L.mb_ : L.cout;      // (padded channels of a backward come out as zeros)
     a.in_bstride = (long)a.C * res * res;
     a.Hin = a.Win = a.Hout = a.Wout = a.Gy = a.Gx = res;
@@ -501,10 +507,22 @@ extern "C" int la_disc_forward(la_disc* h, const float* img, int B, hipStream_t 
         // conv0
         if ((rc = conv_same(h, b.conv0, false, b.xin, b.y0, B, res, LA_ACT_LRELU, sq2, h->clamp, nullptr, nullptr, stream))) return rc;
         // conv1: FIR pad (2,2,2,2) -> (res+1)^2, stride-2 conv, lrelu * sqrt2 * sqrt(1/2), clamp * sqrt(1/2); + skip  (:106-109)
-        if ((rc = la_upfirdn2d_ex(b.y0, h->scrA, B, b.cin, res, res, h->fir, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, 0, 1.f, nullptr, stream))) return rc;
+        // fp16 x2 mode with the a-priori operand scale: the FIR writes its result ALREADY as the contraction's packed operand (scale,
+        // fp16 split, channel interleave: la_fir4x4_adj_pack_kernel with the forward taps) -- one pass instead of the scalar FIR into a
+        // (res+1)^2 fp32 scratch + the pre-split copy of that scratch
+        const size_t qbytes = (size_t)B * la_cdiv(b.cin, 32) * 32 * (res + 1) * (res + 1) * 4;
+        const bool fir_pack = h->precision == LA_PREC_F16X2 && h->clamp > 0.f && h->maxB <= 256 && res % 4 == 0 && h->cws_bytes > qbytes + 1024 &&
+                              !la_dev_env("LA_NO_DISC_FUSE");
+        if (!fir_pack && (rc = la_upfirdn2d_ex(b.y0, h->scrA, B, b.cin, res, res, h->fir, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, 0, 1.f, nullptr, stream))) return rc;
         {
             LaConvArgs a; cbase(a);
             set_w(a, h, b.conv1, false);
+            if (fir_pack) {
+                unsigned* q = reinterpret_cast<unsigned*>(h->cws);
+                if ((rc = la_fir4x4_adjoint_pack_f16(b.y0, q, h->xs_fwd, LA_XS_FAN, B, b.cin, res, res, h->fir, 1.f, stream, 1))) return rc;
+                const size_t used = (qbytes + 255) & ~(size_t)255;
+                a.in_q = q; a.ws = static_cast<char*>(h->cws) + used; a.ws_bytes = h->cws_bytes - used;
+            }
             a.in = h->scrA; a.in_bstride = (long)b.cin * (res + 1) * (res + 1); a.out = b.x1;
             a.B = B; a.C = b.cin; a.M = b.cout; a.Hin = a.Win = res + 1; a.Hout = a.Wout = a.Gy = a.Gx = hq;
             a.in_sy = a.in_sx = 2; a.ntaps = 9;
@@ -565,22 +583,37 @@ extern "C" int la_disc_backward(la_disc* h, const float* dlogits, float* g_img, 
     LA_CHECK_LAUNCH();
     float* g_sum = h->gA;       // gradient w.r.t. the current block's output (sum)
     float* other = h->gB;
+    // fp16 x2 mode: no activation-backward sweeps.  The gradient entering a block comes out of the up-2 FIR of the block above, which
+    // lowers its operand-scale slot rows; the two contractions that read it take their element-wise factor -- act'(x1) of conv1,
+    // sqrt(1/2) of the skip branch -- inside their pre-split copy (LaConvArgs::in_mask_y / in_gain); the FIR adjoint behind the
+    // transposed conv applies act'(y0) and lowers the rows of conv0's backward contraction.  (Round 3: three sweeps of
+    // la_act_grad_pmax_kernel + three scale reductions per block.)  The last block's gradient comes from MinibatchStd: sweeps as before.
+    const bool fuse = h->precision == LA_PREC_F16X2 && !la_dev_env("LA_NO_DISC_FUSE");
+    if (fuse) LA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->xs_b), (int)LA_XS_INIT, (size_t)2 * h->nblocks * h->maxB * LA_XS_FAN, stream));
+    auto rows_g = [&](int k) { return h->xs_b + (size_t)(2 * k) * h->maxB * LA_XS_FAN; };
+    auto rows_c0 = [&](int k) { return h->xs_b + (size_t)(2 * k + 1) * h->maxB * LA_XS_FAN; };
     for (int k = h->nblocks - 1; k >= 0; --k) {
         DBlock& b = h->blk[k];
         const int res = b.res, hq = res / 2;
+        const bool gs = fuse && k < h->nblocks - 1;      // g_sum came out of the up-2 FIR of block k + 1 with its slot rows
         // ---- conv1 branch: act' (gain 1, clamp*sqrt(1/2)) -> transposed stride-2 conv -> FIR adjoint (pad 1)
-        // (every act' below also leaves the plane maxima of its result: the fp16 operand scale of the contraction that follows
-        //  then needs no absmax pass -- la_conv_act_grad_pmax)
         const int nsq = la_conv_act_grad_segments((long)hq * hq), nsf = la_conv_act_grad_segments((long)res * res);
-        if ((rc = la_conv_act_grad_pmax(g_sum, b.x1, h->scrB, h->pm, B, b.cout, (long)hq * hq, LA_ACT_LRELU, 0.2f, sq2 * rs2,
-                                        h->clamp >= 0.f ? h->clamp * rs2 : -1.f, stream))) return rc;
+        if (!gs && (rc = la_conv_act_grad_pmax(g_sum, b.x1, h->scrB, h->pm, B, b.cout, (long)hq * hq, LA_ACT_LRELU, 0.2f, sq2 * rs2,
+                                               h->clamp >= 0.f ? h->clamp * rs2 : -1.f, stream))) return rc;
         {
             LaConvArgs a; cbase(a);
             set_w(a, h, b.conv1, true);
-            a.in = h->scrB; a.in_bstride = (long)b.cout * hq * hq; a.out = h->scrA;
+            a.in = gs ? g_sum : h->scrB; a.in_bstride = (long)b.cout * hq * hq; a.out = h->scrA;
             a.B = B; a.C = b.cout; a.M = b.cin; a.Hin = a.Win = hq; a.Hout = a.Wout = res + 1;
-            a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW; a.in_pmax = h->pm; a.in_pmax_nseg = nsq;
+            a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW;
+            if (gs) {
+                a.in_mask_y = b.x1; a.in_mask_act = LA_ACT_LRELU; a.in_mask_alpha = 0.2f; a.in_mask_gain = sq2 * rs2;
+                a.in_mask_clamp = h->clamp >= 0.f ? h->clamp * rs2 : -1.f;
+                a.acc_scale_x = rows_g(k); a.acc_scale_fan = LA_XS_FAN;
+            } else { a.in_pmax = h->pm; a.in_pmax_nseg = nsq; }
             if (h->precision != LA_PREC_F32 && (rc = la_conv_prepare_input(a, stream))) return rc;   // split once for the four phases
+            const bool merged = h->precision != LA_PREC_F32;      // 16-bit kernels: the four phases in ONE launch (as the generator's up layers)
+            int np = 0;
             for (int py = 0; py < 2; ++py)
                 for (int px = 0; px < 2; ++px) {
                     a.out_oy = py; a.out_ox = px; a.Gy = py ? hq : hq + 1; a.Gx = px ? hq : hq + 1;
@@ -588,17 +621,43 @@ extern "C" int la_disc_backward(la_disc* h, const float* dlogits, float* g_img, 
                     for (int ky = py; ky < 3; ky += 2)
                         for (int kx = px; kx < 3; kx += 2) { a.tap_dy[nt] = -(ky / 2); a.tap_dx[nt] = -(kx / 2); a.tap_w[nt] = ky * 3 + kx; ++nt; }
                     a.ntaps = nt;
+                    if (merged) {
+                        LaConvArgs::Phase& P = a.ph[np++];
+                        P.Gy = a.Gy; P.Gx = a.Gx; P.out_oy = py; P.out_ox = px; P.ntaps = nt;
+                        for (int t = 0; t < nt; ++t) { P.tap_dy[t] = a.tap_dy[t]; P.tap_dx[t] = a.tap_dx[t]; P.tap_w[t] = a.tap_w[t]; }
+                        continue;
+                    }
                     if ((rc = la_conv_launch(a, stream))) return rc;
                 }
+            if (merged) {
+                a.nphase = np;
+                a.out_oy = a.out_ox = 0; a.Gy = a.Gx = hq + 1; a.ntaps = 4;      // launch-wide fields = the largest phase (checks only)
+                if ((rc = la_conv_launch(a, stream))) return rc;
+            }
         }
-        if ((rc = la_upfirdn2d_ex(h->scrA, other, B, b.cin, res + 1, res + 1, h->fir, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1.f, nullptr, stream))) return rc;
-        // ---- conv0: act' then backward-data
-        if ((rc = la_conv_act_grad_pmax(other, b.y0, other, h->pm, B, b.cin, (long)res * res, LA_ACT_LRELU, 0.2f, sq2, h->clamp, stream))) return rc;
-        if ((rc = conv_same(h, b.conv0, true, other, h->scrA, B, res, 0, 0.f, 0.f, nullptr, nullptr, stream, h->pm, nsf))) return rc;   // scrA >= B*cin*res^2
+        if (fuse) {
+            // FIR adjoint + act'(y0) + the slot rows of conv0's backward contraction in one kernel
+            LaFirTail tail{b.y0, LA_ACT_LRELU, 0.2f, sq2, h->clamp, rows_c0(k)};
+            if ((rc = la_upfirdn2d_ex(h->scrA, other, B, b.cin, res + 1, res + 1, h->fir, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1.f, nullptr, stream, nullptr, &tail))) return rc;
+            if ((rc = conv_same(h, b.conv0, true, other, h->scrA, B, res, 0, 0.f, 0.f, nullptr, nullptr, stream, nullptr, 0, rows_c0(k)))) return rc;
+        } else {
+            if ((rc = la_upfirdn2d_ex(h->scrA, other, B, b.cin, res + 1, res + 1, h->fir, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1.f, nullptr, stream))) return rc;
+            // ---- conv0: act' then backward-data
+            if ((rc = la_conv_act_grad_pmax(other, b.y0, other, h->pm, B, b.cin, (long)res * res, LA_ACT_LRELU, 0.2f, sq2, h->clamp, stream))) return rc;
+            if ((rc = conv_same(h, b.conv0, true, other, h->scrA, B, res, 0, 0.f, 0.f, nullptr, nullptr, stream, h->pm, nsf))) return rc;   // scrA >= B*cin*res^2
+        }
         // ---- skip branch: * sqrt(1/2) -> 1x1 adjoint -> FIR-down adjoint (up 2, pad (2,1,2,1), flipped), added to the conv branch
-        if ((rc = la_conv_act_grad_pmax(g_sum, b.ysk, h->scrB, h->pm, B, b.cout, (long)hq * hq, LA_ACT_LINEAR, 0.f, rs2, -1.f, stream))) return rc;
-        if ((rc = conv_same(h, b.skip, true, h->scrB, g_sum, B, hq, 0, 0.f, 0.f, nullptr, nullptr, stream, h->pm, nsq))) return rc;       // reuse g_sum buffer: [B][cin][hq^2]
-        if ((rc = la_upfirdn2d_ex(g_sum, other, B, b.cin, hq, hq, h->fir, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1, 1, 1.f, h->scrA, stream))) return rc;
+        if (gs) {
+            // (the pre-split copy of g_sum carries the factor; the contraction then overwrites the g_sum buffer: [B][cin][hq^2])
+            if ((rc = conv_same(h, b.skip, true, g_sum, g_sum, B, hq, 0, 0.f, 0.f, nullptr, nullptr, stream, nullptr, 0, rows_g(k), rs2))) return rc;
+        } else {
+            if ((rc = la_conv_act_grad_pmax(g_sum, b.ysk, h->scrB, h->pm, B, b.cout, (long)hq * hq, LA_ACT_LINEAR, 0.f, rs2, -1.f, stream))) return rc;
+            if ((rc = conv_same(h, b.skip, true, h->scrB, g_sum, B, hq, 0, 0.f, 0.f, nullptr, nullptr, stream, h->pm, nsq))) return rc;       // reuse g_sum buffer: [B][cin][hq^2]
+        }
+        {
+            LaFirTail tail{nullptr, 0, 0.f, 0.f, 0.f, (fuse && k > 0) ? rows_g(k - 1) : nullptr};
+            if ((rc = la_upfirdn2d_ex(g_sum, other, B, b.cin, hq, hq, h->fir, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1, 1, 1.f, h->scrA, stream, nullptr, &tail))) return rc;
+        }
         // `other` now holds d/d(xin) of this block
         float* t = g_sum; g_sum = other; other = t;
     }

@@ -3,9 +3,16 @@
 #include "la_common.h"
 
 // generic op, optional same-shape addend (skip connection add fused into the store)
+// optional tail of the 4x4 kernels: activation backward of the layer whose saved output `yref` has the shape of `out` (stride-1 kernel:
+// out = fir(in) * act'(yref), bias_act.py:170 with grad = 1) and / or the fp16 operand scale of `out` for the contraction that consumes
+// it (slot rows [B][LA_XS_FAN], la_common.h; stride-1 and up-2 kernels)
+struct LaFirTail {
+    const float* yref; int act; float alpha, gain, clamp;
+    float* xs_out;
+};
 int la_upfirdn2d_ex(const float* in, float* out, int B, int C, int Hin, int Win, const float* f_host, int fh, int fw,
                     int upx, int upy, int dnx, int dny, int padx0, int padx1, int pady0, int pady1, int flip_filter,
-                    float gain, const float* addend, hipStream_t stream, float* pmax = nullptr);
+                    float gain, const float* addend, hipStream_t stream, float* pmax = nullptr, const LaFirTail* tail = nullptr);
 // pmax (optional, [B*C][la_fir4x4_segments(Hout, Wout)]): partial max |out| of every plane, one per workgroup -- lets the
 // contraction that consumes `out` skip its own absmax pass (fp16 operand scale).
 int la_fir4x4_segments(int Hout, int Wout);
@@ -26,4 +33,5 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
 // FIR adjoint of an up-sampling layer written straight into the stride-2 backward contraction's operand format (fp16 mode):
 // q [B][ceil(C/32)][(H+1)*(W+1)][32 channels] = {h | l << 16} of xscale[b] * adjoint(in); see la_upfirdn2d.hip
 int la_fir4x4_adjoint_pack_f16(const float* in, unsigned* q, const float* xscale, int xs_fan, int B, int C, int H, int W, const float* f_host,
-                               float gain, hipStream_t stream);
+                               float gain, hipStream_t stream, int flip_taps = 0);
+// flip_taps = 1: the forward 4x4 FIR with pad 2 (same geometry: (H+1) x (W+1) outputs) instead of the adjoint of the pad-1 FIR

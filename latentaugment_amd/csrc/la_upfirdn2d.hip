@@ -13,7 +13,8 @@ struct FirArgs {
     int upx, upy, dnx, dny, padx0, pady0;
     int fw, fh;
     float f[FIR_MAX * FIR_MAX];  // effective correlation kernel (already flipped as needed, gain folded in)
-    int epi;                     // 0 plain, 1 modconv epilogue
+    int epi;                     // 0 plain, 1 modconv epilogue, 2 activation backward: out = fir(in) * act'(yref) (4x4 stride-1 scalar kernel)
+    const float* yref;           // epi 2: saved output of the activation, same shape as `out`
     const float* demod; int demod_stride;   // [B][stride]
     const float* noise; long noise_bstride; float noise_strength;
     const float* bias;
@@ -106,6 +107,8 @@ __device__ __forceinline__ float la_fir4x4_plane(const FirArgs& a, const float (
             v = v * dm + bv;
             if (a.noise) v += a.noise[(long)(p / a.C) * a.noise_bstride + pos] * a.noise_strength;
             v = la_act_fwd(v, a.act, a.alpha, a.gain, a.clamp);
+        } else if (EPI == 2) {
+            v *= la_act_bwd_from_y(a.yref[(long)p * HWout + pos], a.act, a.alpha, a.gain, a.clamp);
         } else if (a.addend) {
             v += a.addend[(long)p * HWout + pos];
         }
@@ -172,7 +175,7 @@ static int fir_fill(FirArgs& a, const float* in, float* out, int B, int C, int H
     for (int i = 0; i < fh; ++i)
         for (int j = 0; j < fw; ++j)
             a.f[i * fw + j] = gain * (flip_filter ? f_host[i * fw + j] : f_host[(fh - 1 - i) * fw + (fw - 1 - j)]);
-    a.epi = 0; a.demod = nullptr; a.noise = nullptr; a.bias = nullptr; a.addend = nullptr;
+    a.epi = 0; a.demod = nullptr; a.noise = nullptr; a.bias = nullptr; a.addend = nullptr; a.yref = nullptr;
     a.demod_stride = 0; a.noise_bstride = 0; a.noise_strength = 0.f;
     a.act = LA_ACT_LINEAR; a.alpha = 0.f; a.gain = 1.f; a.clamp = -1.f;
     return LA_OK;
@@ -316,11 +319,20 @@ int la_fir4x4_segments(int Hout, int Wout) { return la_cdiv(Wout, 64) * la_cdiv(
 // then columns, ascending) as the generic kernel above, without its per-output tap search; work item = 2 x 4 (up) / 1 x 2 (down)
 // outputs, flat over all planes.
 __global__ __launch_bounds__(256) void la_fir4x4_up2_kernel(FirArgs a) {      // up 2, pad0 2: out [2H][2W]
+    __shared__ unsigned smx[64];                                 // xs_out: max |out| per sample of this workgroup (as la_fir4x4_s1p_kernel)
     const int wq = a.Wout >> 2;                                  // 4-column groups per output row
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const long per_plane = (long)a.Hin * wq;
-    const int p = (int)(gid / per_plane);
-    if (p >= a.P) return;
+    const int pp = (int)(gid / per_plane);
+    const bool live = pp < a.P;
+    if (!live && !a.xs_out) return;
+    if (a.xs_out) {
+        if (threadIdx.x < 64) smx[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    const int p = live ? pp : a.P - 1;
+    float omax = 0.f;
+    if (live) {
     const int within = (int)(gid - (long)p * per_plane);
     const int i = within / wq, q = within - i * wq;
     const int j0 = 2 * q;
@@ -360,6 +372,22 @@ __global__ __launch_bounds__(256) void la_fir4x4_up2_kernel(FirArgs a) {      //
             o[0] += ad.x; o[1] += ad.y; o[2] += ad.z; o[3] += ad.w;
         }
         *reinterpret_cast<float4*>(a.out + (long)p * HWout + pos) = make_float4(o[0], o[1], o[2], o[3]);
+        omax = fmaxf(omax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+    }
+    }
+    if (a.xs_out) {      // operand scale of `out` for its consumer: per-sample maxima of the workgroup through LDS, one lowering per sample
+        const int b = p / a.C, b0 = (int)(((long)blockIdx.x * 256) / per_plane) / a.C;
+        const int bi = b - b0;
+        if (live && omax > 0.f) {
+            if (bi < 64) atomicMax(&smx[bi], __float_as_uint(omax));
+            else { float* row = a.xs_out + (long)b * LA_XS_FAN + la_xs_sub(threadIdx.x); la_xs_lower(row, la_xs_peek(row), a.xs_mult ? a.xs_mult[b] : 1.f, omax); }
+        }
+        __syncthreads();
+        const int bt = b0 + (int)threadIdx.x;
+        if (threadIdx.x < 64 && smx[threadIdx.x] != 0u && bt * a.C < a.P) {
+            float* row = a.xs_out + (long)bt * LA_XS_FAN + la_xs_sub();
+            la_xs_lower(row, la_xs_peek(row), a.xs_mult ? a.xs_mult[bt] : 1.f, __uint_as_float(smx[threadIdx.x]));
+        }
     }
 }
 
@@ -442,6 +470,7 @@ static int fir_launch_inner(const FirArgs& a, hipStream_t stream) {
         dim3 g(la_cdiv(a.Wout, 64), la_cdiv(a.Hout, 4 * FIR_ROWS), a.P < 4096 ? a.P : 4096);
         LA_CHECK_ARG(g.y <= 65535, "upfirdn2d: output too tall");
         if (a.epi == 1) hipLaunchKernelGGL(la_fir4x4_s1_kernel<1>, g, dim3(256), 0, stream, a);
+        else if (a.epi == 2) hipLaunchKernelGGL(la_fir4x4_s1_kernel<2>, g, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(la_fir4x4_s1_kernel<0>, g, dim3(256), 0, stream, a);
         LA_CHECK_LAUNCH();
         return LA_OK;
@@ -462,6 +491,7 @@ static int fir_launch_inner(const FirArgs& a, hipStream_t stream) {
         LA_CHECK_LAUNCH();
         return LA_OK;
     }
+    LA_CHECK_ARG(!a.xs_out && a.epi != 2, "upfirdn2d: this shape runs on the generic kernel, which has no operand-scale / activation-backward tail");
     dim3 grid(la_cdiv(a.Wout, 64), la_cdiv(a.Hout, 4), a.P < 1024 ? a.P : 1024);
     LA_CHECK_ARG(grid.y <= 65535, "upfirdn2d: output too tall");
     hipLaunchKernelGGL(la_upfirdn2d_kernel, grid, dim3(256), 0, stream, a);
@@ -471,12 +501,20 @@ static int fir_launch_inner(const FirArgs& a, hipStream_t stream) {
 
 int la_upfirdn2d_ex(const float* in, float* out, int B, int C, int Hin, int Win, const float* f_host, int fh, int fw,
                     int upx, int upy, int dnx, int dny, int padx0, int padx1, int pady0, int pady1, int flip_filter,
-                    float gain, const float* addend, hipStream_t stream, float* pmax) {
+                    float gain, const float* addend, hipStream_t stream, float* pmax, const LaFirTail* tail) {
     FirArgs a; int ho, wo;
     int rc = fir_fill(a, in, out, B, C, Hin, Win, f_host, fh, fw, upx, upy, dnx, dny, padx0, padx1, pady0, pady1,
                       flip_filter, gain, &ho, &wo);
     if (rc) return rc;
     a.addend = addend;
+    if (tail) {
+        const bool s1 = upx == 1 && upy == 1 && dnx == 1 && dny == 1 && fw == 4 && fh == 4;
+        const bool up2 = upx == 2 && upy == 2 && dnx == 1 && dny == 1 && fw == 4 && fh == 4 && padx0 == 2 && pady0 == 2;
+        LA_CHECK_ARG(!tail->yref || (s1 && !addend), "upfirdn2d: the fused activation backward exists for the 4x4 stride-1 kernel");
+        LA_CHECK_ARG(!tail->xs_out || s1 || up2, "upfirdn2d: the operand-scale hand-over exists for the 4x4 stride-1 and up-2 kernels");
+        if (tail->yref) { a.epi = 2; a.yref = tail->yref; a.act = tail->act; a.alpha = tail->alpha; a.gain = tail->gain; a.clamp = tail->clamp; }
+        a.xs_out = tail->xs_out; a.xs_mult = nullptr;
+    }
     if (pmax && upx == 1 && upy == 1 && dnx == 1 && dny == 1 && fw == 4 && fh == 4) a.pmax = pmax;
     else LA_CHECK_ARG(!pmax, "upfirdn2d: plane maxima are produced by the 4x4 stride-1 kernel only");
     return fir_launch(a, stream);
@@ -615,7 +653,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void l
 
 // in [B][C][H][W] -> q [B][ceil(C/32)][(H+1)*(W+1)][32] packed fp16 pairs of  xscale[b] * (FIR adjoint of `in`)
 int la_fir4x4_adjoint_pack_f16(const float* in, unsigned* q, const float* xscale, int xs_fan, int B, int C, int H, int W, const float* f_host,
-                               float gain, hipStream_t stream) {
+                               float gain, hipStream_t stream, int flip_taps) {
     LA_CHECK_ARG(in && q && xscale && f_host, "fir_adjoint_pack: null pointer");
     LA_CHECK_ARG(W % 4 == 0 && (((size_t)in | (size_t)q) & 15) == 0, "fir_adjoint_pack: rows must be 16-byte aligned");
     FirPackArgs a;
@@ -623,7 +661,9 @@ int la_fir4x4_adjoint_pack_f16(const float* in, unsigned* q, const float* xscale
     a.pad = 2;         // adjoint of pad (1,1,1,1): fw - 1 - pad = 2 per side (upfirdn2d.py:255-266)
     // adjoint = correlation with the flipped filter = flip_filter of the forward op negated; the forward (flip_filter = False)
     // correlates with the flipped taps, so the adjoint correlates with the taps as given
-    for (int i = 0; i < 16; ++i) a.f[i] = gain * f_host[i];
+    // (flip_taps: the FORWARD op with pad (2,2,2,2) -- upfirdn2d(x, f, padding=2), a true convolution, i.e. correlation with the flipped
+    //  taps, upfirdn2d.py:198-199 -- has the same geometry: the discriminator's stride-2 conv reads its (H+1)^2 pre-filtered input this way)
+    for (int i = 0; i < 16; ++i) a.f[i] = gain * f_host[flip_taps ? 15 - i : i];
     dim3 grid(la_cdiv(a.Wz, 64), la_cdiv(a.Hz, 8), B * a.nck);
     LA_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "fir_adjoint_pack: grid too large");
     const int slot = la_prof_open(LA_PC_FIR, 32.0 * B * C * (double)a.Hz * a.Wz, 4.0 * B * C * ((double)H * W + (double)a.Hz * a.Wz), stream);
