@@ -226,7 +226,9 @@ def roofline_leg(lib, _lib, args, one_step, elapsed_per_step):
                               'note': 'SURVEY 8(d): 700.2 MB per image-step (fwd+bwd) + 274.6 MB final forward per image + shared weights'}
     # HBM bytes per launch of the dominant class from the committed PMC passes of this workload (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate passes, scripts/make_profiles.sh): counters cannot be read from inside the process
-    pmc = os.path.join(ROOT, 'profiles', f'r03_pmc_traffic_{args.precision}.json')
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_pmc_traffic_{args.precision}.json')))      # the latest round's set
+    pmc = cands[-1] if cands else ''
     if os.path.isfile(pmc) and args.preset == 'B' and args.w_disc == 0 and args.batch == 8 and args.res == 256:
         pj = json.load(open(pmc))
         if pj.get('precision') == args.precision and dom in pj.get('classes', {}):

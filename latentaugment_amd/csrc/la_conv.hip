@@ -461,7 +461,8 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
         const int ntiles_flat = (int)tiles_flat;
         float taps = (float)a.ntaps;
         if (nphase > 0) { taps = 0.f; for (int p = 0; p < nphase; ++p) taps += (float)a.ph[p].ntaps * ((float)a.ph[p].Gy * a.ph[p].Gx / (float)Gsum); }
-        const int ks = choose_ksplit(bf, (long)ntiles_flat * mtiles, nck, taps, 4.0 * a.B * a.M * (double)Gsum);
+        int ks = choose_ksplit(bf, (long)ntiles_flat * mtiles, nck, taps, 4.0 * a.B * a.M * (double)Gsum);
+        if (la_dev_knob(LA_KNOB_KSPLIT) > 0 && la_dev_knob(LA_KNOB_KSPLIT) <= nck) { const int per = la_cdiv(nck, la_dev_knob(LA_KNOB_KSPLIT)); ks = la_cdiv(nck, per); }
         {
             if ((long)ks * a.B * a.M * Gsum <= splitk_floats && ks >= 2) {
                 as.ksplit = ks;

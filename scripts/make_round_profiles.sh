@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: every artefact of profiles/<RR>_* from ONE box at ONE commit -> gpurun_out/profiles_new/
-#   usage: bash scripts/make_round_profiles.sh r03
-RR=${1:-r03}
+#   usage: bash scripts/make_round_profiles.sh r04
+RR=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/profiles_new
 rm -rf $O; mkdir -p $O
