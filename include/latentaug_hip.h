@@ -158,9 +158,9 @@ int la_synth_create(int img_resolution, int img_channels, int w_dim, const int* 
 void la_synth_destroy(la_synth* h);
 /* contraction precision of every modulated conv of the engine (LA_PREC_*, default LA_PREC_F32) */
 int la_synth_set_precision(la_synth* h, int precision);
-/* f16x2 only: where the power-of-two operand scale of the FORWARD contractions comes from.  0 (default): the a-priori bound
- * conv_clamp * max|style| (no pass over the data; float32-class as long as a layer's activations reach ~2^-16 of that bound
- * somewhere, i.e. O(1e-2) and up).  1: the data maxima (two short passes per layer more; no such limit). */
+/* Kept for ABI compatibility, no effect since round 4 (rounds 2-3: 0 = fp16 operand scale of the forward contractions from the a-priori
+ * bound conv_clamp * max|style|, 1 = from data maxima).  Every fp16 operand scale is now derived from the data of each pass by the
+ * kernel that produces the tensor (slot rows lowered with atomicMin, csrc/la_common.h): no bound, no calibration, nothing to select. */
 int la_synth_set_operand_scale(la_synth* h, int from_data);
 int la_synth_get_precision(const la_synth* h);
 /* ws element (b,l,j) = ws[b*ws_bstride + l*ws_lstride + j] (ws_lstride = 0: W space, one w per sample).

@@ -51,6 +51,9 @@ struct la_disc {
     void* cws; size_t cws_bytes;
     float* xs_b;            // backward slot rows [2 * nblocks][maxB][LA_XS_FAN] (la_common.h): fp16 operand scales of the gradient entering a block
                             // (lowered by the up-2 FIR that produces it) and of the masked gradient entering conv0's backward (lowered by the FIR adjoint)
+    float* xs_f;            // forward slot rows [2 * nblocks + 1][maxB][LA_XS_FAN]: the input of block k (fromrgb output / residual sum of the block
+                            // above; also bounds its FIR-down copy for the skip conv, and for k = nblocks the MinibatchStd output) and conv0's output y0
+                            // (also bounds the pre-filtered copy conv1 reads), each lowered by the kernel that produces the tensor
     float* xs_fwd;          // [maxB] constant fp16 operand scale of every FORWARD contraction input: with a clamp all of them are bounded
                             // (clamped layer outputs, residual sums <= 2 * clamp / sqrt(2), FIR outputs <= their input, |std| <= max|x|)
     int precision, lastB, mbstd_group;
@@ -126,6 +129,7 @@ static size_t d_layout(la_disc* h, void* ws) {
     h->mb = c.take(mb * (h->C4 + 1) * 16); h->yc = c.take(mb * h->C4 * 16); h->fc = c.take(mb * h->C4);
     h->xs_fwd = c.take(mb * LA_XS_FAN);
     h->xs_b = c.take((size_t)2 * DMAX_BLOCKS * mb * LA_XS_FAN);
+    h->xs_f = c.take((size_t)(2 * DMAX_BLOCKS + 1) * mb * LA_XS_FAN);
     h->logits = c.take(mb); h->dlogits = c.take(mb); h->g_fc = c.take(mb * h->C4); h->g_flat = c.take(mb * (h->C4 + 1) * 16);
     h->gA = c.take(gmax); h->gB = c.take(gmax); h->scrA = c.take(smax); h->scrB = c.take(gmax);
     h->pm = c.take(pmax);
@@ -230,10 +234,11 @@ extern "C" const float* la_disc_logits(const la_disc* h) { return h ? h->logits 
 template <int IMGC>
 __global__ __launch_bounds__(256) void la_fromrgb_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ y, int M,
-                                                            long HW, float wgain, float alpha, float gain, float clamp) {
+                                                            long HW, float wgain, float alpha, float gain, float clamp, float* __restrict__ xs_rows) {
     const int b = blockIdx.y;
     const long p4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (p4 >= HW) return;
+    float ymax = 0.f;
+    if (p4 < HW) {
     float4 x[IMGC];
 #pragma unroll
     for (int c = 0; c < IMGC; ++c) x[c] = *reinterpret_cast<const float4*>(img + ((long)b * IMGC + c) * HW + p4);
@@ -248,6 +253,16 @@ __global__ __launch_bounds__(256) void la_fromrgb_fwd_kernel(const float* __rest
         v.x = la_act_fwd(v.x + bv, LA_ACT_LRELU, alpha, gain, clamp); v.y = la_act_fwd(v.y + bv, LA_ACT_LRELU, alpha, gain, clamp);
         v.z = la_act_fwd(v.z + bv, LA_ACT_LRELU, alpha, gain, clamp); v.w = la_act_fwd(v.w + bv, LA_ACT_LRELU, alpha, gain, clamp);
         *reinterpret_cast<float4*>(y + ((long)b * M + m) * HW + p4) = v;
+        ymax = fmaxf(ymax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    }
+    if (xs_rows) {      // fp16 operand scale of y for the contractions that read it: every wave lowers a sub-slot of the sample's row (la_common.h)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+        if ((threadIdx.x & 63) == 0) {
+            float* row = xs_rows + (long)b * LA_XS_FAN + la_xs_sub((int)(threadIdx.x >> 6));
+            la_xs_lower(row, la_xs_peek(row), 1.f, ymax);
+        }
     }
 }
 
@@ -461,7 +476,7 @@ static void set_w(LaConvArgs& a, la_disc* h, const DConv& L, bool backward) {
 // dense conv (k = 3 pad 1, or k = 1) at one resolution, forward (with bias/act epilogue) or backward-data (plain)
 static int conv_same(la_disc* h, const DConv& L, bool backward, const float* in, float* out, int B, int res, int act, float gain,
                      float clamp, const float* addend, float* out2, hipStream_t stream, const float* in_pmax = nullptr, int in_nseg = 0,
-                     const float* xs_rows = nullptr, float in_gain = 1.f) {
+                     const float* xs_rows = nullptr, float in_gain = 1.f, float* xs_out = nullptr) {
     LaConvArgs a; cbase(a);
     set_w(a, h, L, backward);
     a.in = in; a.out = out; a.B = B; a.in_pmax = in_pmax; a.in_pmax_nseg = in_nseg;
@@ -478,7 +493,9 @@ static int conv_same(la_disc* h, const DConv& L, bool backward, const float* in,
     if (backward) { a.epi = LA_EPI_BWD; }
     else {
         a.epi = LA_EPI_FWD; a.bias = L.bias; a.act = act; a.alpha = 0.2f; a.gain = gain; a.clamp = clamp; a.addend = addend; a.out2 = out2;
-        if (h->precision == LA_PREC_F16X2 && h->clamp > 0.f && h->maxB <= 256) { a.acc_scale_x = h->xs_fwd; a.acc_scale_fan = LA_XS_FAN; }      // bound-based scale: no absmax pass
+        a.fwd_xs_out = xs_out;
+        // (no slot rows given: the constant a-priori scale -- every forward input of D is bounded by 4 * conv_clamp)
+        if (!xs_rows && h->precision == LA_PREC_F16X2 && h->clamp > 0.f && h->maxB <= 256) { a.acc_scale_x = h->xs_fwd; a.acc_scale_fan = LA_XS_FAN; }
     }
     return la_conv_launch(a, stream);
 }
@@ -490,36 +507,43 @@ extern "C" int la_disc_forward(la_disc* h, const float* img, int B, hipStream_t 
     LA_CHECK_ARG(B % G == 0, "disc_forward: batch must be divisible by the MinibatchStd group size (as in the reference)");
     const float sq2 = sqrtf(2.f), rs2 = sqrtf(0.5f);
     int rc;
+    // fp16 x2 mode: every contraction input's operand scale comes from the kernel that produced the tensor (slot rows, la_common.h):
+    // rows_x(k) = input of block k (k = nblocks: input of the epilogue conv), rows_y(k) = conv0's output of block k.  A FIR with taps
+    // summing to 1 (the skip path's FIR-down, conv1's pre-filter) and MinibatchStd do not raise the maximum: their outputs share the rows
+    // of their input.
+    const bool slots = h->precision == LA_PREC_F16X2 && !la_dev_env("LA_NO_DISC_FUSE");
+    if (slots) LA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->xs_f), (int)LA_XS_INIT, (size_t)(2 * h->nblocks + 1) * h->maxB * LA_XS_FAN, stream));
+    auto rows_x = [&](int k) { return slots ? h->xs_f + (size_t)k * h->maxB * LA_XS_FAN : nullptr; };
+    auto rows_y = [&](int k) { return slots ? h->xs_f + (size_t)(h->nblocks + 1 + k) * h->maxB * LA_XS_FAN : nullptr; };
     for (int k = 0; k < h->nblocks; ++k) {
         DBlock& b = h->blk[k];
         const int res = b.res, hq = res / 2;
         const long HW = (long)res * res;
         if (k == 0) {
             dim3 grid(la_cdiv(HW / 4, 256), B);
-#define FRGB(N) hipLaunchKernelGGL(la_fromrgb_fwd_kernel<N>, grid, dim3(256), 0, stream, img, b.frgb_w, b.frgb_b, b.xin, b.cin, HW, 1.0f / sqrtf((float)h->imgc), 0.2f, sq2, h->clamp)
+#define FRGB(N) hipLaunchKernelGGL(la_fromrgb_fwd_kernel<N>, grid, dim3(256), 0, stream, img, b.frgb_w, b.frgb_b, b.xin, b.cin, HW, 1.0f / sqrtf((float)h->imgc), 0.2f, sq2, h->clamp, rows_x(0))
             switch (h->imgc) { case 1: FRGB(1); break; case 2: FRGB(2); break; case 3: FRGB(3); break; default: FRGB(4); }
 #undef FRGB
             LA_CHECK_LAUNCH();
         }
         // skip: FIR (pad 1,1,1,1) + decimate 2, then 1x1 conv, linear * sqrt(1/2)      (conv2d_resample.py:94-97)
         if ((rc = la_upfirdn2d_ex(b.xin, h->scrB, B, b.cin, res, res, h->fir, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1, 0, 1.f, nullptr, stream))) return rc;
-        if ((rc = conv_same(h, b.skip, false, h->scrB, b.ysk, B, hq, LA_ACT_LINEAR, rs2, -1.f, nullptr, nullptr, stream))) return rc;
+        if ((rc = conv_same(h, b.skip, false, h->scrB, b.ysk, B, hq, LA_ACT_LINEAR, rs2, -1.f, nullptr, nullptr, stream, nullptr, 0, rows_x(k)))) return rc;
         // conv0
-        if ((rc = conv_same(h, b.conv0, false, b.xin, b.y0, B, res, LA_ACT_LRELU, sq2, h->clamp, nullptr, nullptr, stream))) return rc;
+        if ((rc = conv_same(h, b.conv0, false, b.xin, b.y0, B, res, LA_ACT_LRELU, sq2, h->clamp, nullptr, nullptr, stream, nullptr, 0, rows_x(k), 1.f, rows_y(k)))) return rc;
         // conv1: FIR pad (2,2,2,2) -> (res+1)^2, stride-2 conv, lrelu * sqrt2 * sqrt(1/2), clamp * sqrt(1/2); + skip  (:106-109)
         // fp16 x2 mode with the a-priori operand scale: the FIR writes its result ALREADY as the contraction's packed operand (scale,
         // fp16 split, channel interleave: la_fir4x4_adj_pack_kernel with the forward taps) -- one pass instead of the scalar FIR into a
         // (res+1)^2 fp32 scratch + the pre-split copy of that scratch
         const size_t qbytes = (size_t)B * la_cdiv(b.cin, 32) * 32 * (res + 1) * (res + 1) * 4;
-        const bool fir_pack = h->precision == LA_PREC_F16X2 && h->clamp > 0.f && h->maxB <= 256 && res % 4 == 0 && h->cws_bytes > qbytes + 1024 &&
-                              !la_dev_env("LA_NO_DISC_FUSE");
+        const bool fir_pack = slots && res % 4 == 0 && h->cws_bytes > qbytes + 1024;
         if (!fir_pack && (rc = la_upfirdn2d_ex(b.y0, h->scrA, B, b.cin, res, res, h->fir, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2, 0, 1.f, nullptr, stream))) return rc;
         {
             LaConvArgs a; cbase(a);
             set_w(a, h, b.conv1, false);
             if (fir_pack) {
                 unsigned* q = reinterpret_cast<unsigned*>(h->cws);
-                if ((rc = la_fir4x4_adjoint_pack_f16(b.y0, q, h->xs_fwd, LA_XS_FAN, B, b.cin, res, res, h->fir, 1.f, stream, 1))) return rc;
+                if ((rc = la_fir4x4_adjoint_pack_f16(b.y0, q, rows_y(k), LA_XS_FAN, B, b.cin, res, res, h->fir, 1.f, stream, 1))) return rc;
                 const size_t used = (qbytes + 255) & ~(size_t)255;
                 a.in_q = q; a.ws = static_cast<char*>(h->cws) + used; a.ws_bytes = h->cws_bytes - used;
             }
@@ -530,14 +554,16 @@ extern "C" int la_disc_forward(la_disc* h, const float* img, int B, hipStream_t 
             a.epi = LA_EPI_FWD; a.bias = b.conv1.bias; a.act = LA_ACT_LRELU; a.alpha = 0.2f; a.gain = sq2 * rs2;
             a.clamp = h->clamp >= 0.f ? h->clamp * rs2 : -1.f;
             a.addend = b.ysk; a.out2 = b.sum;
-            if (h->precision == LA_PREC_F16X2 && h->clamp > 0.f && h->maxB <= 256) { a.acc_scale_x = h->xs_fwd; a.acc_scale_fan = LA_XS_FAN; }
+            a.fwd_xs_out = rows_x(k + 1);      // (the residual sum out2 is what the next block reads)
+            if (slots) { a.acc_scale_x = rows_y(k); a.acc_scale_fan = LA_XS_FAN; }
+            else if (h->precision == LA_PREC_F16X2 && h->clamp > 0.f && h->maxB <= 256) { a.acc_scale_x = h->xs_fwd; a.acc_scale_fan = LA_XS_FAN; }
             if ((rc = la_conv_launch(a, stream))) return rc;
         }
     }
     const DBlock& last = h->blk[h->nblocks - 1];
     hipLaunchKernelGGL(la_mbstd_fwd_kernel, dim3(B / G), dim3(256), 0, stream, last.sum, h->mb, B, G, h->C4, 16);
     LA_CHECK_LAUNCH();
-    if ((rc = conv_same(h, h->econv, false, h->mb, h->yc, B, 4, LA_ACT_LRELU, sq2, h->clamp, nullptr, nullptr, stream))) return rc;
+    if ((rc = conv_same(h, h->econv, false, h->mb, h->yc, B, 4, LA_ACT_LRELU, sq2, h->clamp, nullptr, nullptr, stream, nullptr, 0, rows_x(h->nblocks)))) return rc;
     if ((rc = la_fc_f32(h->yc, h->fc_w, h->fc_b, h->fc, B, h->C4 * 16, h->C4, 1.f, LA_ACT_LRELU, 0.2f, sq2, stream))) return rc;
     if ((rc = la_fc_f32(h->fc, h->out_w, h->out_b, h->logits, B, h->C4, 1, 1.f, LA_ACT_LINEAR, 0.f, 1.f, stream))) return rc;
     h->lastB = B;
