@@ -249,6 +249,11 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
         for (int g = tp * VEC; g < G; g += T * VEC) {
             // (the slices' loads in flight eight at a time, added in slice order: with one load and one add per trip the pass was an
             //  exposed L2 latency per slice -- up to 16 of them at the 4x4 and 8x8 layers)
+            // (sums written element by element: a vector add is v_pk_add_f32 -- no packed-FP32 arithmetic anywhere, Makefile)
+            auto add = [](vf& s, const vf& p) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s[e] += p[e];
+            };
             vf acc = ld(wsp + g);
             int k = 1;
             for (; k + 7 < a.ksplit; k += 8) {
@@ -256,17 +261,17 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
 #pragma unroll
                 for (int u = 0; u < 8; ++u) p[u] = ld(wsp + (long)(k + u) * slice + g);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += p[u];
+                for (int u = 0; u < 8; ++u) add(acc, p[u]);
             }
             if (k + 3 < a.ksplit) {
                 vf p[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) p[u] = ld(wsp + (long)(k + u) * slice + g);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc += p[u];
+                for (int u = 0; u < 4; ++u) add(acc, p[u]);
                 k += 4;
             }
-            for (; k < a.ksplit; ++k) acc += ld(wsp + (long)k * slice + g);
+            for (; k < a.ksplit; ++k) { const vf p = ld(wsp + (long)k * slice + g); add(acc, p); }
             const int gy = g / a.Gx, gx = g - gy * a.Gx;
             const long pos = (long)(gy * a.out_sy + a.out_oy) * wpitch + gx * a.out_sx + a.out_ox;
             float v[VEC];
@@ -274,9 +279,9 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
             for (int e = 0; e < VEC; ++e) v[e] = VEC == 1 ? acc[0] : acc[e];
             if (a.epi == LA_EPI_FWD) {
                 vf nz = 0.f;
-                if (a.noise) nz = ld(a.noise + (long)b * a.noise_bstride + pos) * a.noise_strength;
+                if (a.noise) nz = ld(a.noise + (long)b * a.noise_bstride + pos);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] = la_conv_epi_fwd(a, v[e], dmv, nz[e], bv);
+                for (int e = 0; e < VEC; ++e) v[e] = la_conv_epi_fwd(a, v[e], dmv, nz[e] * a.noise_strength, bv);
                 if (a.out2) {
                     const long o2 = ((long)b * a.M + m) * HWout + pos;
                     vf ad = 0.f;
@@ -306,7 +311,11 @@ __global__ __launch_bounds__(256) void la_conv_splitk_finish_kernel(LaConvArgs a
                         }
                     }
                 }
-                if (seam && a.seam_noise) nz0 = ld(a.seam_noise + (long)b * a.seam_noise_bstride + pos) * a.seam_noise_strength;
+                if (seam && a.seam_noise) {
+                    nz0 = ld(a.seam_noise + (long)b * a.seam_noise_bstride + pos);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) nz0[e] *= a.seam_noise_strength;
+                }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     part += v[e] * y[e];

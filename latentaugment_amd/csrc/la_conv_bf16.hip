@@ -1136,7 +1136,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
             const float4 f = *reinterpret_cast<const float4*>(scl + sl.c0);
-            f32x2 v0 = {sl.x[0] * f.x, sl.x[1] * f.y}, v1 = {sl.x[2] * f.z, sl.x[3] * f.w};
+            // (scalar fp32 arithmetic, only the conversions are packed: no v_pk_*_f32, Makefile)
+            float p[4] = {sl.x[0] * f.x, sl.x[1] * f.y, sl.x[2] * f.z, sl.x[3] * f.w};
             if constexpr (ABL) {
                 const uint2 w = make_uint2(__builtin_bit_cast(unsigned, sl.x[0]), __builtin_bit_cast(unsigned, sl.x[2]));
                 *reinterpret_cast<uint2*>(buf + sl.wr) = w;
@@ -1147,13 +1148,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             for (int q = 0; q < NTERM; ++q) {
                 uint2 w;
                 if constexpr (F16) {
-                    const f16x2 h0 = __builtin_convertvector(v0, f16x2), h1 = __builtin_convertvector(v1, f16x2);
+                    const f16x2 h0 = __builtin_convertvector(f32x2{p[0], p[1]}, f16x2), h1 = __builtin_convertvector(f32x2{p[2], p[3]}, f16x2);
                     w = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
-                    if (q + 1 < NTERM) { v0 -= __builtin_convertvector(h0, f32x2); v1 -= __builtin_convertvector(h1, f32x2); }
+                    if (q + 1 < NTERM) { p[0] -= (float)h0[0]; p[1] -= (float)h0[1]; p[2] -= (float)h1[0]; p[3] -= (float)h1[1]; }
                 } else {
-                    const bf16x2_t h0 = __builtin_convertvector(v0, bf16x2_t), h1 = __builtin_convertvector(v1, bf16x2_t);
+                    const bf16x2_t h0 = __builtin_convertvector(f32x2{p[0], p[1]}, bf16x2_t), h1 = __builtin_convertvector(f32x2{p[2], p[3]}, bf16x2_t);
                     w = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
-                    if (q + 1 < NTERM) { v0 -= __builtin_convertvector(h0, f32x2); v1 -= __builtin_convertvector(h1, f32x2); }
+                    if (q + 1 < NTERM) { p[0] -= (float)h0[0]; p[1] -= (float)h0[1]; p[2] -= (float)h1[0]; p[3] -= (float)h1[1]; }
                 }
                 *reinterpret_cast<uint2*>(buf + q * HPLANE + sl.wr) = sl.ok ? w : make_uint2(0u, 0u);
             }
@@ -1425,7 +1426,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
                 for (int n4 = 0; n4 < 4; ++n4) {
                     const int n = hf * 4 + n4;
                     const int px = (n4 >> 1) * 32 + (n & 1) * 16 + c16;
-                    *reinterpret_cast<f32x4*>(tb + px * 36 + mi * 16 + kq * 4) = acc16[mi][n] * inv;
+                    // (element by element: a vector multiply here is two v_pk_mul_f32 -- no packed-FP32 arithmetic anywhere, Makefile)
+                    const f32x4 v = acc16[mi][n];
+                    *reinterpret_cast<f32x4*>(tb + px * 36 + mi * 16 + kq * 4) = f32x4{v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv};
                 }
             __syncthreads();
 #pragma unroll

@@ -208,8 +208,22 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_kernel(const float* __restri
     float4 acc[IMGC];
 #pragma unroll
     for (int c = 0; c < IMGC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-    for (int i = 0; i < C; ++i) {
+    // (eight channels' 16-byte loads in flight per thread, accumulated in channel order: the kernel is a plain stream of x -- with one
+    //  load per trip of a short unrolled loop the scheduler left most of the latency exposed once the packed-FP32 forms were gone)
+    int i = 0;
+    for (; i + 7 < C; i += 8) {
+        float4 xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = *reinterpret_cast<const float4*>(xb + (long)(i + u) * HW);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < IMGC; ++c) {
+                const float wv = weff[c * C + i + u];
+                acc[c].x += wv * xv[u].x; acc[c].y += wv * xv[u].y; acc[c].z += wv * xv[u].z; acc[c].w += wv * xv[u].w;
+            }
+    }
+    for (; i < C; ++i) {
         const float4 xv = *reinterpret_cast<const float4*>(xb + (long)i * HW);
 #pragma unroll
         for (int c = 0; c < IMGC; ++c) {
@@ -262,8 +276,20 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_small_kernel(const float* __
 #pragma unroll
     for (int c = 0; c < IMGC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p4 < HW) {
-#pragma unroll 8
-        for (int i = i0; i < i1; ++i) {
+        int i = i0;
+        for (; i + 7 < i1; i += 8) {      // (eight loads in flight, summed in channel order)
+            float4 xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = *reinterpret_cast<const float4*>(xb + (long)(i + u) * HW);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < IMGC; ++c) {
+                    const float wv = weff[c * C + i + u];
+                    acc[c].x += wv * xv[u].x; acc[c].y += wv * xv[u].y; acc[c].z += wv * xv[u].z; acc[c].w += wv * xv[u].w;
+                }
+        }
+        for (; i < i1; ++i) {
             const float4 xv = *reinterpret_cast<const float4*>(xb + (long)i * HW);
 #pragma unroll
             for (int c = 0; c < IMGC; ++c) {

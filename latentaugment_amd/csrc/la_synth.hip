@@ -298,6 +298,10 @@ extern "C" int la_synth_set_operand_scale(la_synth* h, int from_data) {
     return LA_OK;
 }
 
+#ifdef LA_DEV
+// development build: the transposed-conv intermediate of the LAST up-sampling layer that ran (column-planar rows; scripts/exp_overlap_*.py)
+extern "C" const float* la_synth_dev_zt(const la_synth* h) { return h ? h->zT : nullptr; }
+#endif
 extern "C" const float* la_synth_image(const la_synth* h) { return h ? h->final_img : nullptr; }
 extern "C" const float* la_synth_block_image(const la_synth* h, int k) { return (h && k >= 0 && k < h->nblocks) ? h->rgb[k].img : nullptr; }
 extern "C" const float* la_synth_layer_output(const la_synth* h, int k) { return (h && k >= 0 && k < h->nconv) ? h->conv[k].y : nullptr; }

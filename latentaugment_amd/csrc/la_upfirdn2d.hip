@@ -2,6 +2,7 @@
 // Semantics follow models/stylegan3/torch_utils/ops/upfirdn2d.py:167-211 (ref) / upfirdn2d.cu:29-92.
 // HBM-bound: each output reads <= ceil(fh/up)*ceil(fw/up) inputs (L1/L2 hits), one coalesced store.
 #include "la_upfirdn2d.h"
+#include <stdlib.h>
 
 #define FIR_MAX 8
 
@@ -455,7 +456,8 @@ static int fir_launch_inner(const FirArgs& a, hipStream_t stream) {
                          (((size_t)a.in | (size_t)a.out | (size_t)a.noise | (size_t)a.addend) & 15) == 0 && fir_separable(a.f, fx, fy),
                      "upfirdn2d: column-planar input needs the 4x4 pad-1 separable FIR on aligned planes (W % 4 == 0, no plane maxima)");
         // rows per thread: 16 where that still leaves every SIMD >= 4 waves' worth of threads, else 4 (short serial chains on small planes)
-        const int rows = (long)a.P * (a.Wout / 4) * la_cdiv(a.Hout, 16) >= 256l * 4 * 4 * 64 ? 16 : 4;
+        int rows = (long)a.P * (a.Wout / 4) * la_cdiv(a.Hout, 16) >= 256l * 4 * 4 * 64 ? 16 : 4;
+        if (const char* e = la_dev_env("LA_FIR_ROWS")) rows = atoi(e) == 16 ? 16 : 4;      // (dev knob)
         const long items = (long)a.P * (a.Wout / 4) * la_cdiv(a.Hout, rows);
         LA_CHECK_ARG(items < (1l << 38), "upfirdn2d: too many planes");
         dim3 g((unsigned)((items + 255) / 256));

@@ -47,6 +47,33 @@ def test_product_library_has_no_development_switches(lib):
     assert 'os.environ' not in src      # the loader takes no path from the environment
 
 
+def test_no_packed_fp32_arithmetic_in_any_kernel(lib, tmp_path):
+    """Round 4 traced the 'two streams disturb each other' non-reproducibility of rounds 2-3 to packed-FP32 arithmetic (v_pk_fma_f32 /
+    v_pk_mul_f32 / v_pk_add_f32, emitted by the SLP vectoriser and by vector-typed float expressions): while kernels of another
+    hardware queue run on the chip, the high half of such a result comes out wrong for 16-lane groups.  The library is
+    therefore built without them: every gfx950 code object embedded in the product .so is disassembled here and must contain none."""
+    import subprocess
+    from latentaugment_amd import _lib
+    bundler, objdump = '/opt/rocm/lib/llvm/bin/clang-offload-bundler', '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not (os.path.isfile(bundler) and os.path.isfile(objdump)):
+        pytest.skip('LLVM tools of the ROCm image not found')
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    starts = [m.start() for m in re.finditer(b'__CLANG_OFFLOAD_BUNDLE__', blob)]
+    assert len(starts) >= 8
+    kernels = mfma = 0
+    for i, p in enumerate(starts):
+        src, obj = tmp_path / f'b{i}.bin', tmp_path / f'c{i}.o'
+        src.write_bytes(blob[p:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        r = subprocess.run([bundler, '--type=o', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', f'--input={src}', f'--output={obj}', '--unbundle'],
+                           capture_output=True)
+        assert r.returncode == 0 and obj.stat().st_size > 0, r.stderr.decode()[-500:]
+        dis = subprocess.run([objdump, '-d', str(obj)], capture_output=True).stdout.decode(errors='replace')
+        bad = re.findall(r'v_pk_(?:fma|mul|add)_f32', dis)
+        assert not bad, f'code object {i}: {len(bad)} packed-FP32 instructions'
+        kernels += len(re.findall(r's_endpgm', dis)); mfma += len(re.findall(r'v_mfma_', dis))
+    assert kernels > 100 and mfma > 500      # (the disassembly really covered the kernels)
+
+
 def test_pure_host_entry_points(lib):
     assert lib.la_synth_num_ws(256) == 14 and lib.la_synth_num_ws(512) == 16 and lib.la_synth_num_ws(1024) == 18
     assert lib.la_synth_num_params(4) == 10 and lib.la_synth_num_params(256) == 94
