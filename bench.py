@@ -87,6 +87,7 @@ def parse():
                    help="B: BASELINE.json configs[1] (the metric's config). E: configs[4] per-GPU shape -- config-e 256^2, all four "
                         "criteria at the authors' weights (w_lpips 10, w_pix 0.1, w_latent 0.001, w_disc 0.01), Pelvis-scale banks")
     p.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured step')
+    p.add_argument('--no-overlap', action='store_true', help='discriminator and perceptual criterion one after the other instead of side by side')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true', help='skip the HIP-event leg (used under rocprofv3)')
     p.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
@@ -116,7 +117,7 @@ def make_opt(args, local_rank, global_batch):
         truncation_psi=1.0, w_pix=args.w_pix, w_lpips=args.w_lpips, w_latent=args.w_latent, w_disc=args.w_disc, crop_size_aug=64,
         preprocess_aug='center_random_crop', soft_aug=False, alpha=1.0, verbose_log=False, rand_aug=False,
         lower_bound_clip=False, p_thres=0.0, init_w='inv', final_noise_mode='random',
-        precision=args.precision, hip_graph=not args.no_graph)
+        precision=args.precision, hip_graph=not args.no_graph, overlap_criteria=not args.no_overlap)
 
 
 def cpu_model():

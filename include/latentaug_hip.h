@@ -295,6 +295,11 @@ int la_latent_opt_set_trace(la_latent_opt* h, float* w_trace, float* img_trace);
 /* dw_trace [steps][B][w_dim] (device, or NULL) = dL/dw of every step, L = -latent - pix - lpips + disc (util_latent_aug.py:270):
  * the tensor `loss.backward()` leaves in w_opt.grad (:275) before Adam consumes it.  While set the loop launches eagerly. */
 int la_latent_opt_set_grad_trace(la_latent_opt* h, float* dw_trace);
+/* 1 (default): with both the discriminator and the perceptual criterion active, the two run side by side inside a step -- the
+ * discriminator branch on the launch stream, crop + feature net forward / backward on a stream of the handle's own, forked after the
+ * synthesis forward and joined before the crop gradient is added to the image gradient (two parallel branches of the captured step).
+ * 0: one after the other.  Bit-identical results either way (same launches, same accumulation order).  Drops a captured step. */
+int la_latent_opt_set_overlap(la_latent_opt* h, int enable);
 /* verbose_log timers of the reference's first batch (time_latent / time_disc / time_pix / time_lpips / time_epoch,
  * util_latent_aug.py:221-272): with the time trace on, a run that asks for the loss scalars brackets the criteria of every step with
  * HIP events on the launch stream; la_latent_opt_get_times (after the stream has drained, or blocking) fills ms [steps][5] =

@@ -111,6 +111,7 @@ SIGNATURES = {
     'la_latent_opt_graph_state': (_I, [_P]),
     'la_latent_opt_set_trace': (_I, [_P, _P, _P]),
     'la_latent_opt_set_grad_trace': (_I, [_P, _P]),
+    'la_latent_opt_set_overlap': (_I, [_P, _I]),
     'la_latent_opt_set_time_trace': (_I, [_P, _I]),
     'la_latent_opt_get_times': (_I, [_P, _P]),
     'la_latent_opt_set_lpips_preproc': (_I, [_P, _P, _P, _I]),

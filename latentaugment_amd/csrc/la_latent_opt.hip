@@ -43,6 +43,13 @@ struct la_latent_opt {
     hipStream_t cap_stream; // capture needs a non-default stream; the replay goes to the caller's stream
     float* trace_w;         // optional [steps][B][w_dim]: the latent after every step (verbose_log snapshots); forces eager launches
     float* trace_img;       // optional [steps][B][C][R][R]: the image synthesised in every step
+    // Independent image criteria side by side (round 4): the discriminator branch on the launch stream, the perceptual branch (crop,
+    // feature net forward + backward) on a side stream, forked after the synthesis forward and joined before the crop gradient is
+    // added into g_img -- same arithmetic, same summation order, captured into the step's graph as two parallel branches.  Possible
+    // since no kernel of the library contains packed-FP32 arithmetic ('Two streams').
+    int overlap;            // 1 (default): fork / join when both criteria are active and no loss scalars / traces are asked for
+    hipStream_t side_stream;
+    hipEvent_t ev_fork, ev_join;
     // optional per-criterion times of the verbose_log batch (la_latent_opt_set_time_trace): LA_TEV events per step on the launch stream
     int time_trace, tev_steps;
     hipEvent_t* tev;
@@ -101,6 +108,7 @@ extern "C" int la_latent_opt_create(la_synth* g, int img_resolution, int img_cha
     if (!h->adam_tab_host) { free(h); la_set_error("latent_opt_create: out of host memory"); return LA_ERR_ARG; }
     la_adam_fill_table(h->adam_tab_host, cfg->steps, cfg->beta1, cfg->beta2);
     h->graph_mode = 1;
+    h->overlap = 1;
     *out = h;
     return LA_OK;
 }
@@ -115,9 +123,21 @@ extern "C" void la_latent_opt_destroy(la_latent_opt* h) {
     if (!h) return;
     drop_graph(h);
     if (h->tev) { for (int i = 0; i < h->tev_steps * LA_TEV; ++i) (void)hipEventDestroy(h->tev[i]); free(h->tev); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     free(h->adam_tab_host);
     free(h);
+}
+
+// 1 (default): the discriminator and the perceptual criterion of a step run side by side (two branches of the step); 0: one after the other.
+// Results are bit-identical either way (same launches, same accumulation order into the image gradient).
+extern "C" int la_latent_opt_set_overlap(la_latent_opt* h, int enable) {
+    LA_CHECK_ARG(h, "latent_opt_set_overlap: null handle");
+    h->overlap = enable ? 1 : 0;
+    drop_graph(h);
+    return LA_OK;
 }
 
 // 1 (default): steps 2..N of the first batch and every step of later batches replay ONE captured step; 0: every launch eager
@@ -295,6 +315,11 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     LA_CHECK_ARG(!use_disc || h->d, "latent_opt_run: w_disc != 0 but no discriminator attached (la_latent_opt_set_disc)");
     const bool use_lpips = c.w_lpips != 0.f;
     LA_CHECK_ARG(!use_lpips || h->f, "latent_opt_run: w_lpips != 0 but no feature engine attached (la_latent_opt_set_lpips)");
+    if (use_disc && use_lpips && h->overlap && !h->side_stream) {      // once per handle: the side stream and the fork / join events
+        LA_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        LA_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        LA_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
     LA_CHECK_ARG(!use_lpips || (h->crop_x + h->S <= h->R && h->crop_y + h->S <= h->R), "latent_opt_run: LPIPS crop outside the image");
     const bool img_crit = c.w_pix != 0.f || use_disc || use_lpips;
     const float lp_coef = use_lpips ? c.w_lpips / ((float)h->imgc * (float)h->Mf * nb) : 0.f;
@@ -347,6 +372,14 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
                 (rc = la_pix_grad(img, h->colsumX, h->g_img, B, h->imgc, h->R, cc, off, -2.f * pix_coef, (float)h->Mx, st)))
                 return rc;
             mark(3);
+            // fork: the perceptual branch needs the image only -- it runs on the side stream beside the discriminator branch (the
+            // launch profiler, the loss scalars and the traces keep everything on one stream)
+            const bool fork = h->overlap && use_disc && use_lpips && !L && !tev && !la_prof_enabled() && h->side_stream && h->ev_fork && h->ev_join;
+            hipStream_t sl = fork ? h->side_stream : st;      // stream of the perceptual branch
+            if (fork) {
+                LA_HIP(hipEventRecord(h->ev_fork, st));
+                LA_HIP(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+            }
             if (use_disc) {
                 // loss_disc = softplus(-D(x)).mean() * w_disc enters the total with a plus sign (:270)
                 if ((rc = la_disc_forward(h->d, img, B, st))) return rc;
@@ -359,8 +392,8 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
                 const int N = h->imgc * B;
                 const long FF = h->F;
                 if (c.w_pix == 0.f && !use_disc) LA_HIP(hipMemsetAsync(h->g_img, 0, sizeof(float) * (size_t)B * h->imgc * h->R * h->R, st));
-                if ((rc = la_crop_repeat_ex3(img, h->l_xc, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, h->crop_dev, 3, h->pre_scale, h->pre_shift, st))) return rc;
-                if ((rc = la_feat_forward(h->f, h->l_xc, N, h->l_feat, st))) return rc;
+                if ((rc = la_crop_repeat_ex3(img, h->l_xc, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, h->crop_dev, 3, h->pre_scale, h->pre_shift, sl))) return rc;
+                if ((rc = la_feat_forward(h->f, h->l_xc, N, h->l_feat, sl))) return rc;
                 if (L) {
                     for (int ch = 0; ch < h->imgc; ++ch)
                         if ((rc = la_l2_mean_from_bank(h->bankF + (long)ch * h->Mf * FF, h->Mf, FF, h->l_feat + (long)ch * B * FF, B, FF, 0,
@@ -368,9 +401,13 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
                             return rc;
                 }
                 const long total = (long)N * FF;
-                hipLaunchKernelGGL(la_lpips_gfeat_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, st, h->l_feat, h->l_colsum, h->l_gfeat,
+                hipLaunchKernelGGL(la_lpips_gfeat_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, sl, h->l_feat, h->l_colsum, h->l_gfeat,
                                    B, (int)FF, -2.f * lp_coef, (float)h->Mf, total);
-                if ((rc = la_feat_backward(h->f, h->l_gfeat, h->l_gxc, st))) return rc;
+                if ((rc = la_feat_backward(h->f, h->l_gfeat, h->l_gxc, sl))) return rc;
+                if (fork) {      // join: the crop gradient is added into g_img on the launch stream, after the discriminator's
+                    LA_HIP(hipEventRecord(h->ev_join, h->side_stream));
+                    LA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+                }
                 if ((rc = la_crop_repeat_grad_ex3(h->l_gxc, h->g_img, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, h->crop_dev, 3, h->pre_scale, st)))
                     return rc;
             }

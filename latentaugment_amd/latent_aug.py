@@ -307,6 +307,10 @@ class LatentAug:
         # launch mode of the step loop: one captured step replayed (default) or every launch eager (`opt.hip_graph = False`)
         self.hip_graph = bool(getattr(opt, 'hip_graph', True))
         _lib.check(lib.la_latent_opt_set_graph(h, int(self.hip_graph)), 'la_latent_opt_set_graph')
+        # independent image criteria (discriminator, perceptual) side by side inside a step (default) or one after the other
+        # (`opt.overlap_criteria = False`): bit-identical results, la_latent_opt_set_overlap
+        self.overlap_criteria = bool(getattr(opt, 'overlap_criteria', True))
+        _lib.check(lib.la_latent_opt_set_overlap(h, int(self.overlap_criteria)), 'la_latent_opt_set_overlap')
         self.disc = None
         if self.w_disc > 0:
             if discriminator is None:
