@@ -87,6 +87,11 @@ def parse():
                    help="B: BASELINE.json configs[1] (the metric's config). E: configs[4] per-GPU shape -- config-e 256^2, all four "
                         "criteria at the authors' weights (w_lpips 10, w_pix 0.1, w_latent 0.001, w_disc 0.01), Pelvis-scale banks")
     p.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured step')
+    p.add_argument('--lanes', default='auto', choices=['auto', '1', '2'],
+                   help="stream lanes: a full local batch as two interleaved half-batch loops on two HIP streams ('auto': when the batch is >= 8 and "
+                        "the perceptual criterion is off; 1: never; 2: whenever the batch allows it)")
+    p.add_argument('--lanes-serial', action='store_true',
+                   help='profiling aid: the two stream lanes one after the other on one stream (same launches, each alone on the chip)')
     p.add_argument('--no-overlap', action='store_true', help='discriminator and perceptual criterion one after the other instead of side by side')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true', help='skip the HIP-event leg (used under rocprofv3)')
@@ -117,7 +122,8 @@ def make_opt(args, local_rank, global_batch):
         truncation_psi=1.0, w_pix=args.w_pix, w_lpips=args.w_lpips, w_latent=args.w_latent, w_disc=args.w_disc, crop_size_aug=64,
         preprocess_aug='center_random_crop', soft_aug=False, alpha=1.0, verbose_log=False, rand_aug=False,
         lower_bound_clip=False, p_thres=0.0, init_w='inv', final_noise_mode='random',
-        precision=args.precision, hip_graph=not args.no_graph, overlap_criteria=not args.no_overlap)
+        precision=args.precision, hip_graph=not args.no_graph, overlap_criteria=not args.no_overlap,
+        stream_lanes=args.lanes if args.lanes == 'auto' else int(args.lanes))
 
 
 def cpu_model():
@@ -175,16 +181,36 @@ def cpu_baseline(sd, meta, args):
     return out
 
 
-def roofline_leg(lib, _lib, args, one_step, elapsed_per_step):
-    """HIP events around every launch of one extra batch (eager launches of the same kernels), per kernel class."""
+def bracketed_batch(lib, _lib, one_step):
+    """One extra batch with HIP events around every launch (eager launches of the same kernels): per-class sums, or None."""
     _lib.check(lib.la_prof_set_stride(1), 'la_prof_set_stride')
     _lib.check(lib.la_prof_begin(), 'la_prof_begin')
-    one_step()
+    la = one_step.aug.latent_aug
+    keep = la.lanes_concurrent
+    la.lanes_concurrent = False      # stream lanes one after the other: a bracket must see its launch alone on the chip
+    try:
+        one_step()
+    finally:
+        la.lanes_concurrent = keep
     n = lib.la_prof_num_classes()
     ms, cnt, fl, by = (C.c_double * n)(), (C.c_long * n)(), (C.c_double * n)(), (C.c_double * n)()
     rc = lib.la_prof_end_classes(ms, cnt, fl, by, n)
-    if rc != 0:
+    return None if rc != 0 else (n, ms, cnt, fl, by)
+
+
+def torch_sync():
+    import torch
+    torch.cuda.synchronize()
+
+
+def roofline_leg(lib, _lib, args, one_step, elapsed_per_step):
+    """HIP events around every launch of one extra batch (eager launches of the same kernels), per kernel class."""
+    got = bracketed_batch(lib, _lib, one_step)
+    if got is None:
         return None
+    n, ms, cnt, fl, by = got
+    la = one_step.aug.latent_aug
+    lanes = la.lanes_active
     cm = CONTRACTION[args.precision]
     per = {}
     for i, name in enumerate(CLASSES[:n]):
@@ -217,8 +243,34 @@ def roofline_leg(lib, _lib, args, one_step, elapsed_per_step):
                                  'ms_per_batch': conv_ms},
             'bracketed_ms_per_batch': tot_ms, 'timed_ms_per_batch': elapsed_per_step,
             'measured': 'HIP events around every launch of one extra batch right after the timed region (launched eagerly; the timed '
-                        'region replays the same launches from a captured hipGraph)',
+                        'region replays the same launches from a captured hipGraph)' +
+                        (' -- the two stream lanes (half-batch loops) of the timed region one after the other here, so that every bracket sees '
+                         'its launch alone on the chip: launches are half-batch launches, and bracketed_ms_per_batch exceeds '
+                         'timed_ms_per_batch by what the lanes gain from running side by side' if lanes else ''),
+            'stream_lanes': 2 if lanes else 1,
             'classes': per, 'hbm_peak_gbs': HBM_PEAK_GBS}
+    if lanes:
+        # the same batch through the single loop (full-batch launches, what rounds 1-3 report): the kernel on its own terms, next to the
+        # half-batch launches the timed region really makes
+        mode = la.stream_lanes
+        la.stream_lanes = 1
+        try:
+            one_step()      # (first use of the single loop's handles: packing, capture)
+            torch_sync()
+            got1 = bracketed_batch(lib, _lib, one_step)
+        finally:
+            la.stream_lanes = mode
+        if got1 is not None:
+            n1, ms1, cnt1, fl1, _ = got1
+            i = CLASSES.index(dom)
+            conv1 = [j for j, k in enumerate(CLASSES[:n1]) if k.startswith('conv') and cnt1[j]]
+            cms, cfl = sum(ms1[j] for j in conv1), sum(fl1[j] for j in conv1)
+            roof['single_loop'] = {
+                'note': 'the same batch through ONE loop (--lanes 1): full-batch launches, each alone on the chip',
+                'avg_launch_ms': ms1[i] / cnt1[i], 'launches_per_batch': int(cnt1[i]), 'algorithmic_flops_per_launch': fl1[i] / cnt1[i],
+                'achieved': fl1[i] / (ms1[i] * 1e-3) / 1e12, 'frac': fl1[i] / (ms1[i] * 1e-3) / 1e12 / cm['peak'],
+                'all_contractions': {'achieved': cfl / (cms * 1e-3) / 1e12, 'frac': cfl / (cms * 1e-3) / 1e12 / cm['peak'], 'ms_per_batch': cms},
+                'bracketed_ms_per_batch': sum(ms1[j] for j in range(n1))}
     # whole-pass HBM view: SURVEY 8(d) algorithmic bytes of the G pass per batch over the timed time per batch
     if args.preset == 'B' and args.res == 256 and args.channel_base == 32768 and args.w_disc == 0:
         alg = (args.batch * (args.latent_steps * 700.2e6 + 274.6e6) + (2 * args.latent_steps + 1) * 94e6)
@@ -344,6 +396,9 @@ def main():
         out = aug.get_output()
         host_s[0] += (t_b - t_a) + (time.time() - t_c)      # set_input + get_output (device -> host copy of the whole gathered batch)
         return out
+    one_step.aug = aug
+    if args.lanes_serial:
+        aug.latent_aug.lanes_concurrent = False
 
     def barrier():
         if use_dist:
@@ -405,7 +460,8 @@ def main():
                                f"reference's pairwise-L2 GEMM over the banks runs only when loss scalars are requested: the API returns none), "
                                f'contraction={args.precision}' + (', fp16 operand scales from the data of every pass (lowered by the producing kernels)' if args.precision == 'f16x2' else '') + ', '
                                f'timed call = set_input + LatentAugment.forward + get_output, '
-                               'launch mode = ' + LAUNCH_MODES[aug.latent_aug.graph_state],
+                               'launch mode = ' + LAUNCH_MODES[aug.latent_aug.graph_state] +
+                               (', two stream lanes (samples 0,2,4,.. and 1,3,5,.. as two half-batch loops on two HIP streams)' if aug.latent_aug.lanes_active else ''),
                    'global_batch': gb, 'parallelism': f'dp{world}'},
     }
     if multi is not None:

@@ -171,7 +171,7 @@ class InMemoryLatentCodes:
 
 class LatentAug:
     def __init__(self, phase, opt, save_dir, gpu_ids, generator=None, discriminator=None, banks=None, latent_codes=None,
-                 feature_net=None, group=None):
+                 feature_net=None, group=None, _shared=None):
         self.save_dir = save_dir
         self.phase = phase
         self.group = group
@@ -266,6 +266,8 @@ class LatentAug:
                                         modalities=self.modalities, resolution=self.res)
                 banks['X'] = formats.compute_stats(ds, 'img', cache_dir, step=opt.step_img).get_all_torch()
         banks = banks or {}
+        if _shared is not None:      # a stream lane of another LatentAug (build_lanes): the parent's device-resident banks, not copies
+            banks = dict(_shared['banks'])
         lib = _lib.load()
         self._lib = lib
         crop, off = center_crop_geometry(self.res)
@@ -277,7 +279,10 @@ class LatentAug:
             W = banks['W'].to(device=self.device, dtype=torch.float32).contiguous()
             assert W.shape[1:] == (self.num_ws, self.w_dim)
             self.W, Mw = W, W.shape[0]
-        if self.w_pix > 0:
+        if self.w_pix > 0 and _shared is not None:
+            self.Xc = _shared['Xc']
+            Mx = self.Xc.shape[1]
+        elif self.w_pix > 0:
             X = banks['X'].to(device=self.device, dtype=torch.float32).contiguous()     # [M, C, R, R] in [-1, 1]
             assert X.shape[1:] == (len(self.modalities), self.res, self.res)
             Mx = X.shape[0]
@@ -293,7 +298,7 @@ class LatentAug:
                              criterion_mode={'gemm': 0, 'collapsed': 1}[self.criterion_mode],
                              soft_aug=int(self.soft_aug), alpha=float(self.alpha), loop_noise_mode=1,
                              final_noise_mode={'none': 0, 'const': 1, 'random': 2}[self.final_noise_mode],
-                             norm_batch=0, crop=crop, crop_off=off)
+                             norm_batch=int(getattr(opt, 'norm_batch', 0) or 0), crop=crop, crop_off=off)
         self._cfg = cfg
         nbytes = lib.la_latent_opt_workspace_bytes(self.res, self.engine.img_channels, self.w_dim, C.byref(cfg), Mw, Mx,
                                                    max_local)
@@ -304,6 +309,18 @@ class LatentAug:
                                             _lib.ptr(self._workspace), self._workspace.numel(), C.byref(h)),
                    'la_latent_opt_create')
         self._h = h
+        self._max_local = max_local
+        self._opt, self._discriminator, self._feature_net = opt, discriminator, feature_net
+        # stream lanes: a full local batch as two interleaved half-batch loops on two HIP streams, each with its own loop /
+        # synthesis / discriminator handles.  `opt.stream_lanes`: 'auto' (default: two lanes for a full batch of >= 8 samples when the
+        # perceptual criterion is off -- with it on, the discriminator and the perceptual branch already run side by side inside ONE
+        # loop, which measures faster), 1 (never) or 2 (whenever the batch allows it).
+        self.stream_lanes = getattr(opt, 'stream_lanes', 'auto')
+        assert self.stream_lanes in ('auto', 1, 2), "opt.stream_lanes: 'auto', 1 or 2"
+        self._lanes = None
+        self._lane_stream = None
+        self.lanes_active = False           # the last batch went through the lanes
+        self.lanes_concurrent = True        # False: the lanes one after the other on one stream (bench.py's per-launch brackets)
         # launch mode of the step loop: one captured step replayed (default) or every launch eager (`opt.hip_graph = False`)
         self.hip_graph = bool(getattr(opt, 'hip_graph', True))
         _lib.check(lib.la_latent_opt_set_graph(h, int(self.hip_graph)), 'la_latent_opt_set_graph')
@@ -339,7 +356,10 @@ class LatentAug:
                 banks['fea'] = self._build_feature_banks(opt)
             fea = banks['fea']
             assert len(fea) == imgc
-            self.Fbank = torch.stack([t.to(device=self.device, dtype=torch.float32) for t in fea]).contiguous()   # [C][Mf][F]
+            if _shared is not None and _shared.get('Fbank') is not None:
+                self.Fbank = _shared['Fbank']
+            else:
+                self.Fbank = torch.stack([t.to(device=self.device, dtype=torch.float32) for t in fea]).contiguous()   # [C][Mf][F]
             assert self.Fbank.shape[2] == self.feat.num_features, 'feature bank does not match the feature net'
             Mf = self.Fbank.shape[1]
             scale, shift = _preproc3(getattr(opt, 'lpips_preproc', (1.0, 0.0)))
@@ -407,8 +427,9 @@ class LatentAug:
         off = self.center_off if self.preprocess in ('center_crop', 'center_random_crop') else 0
         return off + int(x1), off + int(y1)
 
-    def run_local(self, w, final_noises=None, want_losses=False, crop_pos=None, trace=None):
+    def run_local(self, w, final_noises=None, want_losses=False, crop_pos=None, trace=None, out=None):
         """w [b,1,w_dim] on this device -> (img [b,C,R,R], w_aug [b,num_ws,w_dim], losses or None).
+        out (optional): (img, w_aug) tensors to fill instead of allocating them on the current stream.
         trace (optional): dict that receives the per-step snapshots 'w' [steps,b,w_dim] (latent after the step) and 'img'
         [steps,b,C,R,R]; trace['want'] (default ('w', 'img')) selects them, and may name 'grad' [steps,b,w_dim] = dL/dw."""
         if self.feat is not None:
@@ -420,8 +441,13 @@ class LatentAug:
         w = w.to(device=self.device, dtype=torch.float32).contiguous()
         b = w.shape[0]
         assert w.ndim == 3 and w.shape[1:] == (1, self.w_dim)
-        img = torch.empty([b, self.engine.img_channels, self.res, self.res], device=self.device, dtype=torch.float32)
-        w_aug = torch.empty([b, self.num_ws, self.w_dim], device=self.device, dtype=torch.float32)
+        if out is not None:
+            img, w_aug = out
+            assert img.shape == (b, self.engine.img_channels, self.res, self.res) and w_aug.shape == (b, self.num_ws, self.w_dim)
+            assert img.is_contiguous() and w_aug.is_contiguous() and img.dtype == w_aug.dtype == torch.float32
+        else:
+            img = torch.empty([b, self.engine.img_channels, self.res, self.res], device=self.device, dtype=torch.float32)
+            w_aug = torch.empty([b, self.num_ws, self.w_dim], device=self.device, dtype=torch.float32)
         losses = torch.zeros([max(self.num_epochs, 1), 4], device=self.device) if want_losses else None
         fn = None
         if self._cfg.final_noise_mode == 2:
@@ -455,6 +481,74 @@ class LatentAug:
                 trace['grad'] = tg
         self._keep = final_noises
         return img, w_aug, losses
+
+    # ---- stream lanes: the local batch as two interleaved half-batch loops on two HIP streams
+    def lanes_eligible(self, b):
+        """Two lanes need the FULL local batch (the criteria's 1/(m*n) is fixed per handle), an even one, and -- with the discriminator --
+        a multiple of 8: MinibatchStd groups sample n with n + b/4, n + 2b/4, n + 3b/4 (networks_stylegan2.py:577-592), and the even /
+        odd halves of the batch keep exactly those groups only then."""
+        if self.stream_lanes == 1 or b != self._max_local or b < 8 or b % 2:
+            return False
+        if self.w_disc > 0 and b % 8:
+            return False
+        return self.stream_lanes == 2 or self.w_lpips <= 0
+
+    def build_lanes(self):
+        import copy
+        half = self._max_local // 2
+        opt = copy.copy(self._opt)
+        opt.batch_size, opt.max_local_batch, opt.norm_batch = half, half, self._max_local
+        opt.verbose_log, opt.stream_lanes = False, 1
+        shared = {'banks': {'W': self.W, 'fea': list(self.Fbank) if self.feat is not None else None}, 'Xc': self.Xc,
+                  'Fbank': self.Fbank if self.feat is not None else None}
+        self._lanes = [LatentAug(self.phase, opt, self.save_dir, [self.device.index], generator=self._generator,
+                                 discriminator=self._discriminator, latent_codes=self.stats_dataset_w, feature_net=self._feature_net,
+                                 _shared=shared) for _ in range(2)]
+        self._lane_stream = torch.cuda.Stream(device=self.device)
+
+    def run_lanes(self, w, final_noises=None, crop_pos=None, concurrent=True):
+        """run_local for a full local batch through the two lanes: samples 0, 2, 4, .. on the current stream, samples 1, 3, 5, .. on the
+        lane stream (forked from / joined into the current stream); every buffer either lane touches is allocated on the current
+        stream before the fork.  `concurrent=False` runs the lanes one after the other on the current stream (same launches)."""
+        if self._lanes is None:
+            self.build_lanes()
+        w = w.to(device=self.device, dtype=torch.float32).contiguous()
+        b = w.shape[0]
+        assert b == self._max_local and b % 2 == 0, 'stream lanes take the full (even) local batch'
+        if crop_pos is None and self.feat is not None:
+            crop_pos = getattr(self, 'crop_params', None)
+            crop_pos = crop_pos['crop_pos'] if crop_pos else get_params(self.res, self.crop_size, self.preprocess)['crop_pos']
+        if self._cfg.final_noise_mode == 2 and final_noises is None:
+            final_noises = self.engine.make_noises(b)      # ONE draw for the batch, as the single loop makes it; a lane keeps its rows
+        parts, outs, fns = [], [], []
+        for k in (0, 1):
+            parts.append(w[k::2].contiguous())
+            outs.append((torch.empty([b // 2, self.engine.img_channels, self.res, self.res], device=self.device, dtype=torch.float32),
+                         torch.empty([b // 2, self.num_ws, self.w_dim], device=self.device, dtype=torch.float32)))
+            fns.append([t[k::2].contiguous() if t is not None else None for t in final_noises] if final_noises is not None else None)
+        main = torch.cuda.current_stream(self.device)
+        side = self._lane_stream if concurrent else main
+        if concurrent:
+            side.wait_stream(main)
+        self._lanes[0].run_local(parts[0], fns[0], crop_pos=crop_pos, out=outs[0])
+        with torch.cuda.stream(side):
+            self._lanes[1].run_local(parts[1], fns[1], crop_pos=crop_pos, out=outs[1])
+        if concurrent:
+            main.wait_stream(side)
+        img = torch.empty([b, self.engine.img_channels, self.res, self.res], device=self.device, dtype=torch.float32)
+        w_aug = torch.empty([b, self.num_ws, self.w_dim], device=self.device, dtype=torch.float32)
+        for k in (0, 1):
+            img[k::2] = outs[k][0]
+            w_aug[k::2] = outs[k][1]
+        self._keep_lanes = (parts, outs, fns)
+        return img, w_aug, None
+
+    def run_batch(self, w, final_noises=None):
+        """The local batch through two stream lanes when it qualifies (lanes_eligible), through the single loop otherwise."""
+        self.lanes_active = self.lanes_eligible(w.shape[0])
+        if self.lanes_active:
+            return self.run_lanes(w, final_noises, concurrent=self.lanes_concurrent)
+        return self.run_local(w, final_noises)
 
     # ---- verbose_log artefacts of the first batch (reference :278-300, :620-655)
     def _log_first_batch(self, losses, elapsed, trace, fname, times=None):
@@ -540,7 +634,7 @@ class LatentAug:
                     # first-batch log of the reference (:278-300): rank 0 reports its own shard, as replica 0 of a DataParallel run would
                     img, w_aug = self._run_verbose(w[lo:hi], fn, fname[lo:hi] if fname is not None else None)
                 else:
-                    img, w_aug, _ = self.run_local(w[lo:hi], fn)
+                    img, w_aug, _ = self.run_batch(w[lo:hi], fn)
                 self._verbose_flag = False
             else:
                 img = torch.empty([0, self.engine.img_channels, self.res, self.res], device=self.device)
@@ -561,7 +655,7 @@ class LatentAug:
             img, w_aug = self._run_verbose(w, final_noises, fname)
             self._verbose_flag = False
             return img, w_aug
-        img, w_aug, _ = self.run_local(w, final_noises)
+        img, w_aug, _ = self.run_batch(w, final_noises)
         return img, w_aug
 
     def _run_verbose(self, w, final_noises, fname):
@@ -596,7 +690,9 @@ class LatentAug:
     @property
     def graph_state(self):
         """1: the optimisation step is replayed from a captured hipGraph; 0: eager launches (`opt.hip_graph = False`, or no batch has
-        run yet); -1: eager because the runtime refused the capture."""
+        run yet); -1: eager because the runtime refused the capture.  (With stream lanes: of the lanes, which run the batches.)"""
+        if self.lanes_active and self._lanes:
+            return min(l.graph_state for l in self._lanes)
         return int(self._lib.la_latent_opt_graph_state(self._h))
 
     __call__ = forward

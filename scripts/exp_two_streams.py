@@ -16,17 +16,28 @@ from latentaugment_amd.latent_aug import LatentAug                          # no
 
 dev = torch.device('cuda', 0)
 NG = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-sys.argv = ['bench.py']
+sys.argv = ['bench.py'] + sys.argv[2:]                                     # bench arguments after the stream count (--preset E, --w-disc 0.01)
 args = bench.apply_preset(bench.parse())
 sd, meta = synthetic.make_generator_state_dict(img_resolution=args.res, img_channels=2, channel_base=args.channel_base, seed=0)
 W, X = synthetic.make_banks(meta['num_ws'], res=args.res, M_w=args.M_w, M_x=args.M_x)
 w0 = synthetic.make_latents(8, seed=1).to(dev)
 
 
+extra = {}
+banks = {'W': W, 'X': X}
+if args.w_lpips > 0:
+    extra['feature_net'] = synthetic.make_vgg16_lpips_ops(seed=7)
+    F = synthetic.lpips_num_features(64)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    banks['fea'] = [torch.randn([args.M_x, F], device=dev, generator=gen) * (1.0 / F) ** 0.5 for _ in range(2)]
+if args.w_disc > 0:
+    extra['discriminator'] = synthetic.make_discriminator_state_dict(img_resolution=args.res, img_channels=2, channel_base=args.channel_base)
+
+
 def make(batch):
     opt = bench.make_opt(args, 0, batch)
     opt.final_noise_mode = 'const'
-    return LatentAug('train', opt, '/tmp', [0], generator=sd, banks={'W': W, 'X': X})
+    return LatentAug('train', opt, '/tmp', [0], generator=sd, banks=banks, **extra)
 
 
 full = make(8)
@@ -46,7 +57,7 @@ def run_parts(concurrent):
         with torch.cuda.stream(st if concurrent else torch.cuda.current_stream()):
             if concurrent:
                 st.wait_stream(torch.cuda.default_stream(dev))
-            outs.append(la.run_local(w0[k * per:(k + 1) * per], crop_pos=(0, 0))[:2])
+            outs.append(la.run_local(w0[k::NG].contiguous(), crop_pos=(0, 0))[:2])      # interleaved: keeps D's MinibatchStd groups (n, n+2, ..)
         if not concurrent:
             torch.cuda.synchronize()
     if concurrent:
@@ -80,3 +91,32 @@ for k in range(NG):
 for k in range(NG):
     di = float((a[k][0] - b[k][0]).abs().max()); dw = float((a[k][1] - b[k][1]).abs().max())
     print(f'part {k}: overlapped vs alone: max |d img| {di:.3e}, max |d w| {dw:.3e}', flush=True)
+
+# ---- both half-batch loops (eager launches inside) captured as ONE graph: the halves are parallel branches of it, and each half's
+# discriminator / perceptual fork is a branch of its branch.  (Two separately replayed graphs that fork inside do not overlap at all.)
+if os.environ.get('LA_EXP_ONE_GRAPH', '1') != '0':
+    lib = parts[0]._lib
+    for la in parts:
+        lib.la_latent_opt_set_graph(la._h, 0)
+    wp = [w0[k::NG].contiguous() for k in range(NG)]
+    for k, la in enumerate(parts):          # first-use effects outside the capture
+        la.run_local(wp[k], crop_pos=(0, 0))
+    torch.cuda.synchronize()
+    cap = torch.cuda.Stream(device=dev)
+    g = torch.cuda.CUDAGraph()
+    res = []
+    with torch.cuda.graph(g, stream=cap, capture_error_mode='relaxed'):
+        for k, (la, st) in enumerate(zip(parts, streams)):
+            if k == 0:
+                res.append(la.run_local(wp[k], crop_pos=(0, 0))[:2])
+            else:
+                st.wait_stream(cap)
+                with torch.cuda.stream(st):
+                    res.append(la.run_local(wp[k], crop_pos=(0, 0))[:2])
+        for st in streams[1:]:
+            cap.wait_stream(st)
+    t_g = timed(g.replay)
+    print(f'both halves as branches of ONE captured graph: {1e3 * t_g:.1f} ms ({8 / t_g:.1f} images/s)', flush=True)
+    g.replay(); torch.cuda.synchronize()
+    for k in range(NG):
+        print(f'part {k}: one graph vs alone: max |d w| {float((a[k][1] - res[k][1]).abs().max()):.3e}', flush=True)
