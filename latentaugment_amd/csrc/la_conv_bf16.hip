@@ -482,8 +482,14 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // MF = 1 (three-wave fp16 x2 form, 128-row tiles): the step on v_mfma_f32_16x16x32_f16, as in the halo kernel (2 x 8 tiles of 16 x 16
 // per wave, the pixel fragments read twice per step, LDS slots swizzled by 2 * ((pixel >> 2) & 1), accumulators brought into the
 // 32x32 layout through LDS before the shared epilogue).
-template <int MT, bool SPLIT, int FMT, int WV, int MF = 0>
+template <int MT, bool SPLIT, int FMT, int WV, int MFX = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void la_conv_bf16_kernel(LaConvArgs a_in) {
+    // MFX bits 4 / 5 (development build only, WRONG results, timing only): the pixel records / the weight fragments are fetched for the
+    // first tap of a chunk only and re-used for its other taps -- what ANY scheme that removes the per-tap re-read (a linear halo in
+    // LDS, parity planes) could gain at most
+    constexpr int MF = MFX & 15;
+    constexpr bool ABL_PIX = (MFX & 16) != 0, ABL_WGT = (MFX & 32) != 0;
+    constexpr bool ABL_BAR = (MFX & 64) != 0, ABL_LDSW = (MFX & 128) != 0;      // (same status) no barrier per step / no LDS write per step
     static_assert(MF == 0 || (WV == 3 && FMT == FMT_F16X2 && MT == 128), "the 16x16x32 form exists for the three-wave fp16 x2 kernel on 128-row tiles");
     // MF = 2: MF = 1 on THREE pixel buffers.  The barrier at the end of step s then publishes the buffer of step s + 2, so the buffer of
     // step s + 1 is already complete while step s computes: its first fragments are read under the last MFMAs of step s, and no LDS
@@ -613,6 +619,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     unsigned ex[16], ey[NTERM == 3 ? 16 : 1];
     bool ok_r = false;
     auto load_b = [&](int cc, int t) {
+        if constexpr (ABL_PIX) { if (t != 0) return; }
         if constexpr (PIECES) {
             const int dy = (int)((dypack >> (4 * t)) & 15u) - 8, dx = (int)((dxpack >> (4 * t)) & 15u) - 8;
             const unsigned delta = (unsigned)((dy * a.Win + dx) * (KCB * EB));      // (scalar)
@@ -750,6 +757,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         mblk16 = mblk16 < (Mp >> 5) ? mblk16 : (Mp >> 5) - 1;
         const unsigned a16_off = (unsigned)mblk16 * 2048u + (unsigned)(kq * 32 + c16) * 16u;
         auto load_a16 = [&](int cc, int t, int mi, f16x8 (&dst)[2]) {
+            if constexpr (ABL_WGT) { if (t != 0) return; }
             const unsigned tw = (unsigned)((wpack >> (4 * t)) & 15u);
             const unsigned so = (tw * nck + cc) * slab_bytes;
 #pragma unroll
@@ -789,7 +797,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             const int ib1 = ib == 2 ? 0 : ib + 1, ib2 = ib1 == 2 ? 0 : ib1 + 1;
             const unsigned char* cur = smem + ib * BBUF;
             const unsigned char* nx1 = smem + ib1 * BBUF;
-            write_b(smem + ib2 * BBUF);                // step s+2 (loaded during step s-1)
+            if constexpr (!ABL_LDSW) write_b(smem + ib2 * BBUF);                // step s+2 (loaded during step s-1)
             load_b(c2, t2);                            // step s+3
             __builtin_amdgcn_sched_barrier(0);
             const bool more = s + 1 < nstep;
@@ -811,7 +819,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             adv(c1, t1);           // weights run one step ahead, pieces three
             adv(c2, t2);
             ib = ib1;
-            __syncthreads();
+            if constexpr (!ABL_BAR) __syncthreads();
         }
       } else {
         load_b(c0, t0);
@@ -1674,6 +1682,17 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
             const size_t lds_mf = lds128 > (size_t)4 * 64 * 36 * 4 ? lds128 : (size_t)4 * 64 * 36 * 4;
             const size_t lds_3 = (size_t)3 * NTERM * NT * BPITCH;      // three pixel buffers (>= the accumulator hand-over's 36 KB)
             const bool three = fk == 2 || (fk == 0 && !split) || fk == 3;      // default: direct launches on three buffers (knob 2: both, 1: neither)
+#ifdef LA_DEV
+            if (fk >= 16 && !split) {      // ablations of the direct launches (kernel comment): 18 = no pixel re-reads, 34 = no weight re-reads, 50 = neither
+                if (fk == 18) hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT_F16X2, 3, 18>), grid, dim3(256), lds_3, stream, as);
+                else if (fk == 66) hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT_F16X2, 3, 66>), grid, dim3(256), lds_3, stream, as);       // no barrier
+                else if (fk == 130) hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT_F16X2, 3, 130>), grid, dim3(256), lds_3, stream, as);     // no LDS write
+                else if (fk == 242) hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT_F16X2, 3, 242>), grid, dim3(256), lds_3, stream, as);     // none of the four
+                else if (fk == 34) hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT_F16X2, 3, 34>), grid, dim3(256), lds_3, stream, as);
+                else hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT_F16X2, 3, 50>), grid, dim3(256), lds_3, stream, as);
+                return LA_OK;
+            }
+#endif
             if (three && !split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT_F16X2, 3, 2>), grid, dim3(256), lds_3, stream, as);
             else if (fk == 2 && split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT_F16X2, 3, 2>), grid, dim3(256), lds_3, stream, as);
             else if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT_F16X2, 3, 1>), grid, dim3(256), lds_mf, stream, as);
