@@ -59,6 +59,7 @@ struct la_disc {
     int precision, lastB, mbstd_group;
 };
 
+static inline int dz_xhalf(int res) { return (res / 2 + 1 + 3) & ~3; }      // column-planar rows of a (res+1)-wide intermediate: odd columns start here
 static size_t alup(size_t v) { return (v + 63) & ~(size_t)63; }
 struct DCarver {
     char* base; size_t off;
@@ -115,7 +116,8 @@ static size_t d_layout(la_disc* h, void* ws) {
         b.x1 = c.take(mb * b.cout * hq); b.ysk = c.take(mb * b.cout * hq); b.sum = c.take(mb * b.cout * hq);
         if (k + 1 < h->nblocks) h->blk[k + 1].xin = b.sum;
         if (mb * b.cin * hw > gmax) gmax = mb * b.cin * hw;
-        const size_t s1 = mb * b.cin * (size_t)(b.res + 1) * (b.res + 1);
+        // (backward: the transposed conv's (res+1)-row intermediate in column-planar rows of pitch 2 * dz_xhalf(res), as the generator's up layers)
+        const size_t s1 = mb * b.cin * (size_t)(b.res + 1) * (size_t)(2 * dz_xhalf(b.res));
         if (s1 > smax) smax = s1;
         size_t w;
         w = la_modconv_workspace_bytes((int)mb, b.cin, b.cin, b.res, 0); if (w > cw) cw = w;
@@ -618,6 +620,7 @@ extern "C" int la_disc_backward(la_disc* h, const float* dlogits, float* g_img, 
     if (fuse) LA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->xs_b), (int)LA_XS_INIT, (size_t)2 * h->nblocks * h->maxB * LA_XS_FAN, stream));
     auto rows_g = [&](int k) { return h->xs_b + (size_t)(2 * k) * h->maxB * LA_XS_FAN; };
     auto rows_c0 = [&](int k) { return h->xs_b + (size_t)(2 * k + 1) * h->maxB * LA_XS_FAN; };
+    auto zx_of = [&](int res) { return (fuse && h->precision != LA_PREC_F32 && res % 4 == 0) ? dz_xhalf(res) : 0; };
     for (int k = h->nblocks - 1; k >= 0; --k) {
         DBlock& b = h->blk[k];
         const int res = b.res, hq = res / 2;
@@ -632,6 +635,10 @@ extern "C" int la_disc_backward(la_disc* h, const float* dlogits, float* g_img, 
             a.in = gs ? g_sum : h->scrB; a.in_bstride = (long)b.cout * hq * hq; a.out = h->scrA;
             a.B = B; a.C = b.cout; a.M = b.cin; a.Hin = a.Win = hq; a.Hout = a.Wout = res + 1;
             a.out_sy = a.out_sx = 2; a.epi = LA_EPI_RAW;
+            // fused tail: the intermediate in column-planar rows (even columns | odd columns: every phase stores contiguous runs), read by
+            // the planar vector FIR kernel (la_fir4x4_s1p_kernel) -- the scalar kernel on dense rows took 291 us at 8 x 128 x 256^2
+            const int zx = zx_of(res), zp = 2 * zx;
+            if (zx) { a.out_pitch = zp; a.out_plane = (long)zp * (res + 1); a.out_sx = 1; a.Wout = zp; }
             if (gs) {
                 a.in_mask_y = b.x1; a.in_mask_act = LA_ACT_LRELU; a.in_mask_alpha = 0.2f; a.in_mask_gain = sq2 * rs2;
                 a.in_mask_clamp = h->clamp >= 0.f ? h->clamp * rs2 : -1.f;
@@ -642,14 +649,14 @@ extern "C" int la_disc_backward(la_disc* h, const float* dlogits, float* g_img, 
             int np = 0;
             for (int py = 0; py < 2; ++py)
                 for (int px = 0; px < 2; ++px) {
-                    a.out_oy = py; a.out_ox = px; a.Gy = py ? hq : hq + 1; a.Gx = px ? hq : hq + 1;
+                    a.out_oy = py; a.out_ox = zx ? px * zx : px; a.Gy = py ? hq : hq + 1; a.Gx = px ? hq : hq + 1;
                     int nt = 0;
                     for (int ky = py; ky < 3; ky += 2)
                         for (int kx = px; kx < 3; kx += 2) { a.tap_dy[nt] = -(ky / 2); a.tap_dx[nt] = -(kx / 2); a.tap_w[nt] = ky * 3 + kx; ++nt; }
                     a.ntaps = nt;
                     if (merged) {
                         LaConvArgs::Phase& P = a.ph[np++];
-                        P.Gy = a.Gy; P.Gx = a.Gx; P.out_oy = py; P.out_ox = px; P.ntaps = nt;
+                        P.Gy = a.Gy; P.Gx = a.Gx; P.out_oy = py; P.out_ox = a.out_ox; P.ntaps = nt;
                         for (int t = 0; t < nt; ++t) { P.tap_dy[t] = a.tap_dy[t]; P.tap_dx[t] = a.tap_dx[t]; P.tap_w[t] = a.tap_w[t]; }
                         continue;
                     }
@@ -664,6 +671,7 @@ extern "C" int la_disc_backward(la_disc* h, const float* dlogits, float* g_img, 
         if (fuse) {
             // FIR adjoint + act'(y0) + the slot rows of conv0's backward contraction in one kernel
             LaFirTail tail{b.y0, LA_ACT_LRELU, 0.2f, sq2, h->clamp, rows_c0(k)};
+            if (zx_of(res)) { tail.in_pitch = 2 * zx_of(res); tail.in_plane = (long)tail.in_pitch * (res + 1); tail.in_xhalf = zx_of(res); }
             if ((rc = la_upfirdn2d_ex(h->scrA, other, B, b.cin, res + 1, res + 1, h->fir, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1.f, nullptr, stream, nullptr, &tail))) return rc;
             if ((rc = conv_same(h, b.conv0, true, other, h->scrA, B, res, 0, 0.f, 0.f, nullptr, nullptr, stream, nullptr, 0, rows_c0(k)))) return rc;
         } else {

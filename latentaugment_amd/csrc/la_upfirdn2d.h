@@ -9,6 +9,7 @@
 struct LaFirTail {
     const float* yref; int act; float alpha, gain, clamp;
     float* xs_out;
+    int in_pitch = 0; long in_plane = 0; int in_xhalf = 0;      // (4x4 stride-1 only) padded / column-planar input rows, as la_upfirdn2d_modconv_epilogue takes them
 };
 int la_upfirdn2d_ex(const float* in, float* out, int B, int C, int Hin, int Win, const float* f_host, int fh, int fw,
                     int upx, int upy, int dnx, int dny, int padx0, int padx1, int pady0, int pady1, int flip_filter,

@@ -274,6 +274,12 @@ __global__ __launch_bounds__(256) void la_fir4x4_s1p_kernel(FirArgs a, float4 fx
                 o.y = la_act_fwd(o.y * dm + bv + nz.y, a.act, a.alpha, a.gain, a.clamp);
                 o.z = la_act_fwd(o.z * dm + bv + nz.z, a.act, a.alpha, a.gain, a.clamp);
                 o.w = la_act_fwd(o.w * dm + bv + nz.w, a.act, a.alpha, a.gain, a.clamp);
+            } else if (EPI == 2) {      // activation backward from the saved output at this position (FirArgs::yref)
+                const float4 yr = *reinterpret_cast<const float4*>(a.yref + (long)p * HWout + pos);
+                o.x *= la_act_bwd_from_y(yr.x, a.act, a.alpha, a.gain, a.clamp);
+                o.y *= la_act_bwd_from_y(yr.y, a.act, a.alpha, a.gain, a.clamp);
+                o.z *= la_act_bwd_from_y(yr.z, a.act, a.alpha, a.gain, a.clamp);
+                o.w *= la_act_bwd_from_y(yr.w, a.act, a.alpha, a.gain, a.clamp);
             } else if (a.addend) {
                 const float4 ad = *reinterpret_cast<const float4*>(a.addend + (long)p * HWout + pos);
                 o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
@@ -453,7 +459,7 @@ static int fir_launch_inner(const FirArgs& a, hipStream_t stream) {
         LA_CHECK_ARG(s1 && !a.pmax && a.padx0 == 1 && a.pady0 == 1 && a.Wout % 4 == 0 && a.Win == a.Wout + 1 &&
                          a.in_pitch % 4 == 0 && a.in_plane % 4 == 0 && a.in_xhalf % 4 == 0 && a.in_xhalf >= (a.Win + 1) / 2 &&
                          a.in_pitch >= a.in_xhalf + a.Win / 2 && (a.noise_bstride % 4) == 0 &&
-                         (((size_t)a.in | (size_t)a.out | (size_t)a.noise | (size_t)a.addend) & 15) == 0 && fir_separable(a.f, fx, fy),
+                         (((size_t)a.in | (size_t)a.out | (size_t)a.noise | (size_t)a.addend | (size_t)a.yref) & 15) == 0 && fir_separable(a.f, fx, fy),
                      "upfirdn2d: column-planar input needs the 4x4 pad-1 separable FIR on aligned planes (W % 4 == 0, no plane maxima)");
         // rows per thread: 16 where that still leaves every SIMD >= 4 waves' worth of threads, else 4 (short serial chains on small planes)
         int rows = (long)a.P * (a.Wout / 4) * la_cdiv(a.Hout, 16) >= 256l * 4 * 4 * 64 ? 16 : 4;
@@ -463,6 +469,7 @@ static int fir_launch_inner(const FirArgs& a, hipStream_t stream) {
         dim3 g((unsigned)((items + 255) / 256));
         const float4 vx = make_float4(fx[0], fx[1], fx[2], fx[3]), vy = make_float4(fy[0], fy[1], fy[2], fy[3]);
         if (a.epi == 1) { if (rows == 4) hipLaunchKernelGGL((la_fir4x4_s1p_kernel<1, 4>), g, dim3(256), 0, stream, a, vx, vy); else hipLaunchKernelGGL((la_fir4x4_s1p_kernel<1, 16>), g, dim3(256), 0, stream, a, vx, vy); }
+        else if (a.epi == 2) { if (rows == 4) hipLaunchKernelGGL((la_fir4x4_s1p_kernel<2, 4>), g, dim3(256), 0, stream, a, vx, vy); else hipLaunchKernelGGL((la_fir4x4_s1p_kernel<2, 16>), g, dim3(256), 0, stream, a, vx, vy); }
         else { if (rows == 4) hipLaunchKernelGGL((la_fir4x4_s1p_kernel<0, 4>), g, dim3(256), 0, stream, a, vx, vy); else hipLaunchKernelGGL((la_fir4x4_s1p_kernel<0, 16>), g, dim3(256), 0, stream, a, vx, vy); }
         LA_CHECK_LAUNCH();
         return LA_OK;
@@ -516,6 +523,10 @@ int la_upfirdn2d_ex(const float* in, float* out, int B, int C, int Hin, int Win,
         LA_CHECK_ARG(!tail->xs_out || s1 || up2, "upfirdn2d: the operand-scale hand-over exists for the 4x4 stride-1 and up-2 kernels");
         if (tail->yref) { a.epi = 2; a.yref = tail->yref; a.act = tail->act; a.alpha = tail->alpha; a.gain = tail->gain; a.clamp = tail->clamp; }
         a.xs_out = tail->xs_out; a.xs_mult = nullptr;
+        if (tail->in_pitch > 0) {      // padded / column-planar input rows (the transposed conv's intermediate): the planar vector kernel
+            LA_CHECK_ARG(s1, "upfirdn2d: a padded input layout needs the 4x4 stride-1 kernel");
+            a.in_pitch = tail->in_pitch; a.in_plane = tail->in_plane; a.in_xhalf = tail->in_xhalf;
+        }
     }
     if (pmax && upx == 1 && upy == 1 && dnx == 1 && dny == 1 && fw == 4 && fh == 4) a.pmax = pmax;
     else LA_CHECK_ARG(!pmax, "upfirdn2d: plane maxima are produced by the 4x4 stride-1 kernel only");
