@@ -698,6 +698,11 @@ extern "C" int la_disc_backward(la_disc* h, const float* dlogits, float* g_img, 
     // fromrgb backward: act' then the 1x1 adjoint onto the image channels (streams the gradient once)
     DBlock& b0 = h->blk[0];
     const long n0 = (long)B * b0.cin * h->R * h->R;
+    if (fuse && (long)h->R * h->R > 4096) {      // act' inside the 1x1's stream of the gradient
+        const LaTorgbMask mk{b0.xin, LA_ACT_LRELU, 0.2f, sq2, h->clamp};
+        return la_torgb_forward(g_sum, b0.frgb_wt, nullptr, 0, nullptr, accumulate ? g_img : nullptr, nullptr, g_img, B, b0.cin, h->imgc, h->R,
+                                h->R, -1.f, stream, &mk);
+    }
     if ((rc = la_bias_act_grad_f32(g_sum, b0.xin, g_sum, nullptr, n0, 1, 1, LA_ACT_LRELU, 0.2f, sq2, h->clamp, stream))) return rc;
     return la_torgb_forward(g_sum, b0.frgb_wt, nullptr, 0, nullptr, accumulate ? g_img : nullptr, nullptr, g_img, B, b0.cin, h->imgc, h->R,
                             h->R, -1.f, stream);

@@ -56,9 +56,12 @@ int la_affine_forward(const LaStyleTable& t, const float* ws, long ws_bstride, l
 int la_xscale_from_bounds(const LaDemodTable& t, const float* s_all, int s_stride, const float* cst, int cst_n, float* xs, float* xs_mult, int B,
                           hipStream_t, float* xs_bwd = nullptr);
 int la_demod_forward(const LaDemodTable& t, const float* s_all, int s_stride, int B, float* d_all, hipStream_t);
+// mask (optional, planes above 64x64): x is a gradient still to be taken through an activation -- x[b][i][p] * act'(mask.y[b][i][p]) is what
+// the 1x1 reads (the discriminator's FromRGB backward: one stream of the gradient and the saved output instead of a sweep + a stream)
+struct LaTorgbMask { const float* y; int act; float alpha, gain, clamp; };
 int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_stride, const float* bias,
                      const float* skip, float* rgb_pre, float* img, int B, int C, int imgc, int H, int W, float clamp,
-                     hipStream_t);
+                     hipStream_t, const LaTorgbMask* mask = nullptr);
 int la_seam_slabs(long HW);
 int la_seam_backward(const LaSeamArgs& a, int B, int imgc, hipStream_t);
 int la_style_backward_conv(float* ds_part, int ntiles, float* ddn_part, int nslabs, const float* d,

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_kernel(const float* __restri
                                                           const float* __restrict__ s, int s_stride,
                                                           const float* __restrict__ bias, const float* __restrict__ skip,
                                                           float* __restrict__ rgb_pre, float* __restrict__ img, int C,
-                                                          long HW, float clamp) {
+                                                          long HW, float clamp, LaTorgbMask mk) {
     extern __shared__ float weff[];   // [IMGC][C]
     const int b = blockIdx.y;
     for (int k = threadIdx.x; k < IMGC * C; k += blockDim.x) {
@@ -215,6 +215,19 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_kernel(const float* __restri
         float4 xv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) xv[u] = *reinterpret_cast<const float4*>(xb + (long)(i + u) * HW);
+        if (mk.y) {      // x is a gradient still to be taken through the activation whose saved output is mk.y (same layout as x)
+            const float* mb = mk.y + (long)b * C * HW + p4;
+            float4 mv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mv[u] = *reinterpret_cast<const float4*>(mb + (long)(i + u) * HW);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                xv[u].x *= la_act_bwd_from_y(mv[u].x, mk.act, mk.alpha, mk.gain, mk.clamp);
+                xv[u].y *= la_act_bwd_from_y(mv[u].y, mk.act, mk.alpha, mk.gain, mk.clamp);
+                xv[u].z *= la_act_bwd_from_y(mv[u].z, mk.act, mk.alpha, mk.gain, mk.clamp);
+                xv[u].w *= la_act_bwd_from_y(mv[u].w, mk.act, mk.alpha, mk.gain, mk.clamp);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
@@ -224,7 +237,12 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_kernel(const float* __restri
             }
     }
     for (; i < C; ++i) {
-        const float4 xv = *reinterpret_cast<const float4*>(xb + (long)i * HW);
+        float4 xv = *reinterpret_cast<const float4*>(xb + (long)i * HW);
+        if (mk.y) {
+            const float4 mv = *reinterpret_cast<const float4*>(mk.y + (long)b * C * HW + p4 + (long)i * HW);
+            xv.x *= la_act_bwd_from_y(mv.x, mk.act, mk.alpha, mk.gain, mk.clamp); xv.y *= la_act_bwd_from_y(mv.y, mk.act, mk.alpha, mk.gain, mk.clamp);
+            xv.z *= la_act_bwd_from_y(mv.z, mk.act, mk.alpha, mk.gain, mk.clamp); xv.w *= la_act_bwd_from_y(mv.w, mk.act, mk.alpha, mk.gain, mk.clamp);
+        }
 #pragma unroll
         for (int c = 0; c < IMGC; ++c) {
             const float wv = weff[c * C + i];
@@ -327,8 +345,11 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_small_kernel(const float* __
 
 int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_stride, const float* bias,
                      const float* skip, float* rgb_pre, float* img, int B, int C, int imgc, int H, int W, float clamp,
-                     hipStream_t stream) {
+                     hipStream_t stream, const LaTorgbMask* mask) {
     const long HW = (long)H * W;
+    LaTorgbMask mk{nullptr, 0, 0.f, 0.f, 0.f};
+    if (mask) mk = *mask;
+    LA_CHECK_ARG(!mk.y || HW > 4096, "torgb: the fused activation backward exists for planes above 64x64 only");
     LA_CHECK_ARG(HW % 4 == 0, "torgb: H*W must be a multiple of 4");
     LA_CHECK_ARG(imgc >= 1 && imgc <= 4, "torgb: img_channels must be 1..4");
     // launch profiler: x streamed once (+ the image-sized outputs / skip)
@@ -348,7 +369,7 @@ int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_st
     }
     dim3 grid(la_cdiv(HW / 4, 256), B);
     const size_t lds = (size_t)imgc * C * sizeof(float);
-#define LAUNCH(N) hipLaunchKernelGGL(la_torgb_fwd_kernel<N>, grid, dim3(256), lds, stream, x, wrgb, s, s_stride, bias, skip, rgb_pre, img, C, HW, clamp)
+#define LAUNCH(N) hipLaunchKernelGGL(la_torgb_fwd_kernel<N>, grid, dim3(256), lds, stream, x, wrgb, s, s_stride, bias, skip, rgb_pre, img, C, HW, clamp, mk)
     switch (imgc) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
     LA_CHECK_LAUNCH();
