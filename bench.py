@@ -90,6 +90,8 @@ def parse():
     p.add_argument('--lanes', default='auto', choices=['auto', '1', '2'],
                    help="stream lanes: a full local batch as two interleaved half-batch loops on two HIP streams ('auto': when the batch is >= 8 and "
                         "the perceptual criterion is off; 1: never; 2: whenever the batch allows it)")
+    p.add_argument('--whole-frames', action='store_true',
+                   help='every loop step synthesises the whole frame (default: with the discriminator off, only the rows the criteria\'s centre crop depends on)')
     p.add_argument('--lanes-serial', action='store_true',
                    help='profiling aid: the two stream lanes one after the other on one stream (same launches, each alone on the chip)')
     p.add_argument('--no-overlap', action='store_true', help='discriminator and perceptual criterion one after the other instead of side by side')
@@ -123,7 +125,7 @@ def make_opt(args, local_rank, global_batch):
         preprocess_aug='center_random_crop', soft_aug=False, alpha=1.0, verbose_log=False, rand_aug=False,
         lower_bound_clip=False, p_thres=0.0, init_w='inv', final_noise_mode='random',
         precision=args.precision, hip_graph=not args.no_graph, overlap_criteria=not args.no_overlap,
-        stream_lanes=args.lanes if args.lanes == 'auto' else int(args.lanes))
+        stream_lanes=args.lanes if args.lanes == 'auto' else int(args.lanes), loop_window=not args.whole_frames)
 
 
 def cpu_model():
@@ -461,7 +463,10 @@ def main():
                                f'contraction={args.precision}' + (', fp16 operand scales from the data of every pass (lowered by the producing kernels)' if args.precision == 'f16x2' else '') + ', '
                                f'timed call = set_input + LatentAugment.forward + get_output, '
                                'launch mode = ' + LAUNCH_MODES[aug.latent_aug.graph_state] +
-                               (', two stream lanes (samples 0,2,4,.. and 1,3,5,.. as two half-batch loops on two HIP streams)' if aug.latent_aug.lanes_active else ''),
+                               (', two stream lanes (samples 0,2,4,.. and 1,3,5,.. as two half-batch loops on two HIP streams)' if aug.latent_aug.lanes_active else '') +
+                               (', loop steps synthesise the rows the criteria read (image rows %d..%d, the centre crop, and what they depend on in the '
+                                'blocks at >= 64^2); the final synthesis is a whole frame' % (aug.latent_aug.loop_window[0], aug.latent_aug.loop_window[1] - 1)
+                                if aug.latent_aug.loop_window else ', whole frames in every loop step'),
                    'global_batch': gb, 'parallelism': f'dp{world}'},
     }
     if multi is not None:

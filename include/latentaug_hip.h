@@ -162,6 +162,11 @@ int la_synth_set_precision(la_synth* h, int precision);
  * bound conv_clamp * max|style|, 1 = from data maxima).  Every fp16 operand scale is now derived from the data of each pass by the
  * kernel that produces the tensor (slot rows lowered with atomicMin, csrc/la_common.h): no bound, no calibration, nothing to select. */
 int la_synth_set_operand_scale(la_synth* h, int from_data);
+/* Row window of the image for the forward passes that follow (rows [row_lo, row_hi) of img_resolution; 0, 0 = whole frames): the 16-bit
+ * forward kernels of the blocks at >= 64^2 compute the rows that window depends on -- 3x3 / FIR taps and the up-sampling geometry of
+ * networks_stylegan2.py:270-330 followed down the blocks -- and leave the other rows of every buffer as they were.  la_synth_backward is
+ * unchanged and expects an image gradient that is zero outside the window. */
+int la_synth_set_row_window(la_synth* h, int row_lo, int row_hi);
 int la_synth_get_precision(const la_synth* h);
 /* ws element (b,l,j) = ws[b*ws_bstride + l*ws_lstride + j] (ws_lstride = 0: W space, one w per sample).
  * noise_mode 0 'none', 1 'const', 2 explicit unit-variance tensors noises[layer] [B][res][res] ('random' drawn by the caller).
@@ -300,6 +305,13 @@ int la_latent_opt_set_grad_trace(la_latent_opt* h, float* dw_trace);
  * synthesis forward and joined before the crop gradient is added to the image gradient (two parallel branches of the captured step).
  * 0: one after the other.  Bit-identical results either way (same launches, same accumulation order).  Drops a captured step. */
 int la_latent_opt_set_overlap(la_latent_opt* h, int enable);
+/* Image rows [row_lo, row_hi) that the loop's image criteria read (0, 0 = not known, the default).  The reference synthesises a whole
+ * frame in every epoch and hands the pixel criterion its centre crop and the perceptual criterion a window inside it
+ * (util_latent_aug.py:216, :246-262; util_dataset.py:284-323): no output of the loop depends on the other rows.  With a window given, the
+ * synthesis passes of the loop steps compute only what those rows depend on (la_synth_set_row_window); the final synthesis of the
+ * augmented latent (:303) is a whole frame.  Ignored while the discriminator (whole frame, :233-242) is active or per-step images are
+ * traced.  Drops a captured step when the window changes. */
+int la_latent_opt_set_row_window(la_latent_opt* h, int row_lo, int row_hi);
 /* verbose_log timers of the reference's first batch (time_latent / time_disc / time_pix / time_lpips / time_epoch,
  * util_latent_aug.py:221-272): with the time trace on, a run that asks for the loss scalars brackets the criteria of every step with
  * HIP events on the launch stream; la_latent_opt_get_times (after the stream has drained, or blocking) fills ms [steps][5] =

@@ -117,6 +117,10 @@ struct LaConvArgs {
     // ~4x the workgroups instead of four launches that each end in a nearly empty last round.  Phase grids at the split-K sizes
     // (<= 34x34) run the same way through the split-K kernel: blockIdx.x walks the phases' flattened-pixel tiles back to back,
     // one finish launch serves all phases (blockIdx.z = phase).
+    // Row window (16-bit direct kernels; a hint, 0 / 0 = all rows): only output-grid rows [row_lo, row_hi) are wanted -- pixel tiles that
+    // hold none of them return at once and write nothing (merged phases: the window counts rows of every phase's own grid).  The
+    // caller guarantees that nobody reads the rows left out (la_synth.hip: the loop steps of a criterion that sees a crop only).
+    int row_lo, row_hi;
     int nphase;
     struct Phase {
         int Gy, Gx, out_oy, out_ox, ntaps; int tap_dy[LA_CONV_PHASE_TAPS], tap_dx[LA_CONV_PHASE_TAPS], tap_w[LA_CONV_PHASE_TAPS];

@@ -443,6 +443,12 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
             gt = gout = ntw = 0.0;
             for (int p = 0; p < nphase; ++p) { gt += (double)a.ph[p].Gy * a.ph[p].Gx * a.ph[p].ntaps; gout += (double)a.ph[p].Gy * a.ph[p].Gx; ntw += a.ph[p].ntaps; }
         }
+        if (a.row_hi > 0 && a.Gy > 0) {      // row window: only the wanted rows are work (tiles hold 4 rows / 128 flattened pixels: counted as wanted)
+            int lo = a.row_lo > 0 ? a.row_lo : 0, hi = a.row_hi < a.Gy ? a.row_hi : a.Gy;
+            lo &= ~3; hi = (hi + 3) & ~3; if (hi > a.Gy) hi = a.Gy;
+            const double f = hi > lo ? (double)(hi - lo) / a.Gy : 0.0;
+            gt *= f; gout *= f;
+        }
         pflops = 2.0 * a.B * gt * a.M * (double)a.C;
         pbytes = 4.0 * ((double)a.B * a.C * a.Hin * a.Win * (a.in_bstride ? 1.0 : 1.0 / a.B) + (double)a.B * a.M * gout + ntw * a.C * a.M);
     }

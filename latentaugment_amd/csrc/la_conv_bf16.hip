@@ -533,10 +533,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     // XCD-aware tile order (direct mode): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
     // run of pixel tiles -- vertically adjacent tiles (which share the +-1 row halos of the 3x3 taps) then hit the same L2.
     int ntile = bx;
-    if (!SPLIT && (gridDim.x & 7) == 0) ntile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int m0 = blockIdx.y * MT;
     const int G = a.Gy * a.Gx;
     const int Ntot = SPLIT ? a.B * G : G;
+    if (!SPLIT) {
+        // row window (LaConvArgs::row_lo): the tiles that hold a wanted row are a contiguous run [t0, t0 + nt) of the flattened tiles; the
+        // first nt workgroups of the launch take them (in the XCD-aware order below, so the run is spread over all XCDs), the rest return
+        int t0 = 0, nt = (int)gridDim.x;
+        if (a.row_hi > 0) {
+            const int tall = (G + NT - 1) / NT;
+            t0 = (a.row_lo * a.Gx) / NT;
+            int t1 = ((a.row_hi < a.Gy ? a.row_hi : a.Gy) * a.Gx + NT - 1) / NT;
+            t1 = t1 < tall ? t1 : tall;
+            nt = t1 - t0;
+            if ((int)blockIdx.x >= nt) return;
+        }
+        if ((nt & 7) == 0) ntile = (blockIdx.x & 7) * (nt >> 3) + (blockIdx.x >> 3);
+        ntile += t0;
+    }
     if (!SPLIT && (long)ntile * NT >= G) return;          // merged phases: the launch is sized for the largest phase
     const int l31 = lane & 31, lh = lane >> 5;
 
@@ -1077,12 +1091,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN_, wn = wid % WN_;
+    const int tpr = a.Gx >> 5;
+    // row window (LaConvArgs::row_lo): the 4-row tiles that hold a wanted row are the run [t0, t0 + nt) of the row-major tile order; the
+    // first nt workgroups of the launch take them -- in the XCD-aware order, so that the run is spread over all eight XCDs (a test on the
+    // tile row alone left the XCDs that own the top and the bottom of the frame idle and the launch as long as before) -- the rest return
+    int t0 = 0, nt = (int)gridDim.x;
+    if (a.row_hi > 0) {
+        const int r0 = a.row_lo >> 2, r1 = ((a.row_hi < a.Gy ? a.row_hi : a.Gy) + 3) >> 2;
+        t0 = r0 * tpr; nt = (r1 - r0) * tpr;
+        if ((int)blockIdx.x >= nt) return;
+    }
     int ntile = blockIdx.x;
-    if ((gridDim.x & 7) == 0) ntile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous tile runs
+    if ((nt & 7) == 0) ntile = (blockIdx.x & 7) * (nt >> 3) + (blockIdx.x >> 3);   // XCD-contiguous tile runs
+    ntile += t0;
     const int m0 = blockIdx.y * MT;
     const int b = blockIdx.z;
     const int G = a.Gy * a.Gx;
-    const int tpr = a.Gx >> 5;
     const int tyb = ntile / tpr, txb = ntile - tyb * tpr;
     const int y0 = tyb * 4 - 1, x0 = txb * 32 - 1;              // grid coordinates of halo pixel (0, 0)
     const unsigned HWin = (unsigned)(a.Hin * a.Win);

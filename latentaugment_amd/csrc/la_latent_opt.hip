@@ -47,6 +47,7 @@ struct la_latent_opt {
     // feature net forward + backward) on a side stream, forked after the synthesis forward and joined before the crop gradient is
     // added into g_img -- same arithmetic, same summation order, captured into the step's graph as two parallel branches.  Possible
     // since no kernel of the library contains packed-FP32 arithmetic ('Two streams').
+    int win_lo, win_hi;     // image rows the criteria read (la_latent_opt_set_row_window; 0 / 0 = unknown: whole frames in every step)
     int overlap;            // 1 (default): fork / join when both criteria are active and no loss scalars / traces are asked for
     hipStream_t side_stream;
     hipEvent_t ev_fork, ev_join;
@@ -109,6 +110,7 @@ extern "C" int la_latent_opt_create(la_synth* g, int img_resolution, int img_cha
     la_adam_fill_table(h->adam_tab_host, cfg->steps, cfg->beta1, cfg->beta2);
     h->graph_mode = 1;
     h->overlap = 1;
+    h->win_lo = h->win_hi = 0;
     *out = h;
     return LA_OK;
 }
@@ -137,6 +139,18 @@ extern "C" int la_latent_opt_set_overlap(la_latent_opt* h, int enable) {
     LA_CHECK_ARG(h, "latent_opt_set_overlap: null handle");
     h->overlap = enable ? 1 : 0;
     drop_graph(h);
+    return LA_OK;
+}
+
+// Image rows [row_lo, row_hi) that the IMAGE criteria of the loop read (0, 0 = not known): with the pixel criterion on its centre crop and
+// the perceptual criterion on a window inside it, nothing in a loop step depends on the other rows of the synthesised image, and the
+// synthesis passes of the steps deliver that window only (la_synth_set_row_window: the top blocks compute the rows it depends on).  The
+// final synthesis of the augmented latent is always a whole frame.  Ignored while the discriminator (whole frame) is active or
+// per-step images are traced.
+extern "C" int la_latent_opt_set_row_window(la_latent_opt* h, int row_lo, int row_hi) {
+    LA_CHECK_ARG(h && row_lo >= 0 && (row_hi == 0 ? row_lo == 0 : (row_hi > row_lo && row_hi <= h->R)), "latent_opt_set_row_window: bad window");
+    if (row_lo != h->win_lo || row_hi != h->win_hi) drop_graph(h);
+    h->win_lo = row_lo; h->win_hi = row_hi;
     return LA_OK;
 }
 
@@ -336,6 +350,13 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
             if ((rc = la_bank_colsum(h->bankF + (long)ch * h->Mf * h->F, h->Mf, h->F, h->l_colsum + (long)ch * h->F, stream))) return rc;
         h->l_colsum_valid = 1;
     }
+    // loop steps: the synthesis delivers the rows the criteria read (la_latent_opt_set_row_window); whole frames with the discriminator,
+    // with per-step image snapshots, or with no window given
+    const bool windowed = h->win_hi > 0 && !use_disc && !h->trace_img;
+    struct WinGuard {      // (whole frames again on every way out, and for the final synthesis below)
+        la_synth* g; ~WinGuard() { (void)la_synth_set_row_window(g, 0, 0); }
+    } win_guard{h->g};
+    if ((rc = la_synth_set_row_window(h->g, windowed ? h->win_lo : 0, windowed ? h->win_hi : 0))) return rc;
     if (want_losses && c.steps > 0) LA_HIP(hipMemsetAsync(h->losses, 0, (size_t)c.steps * 4 * sizeof(float), stream));
     // loss = -loss_latent - loss_pix - loss_lpips + loss_disc  (:270): the diversity terms enter with a minus sign
     const float lat_coef = h->Mw ? c.w_latent / ((float)h->Mw * nb * (float)h->num_ws * (float)wd) : 0.f;
@@ -461,6 +482,7 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
         }
     }
     if ((rc = la_broadcast_mix(h->w_opt, w0, w_aug_out, B, h->num_ws, wd, c.alpha, c.soft_aug, stream))) return rc;
+    if ((rc = la_synth_set_row_window(h->g, 0, 0))) return rc;      // the augmented image: a whole frame
     if ((rc = la_synth_forward(h->g, w_aug_out, (long)h->num_ws * wd, wd, B, c.final_noise_mode, final_noises, img_out, stream)))
         return rc;
     if (losses_out && c.steps > 0)

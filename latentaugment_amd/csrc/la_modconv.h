@@ -20,14 +20,18 @@ int la_modconv3x3_fwd_ex(const float* x, long x_bstride, const float* in_pmax, i
                          int s_stride, const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                          const float* bias, int act, float alpha, float gain, float clamp, float* y, void* ws, size_t ws_bytes, int B,
                          int cin, int cout, int res, hipStream_t stream, const float* xscale = nullptr, const LaRgbFuse* rgb = nullptr,
-                         float* xs_out = nullptr, const float* xs_mult = nullptr);
+                         float* xs_out = nullptr, const float* xs_mult = nullptr, int row_lo = 0, int row_hi = 0);
+// row_lo / row_hi (0 / 0 = all): row window of the output, LaConvArgs::row_lo -- a hint: rows outside it may or may not be written
 // xs_out / xs_mult (optional): the operand scale of y for the contraction that consumes it (LaConvArgs::fwd_xs_out / fwd_xs_mult)
 int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
                              const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                              const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
                              float* scratch, float* y, float* y_pmax, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
                              hipStream_t stream, const float* xscale = nullptr, int scratch_pitch = 0, int scratch_xhalf = 0,
-                             float* xs_out = nullptr, const float* xs_mult = nullptr);
+                             float* xs_out = nullptr, const float* xs_mult = nullptr, int row_lo = 0, int row_hi = 0);
+// row_lo / row_hi (0 / 0 = all; column-planar scratch only): row window of y -- the FIR writes exactly these rows, the transposed conv the
+// rows of its intermediate they read.  la_modconv3x3_up2_fwd_rows: the input rows such a call reads.
+void la_modconv3x3_up2_fwd_rows(int res, int row_lo, int row_hi, int* in_lo, int* in_hi);
 // scratch_pitch / scratch_xhalf (floats; both 0 = dense (res+1)-wide rows, or both set): COLUMN-PLANAR rows of the transposed-conv
 // intermediate -- the even output columns of a row at [0, res/2 + 1), the odd ones from scratch_xhalf on (a multiple of 4,
 // scratch_pitch >= scratch_xhalf + res/2) -- so that every output phase of the transposed conv stores contiguous runs and the FIR

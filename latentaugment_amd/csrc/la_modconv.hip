@@ -42,9 +42,11 @@ int la_modconv3x3_fwd_ex(const float* x, long x_bstride, const float* in_pmax, i
                          int s_stride, const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                          const float* bias, int act, float alpha, float gain, float clamp, float* y, void* ws, size_t ws_bytes, int B,
                          int cin, int cout, int res, hipStream_t stream, const float* xscale, const LaRgbFuse* rgb, float* xs_out,
-                         const float* xs_mult) {
+                         const float* xs_mult, int row_lo, int row_hi) {
     LA_CHECK_ARG(x && wf && y, "modconv_fwd: null pointer");
+    LA_CHECK_ARG(row_lo >= 0 && (row_hi == 0 || (row_hi > row_lo && row_hi <= res)), "modconv_fwd: bad row window");
     LaConvArgs a; base_args(a);
+    a.row_lo = row_lo; a.row_hi = row_hi;
     a.fwd_xs_out = xs_out; a.fwd_xs_mult = xs_mult;
     if (rgb) {
         LA_CHECK_ARG(rgb->imgc >= 1 && rgb->imgc <= 4 && rgb->w && rgb->s && rgb->rgb_pre && rgb->img && la_modconv3x3_fwd_fuses_rgb(precision, B, cin, cout, res),
@@ -79,8 +81,11 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
                              const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                              const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
                              float* scratch, float* y, float* y_pmax, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
-                             hipStream_t stream, const float* xscale, int scratch_pitch, int scratch_xhalf, float* xs_out, const float* xs_mult) {
+                             hipStream_t stream, const float* xscale, int scratch_pitch, int scratch_xhalf, float* xs_out, const float* xs_mult,
+                             int row_lo, int row_hi) {
     LA_CHECK_ARG(x && wf && y && scratch && fir_host, "modconv_up2_fwd: null pointer");
+    LA_CHECK_ARG(row_lo >= 0 && (row_hi == 0 || (row_hi > row_lo && row_hi <= res)), "modconv_up2_fwd: bad row window");
+    if (scratch_xhalf == 0) row_lo = row_hi = 0;      // (only the planar FIR kernel honours a window)
     LA_CHECK_ARG(scratch_pitch == 0 || scratch_pitch >= res + 1, "modconv_up2_fwd: scratch pitch smaller than a row");
     LA_CHECK_ARG((scratch_xhalf == 0 && scratch_pitch == 0) || (scratch_xhalf >= res / 2 + 1 && scratch_pitch >= scratch_xhalf + res / 2),
                  "modconv_up2_fwd: bad column-planar scratch layout");
@@ -97,6 +102,11 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
     if (scratch_pitch > 0) { a.out_pitch = scratch_pitch; a.out_plane = (long)scratch_pitch * (res + 1); }      // padded (2h+1)-wide rows
     if (scratch_xhalf > 0) { a.out_sx = 1; a.Wout = scratch_pitch; }      // column-planar rows: phase px writes the contiguous run from px * xhalf
     if (precision == LA_PREC_F16X2 && xscale) { a.acc_scale_x = xscale; a.acc_scale_fan = LA_XS_FAN; }      // preset operand scale (slot rows of the caller): no absmax pass
+    if (row_hi > 0) {
+        // FIR output row y reads intermediate rows y - 1 .. y + 2; intermediate row Y = 2 q + py belongs to row q of phase py
+        const int zlo = row_lo - 1 > 0 ? row_lo - 1 : 0, zhi = row_hi + 2 < res + 1 ? row_hi + 2 : res + 1;
+        a.row_lo = zlo >> 1; a.row_hi = ((zhi - 1) >> 1) + 1;
+    }
     if (precision != LA_PREC_F32) {
         // split the (modulated) input once for the four phase launches
         int rc = la_conv_prepare_input(a, stream);
@@ -134,7 +144,18 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
     // FIR with pad (1,1,1,1) and gain up^2 = 4 (conv2d_resample.py:119-126), then the layer epilogue
     return la_upfirdn2d_modconv_epilogue(scratch, y, B, cout, res + 1, res + 1, fir_host, 4, 4, 1, 1, 1, 1, 4.f, d, d_stride,
                                          noise, noise_bstride, noise_strength, bias, act, alpha, gain, clamp, stream, y_pmax,
-                                         scratch_pitch, (long)scratch_pitch * (res + 1), scratch_xhalf, xs_out, xs_mult);
+                                         scratch_pitch, (long)scratch_pitch * (res + 1), scratch_xhalf, xs_out, xs_mult, row_lo, row_hi);
+}
+
+// input rows [in_lo, in_hi) (of the res/2-row input) that la_modconv3x3_up2_fwd_ex reads for the row window [row_lo, row_hi) of y: the phase
+// rows of the window (above), widened by the 128-pixel granularity of the contraction's flattened tiles, plus the tap row above
+void la_modconv3x3_up2_fwd_rows(int res, int row_lo, int row_hi, int* in_lo, int* in_hi) {
+    const int hin = res / 2;
+    const int zlo = row_lo - 1 > 0 ? row_lo - 1 : 0, zhi = row_hi + 2 < res + 1 ? row_hi + 2 : res + 1;
+    const int qlo = zlo >> 1, qhi = ((zhi - 1) >> 1) + 1;
+    const int slack = (128 + hin - 1) / hin;      // rows a 128-pixel tile can reach beyond the window (phase grids are hin or hin + 1 wide)
+    int lo = qlo - slack - 1, hi = qhi + slack;
+    *in_lo = lo > 0 ? lo : 0; *in_hi = hi < hin ? hi : hin;
 }
 
 extern "C" int la_modconv3x3_up2_fwd_f32(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,

@@ -63,6 +63,7 @@ struct la_synth {
     int lastB;
     int precision;
     float* final_img;   // where the last forward put the full-resolution image
+    int win_lo, win_hi;  // row window of the image the next forward passes are asked for (la_synth_set_row_window; 0 / 0 = the whole image)
 };
 
 static size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }
@@ -254,6 +255,10 @@ extern "C" int la_synth_create(int img_resolution, int img_channels, int w_dim, 
     layout(h, workspace, workspace_bytes, &need);
     if (need > workspace_bytes) { free(h); la_set_error("synth_create: workspace too small"); return LA_ERR_WORKSPACE; }
     h->clamp = conv_clamp;
+    h->win_lo = h->win_hi = 0;
+    // every buffer starts as zeros: a forward pass restricted to a row window (la_synth_set_row_window) leaves the other rows of its saved
+    // activations as they were, and the backward pass multiplies them with gradients that are exactly zero there -- they must be finite
+    if (hipMemsetAsync(workspace, 0, need, stream) != hipSuccess) { free(h); la_set_error("synth_create: clearing the workspace failed"); return LA_ERR_HIP; }
     memcpy(h->fir, fir_host, sizeof(float) * 16);
     int p = 0, ci = 0;
     for (int k = 0; k < h->nblocks; ++k) {
@@ -298,6 +303,17 @@ extern "C" int la_synth_set_operand_scale(la_synth* h, int from_data) {
     return LA_OK;
 }
 
+// Row window of the IMAGE that the following forward passes must deliver (rows [row_lo, row_hi) of the img_resolution rows; 0, 0 = all):
+// the latent-optimisation loop whose criteria read a centre crop only (la_latent_opt.hip).  The 16-bit forward kernels of the blocks at
+// >= 64^2 then compute only the rows that window depends on (3x3 taps, FIR taps and the up-sampling geometry followed down the
+// blocks, tile granularities included: everything that IS computed is exact); the rest of every buffer keeps older contents.  The
+// backward pass is unchanged: image-gradient rows outside the window must be zero (they are for a criterion that reads the window only).
+extern "C" int la_synth_set_row_window(la_synth* h, int row_lo, int row_hi) {
+    LA_CHECK_ARG(h && row_lo >= 0 && (row_hi == 0 ? row_lo == 0 : (row_hi > row_lo && row_hi <= h->R)), "synth_set_row_window: bad window");
+    h->win_lo = row_lo; h->win_hi = row_hi;
+    return LA_OK;
+}
+
 #ifdef LA_DEV
 // development build: the transposed-conv intermediate of the LAST up-sampling layer that ran (column-planar rows; scripts/exp_overlap_*.py)
 extern "C" const float* la_synth_dev_zt(const la_synth* h) { return h ? h->zT : nullptr; }
@@ -327,6 +343,29 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
     if (f16 && (rc = la_xscale_from_bounds(h->dt, h->s_all, h->S, h->cst, h->channels[0] * 16, h->xs_fwd, h->xs_mult, B, stream, h->xs_bwd))) return rc;
     auto fwd_row = [&](int conv_index) { return (f16 && conv_index < h->nconv) ? h->xs_fwd + (long)conv_index * B * LA_XS_FAN : nullptr; };
     auto fwd_mult = [&](int conv_index) { return (f16 && conv_index < h->nconv) ? h->xs_mult + (long)conv_index * B : nullptr; };
+    // row windows of the conv outputs for an image row window (la_synth_set_row_window), top block downwards until a window is the
+    // whole plane: conv1 in 4-row tiles around what the image / the block above need, conv0 (FIR output) one row more on either side,
+    // the block below what conv0's transposed conv reads (la_modconv3x3_up2_fwd_rows) and what the image up-sampling reads
+    int wlo[2 * MAX_BLOCKS], whi[2 * MAX_BLOCKS];
+    for (int i = 0; i < h->nconv; ++i) wlo[i] = whi[i] = 0;
+    if (h->win_hi > 0 && h->precision != LA_PREC_F32 && !zt_dense) {
+        int img_lo = h->win_lo, img_hi = h->win_hi, up_lo = 0, up_hi = 0;      // needs of block k: image rows, rows read by block k + 1
+        for (int k = h->nblocks - 1, c1 = h->nconv - 1; k >= 1; --k, c1 -= 2) {
+            const int res = 4 << k;
+            if (res < 64) break;
+            int lo = img_lo, hi = img_hi;
+            if (up_hi > 0) { lo = up_lo < lo ? up_lo : lo; hi = up_hi > hi ? up_hi : hi; }
+            lo &= ~3; hi = (hi + 3) & ~3;
+            if (hi > res) hi = res;
+            if (lo <= 0 && hi >= res) break;                      // everything is needed from here down
+            wlo[c1] = lo; whi[c1] = hi;
+            const int l0 = lo - 1 > 0 ? lo - 1 : 0, h0 = hi + 1 < res ? hi + 1 : res;
+            wlo[c1 - 1] = l0; whi[c1 - 1] = h0;
+            la_modconv3x3_up2_fwd_rows(res, l0, h0, &up_lo, &up_hi);
+            img_lo = (img_lo - 2) >> 1; if (img_lo < 0) img_lo = 0;
+            img_hi = (img_hi >> 1) + 1; if (img_hi > res / 2) img_hi = res / 2;
+        }
+    }
     int ci = 0;
     const float* x = h->cst;
     long x_bstride = 0;
@@ -360,13 +399,14 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
                 rc = la_modconv3x3_fwd_ex(x, x_bstride, nullptr, 0, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                           L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f, sq2,
                                           h->clamp, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream, fwd_row(ci),
-                                          (fuse_rgb && q == nl - 1) ? &rf : nullptr, fwd_row(ci + 1), fwd_mult(ci + 1));
+                                          (fuse_rgb && q == nl - 1) ? &rf : nullptr, fwd_row(ci + 1), fwd_mult(ci + 1), wlo[ci], whi[ci]);
             } else {
                 rc = la_modconv3x3_up2_fwd_ex(x, x_bstride, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                               L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f,
                                               sq2, h->clamp, h->fir, h->zT, L.y, nullptr, h->cws, h->cws_bytes, B, L.cin,
                                               L.cout, res, stream, fwd_row(ci),
-                                              zt_dense ? 0 : 2 * zt_xhalf(res), zt_dense ? 0 : zt_xhalf(res), fwd_row(ci + 1), fwd_mult(ci + 1));
+                                              zt_dense ? 0 : 2 * zt_xhalf(res), zt_dense ? 0 : zt_xhalf(res), fwd_row(ci + 1), fwd_mult(ci + 1),
+                                              wlo[ci], whi[ci]);
             }
             if (rc) return rc;
             x = L.y; x_bstride = (long)L.cout * res * res;

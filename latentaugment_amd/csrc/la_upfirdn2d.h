@@ -25,7 +25,8 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
                                   const float* demod, int demod_stride, const float* noise, long noise_bstride,
                                   float noise_strength, const float* bias, int act, float alpha, float gain,
                                   float clamp, hipStream_t stream, float* pmax = nullptr, int in_pitch = 0, long in_plane = 0, int in_xhalf = 0,
-                                  float* xs_out = nullptr, const float* xs_mult = nullptr);
+                                  float* xs_out = nullptr, const float* xs_mult = nullptr, int row_lo = 0, int row_hi = 0);
+// row_lo / row_hi (column-planar input only; 0 / 0 = all): only output rows [row_lo, row_hi) are computed and written
 // xs_out / xs_mult (optional): slot rows [B][LA_XS_FAN] of the fp16 operand scale of `out` for the contraction that consumes it
 // (la_common.h): lowered by the producing workgroups to pow2(xs_mult[b] * max |out|)
 // in_pitch / in_plane (floats, 0 = dense): padded row pitch / plane stride of `in` (multiples of 4 select the vector kernel)

@@ -26,6 +26,7 @@ struct FirArgs {
     int in_xhalf;                // > 0: COLUMN-PLANAR rows -- the even columns of a row at [0, ceil(Win/2)), the odd ones from in_xhalf on
     float* xs_out;               // optional (4x4 stride-1 kernels): slot rows [B][LA_XS_FAN] of the fp16 operand scale of `out` for the
     const float* xs_mult;        //   contraction that consumes it: every wave lowers its sample's row to pow2(xs_mult[b] * its max |out|)
+    int row_lo, row_hi;          // row window (planar vector kernel; 0 / 0 = all): only output rows [row_lo, row_hi) are computed and written
 };
 
 __global__ __launch_bounds__(256) void la_upfirdn2d_kernel(FirArgs a) {
@@ -167,7 +168,7 @@ static int fir_fill(FirArgs& a, const float* in, float* out, int B, int C, int H
     LA_CHECK_ARG(upW >= fw && upH >= fh, "upfirdn2d: upsampled image smaller than the filter");
     *Wout = (upW - fw + dnx) / dnx;   // upfirdn2d.cpp:35-36
     *Hout = (upH - fh + dny) / dny;
-    a.in = in; a.out = out; a.P = B * C; a.C = C; a.pmax = nullptr; a.xs_out = nullptr; a.xs_mult = nullptr;
+    a.in = in; a.out = out; a.P = B * C; a.C = C; a.pmax = nullptr; a.xs_out = nullptr; a.xs_mult = nullptr; a.row_lo = a.row_hi = 0;
     a.in_pitch = Win; a.in_plane = (long)Hin * Win; a.in_xhalf = 0;
     a.Hin = Hin; a.Win = Win; a.Hout = *Hout; a.Wout = *Wout;
     a.upx = upx; a.upy = upy; a.dnx = dnx; a.dny = dny; a.padx0 = padx0; a.pady0 = pady0;
@@ -211,7 +212,10 @@ __global__ __launch_bounds__(256) void la_fir4x4_s1p_kernel(FirArgs a, float4 fx
     if (live) {
         const int within = (int)(gid - (long)p * per_plane);
         const int strip = within / w4, xg = within - strip * w4;
-        const int x0 = xg * 4, q2 = xg * 2, y0 = strip * ROWS;
+        const int x0 = xg * 4, q2 = xg * 2;
+        // row window (FirArgs::row_lo, 0 / 0 = all): the strip shrinks to the wanted rows, a strip without one does nothing
+        const int ys = strip * ROWS;
+        const int y0 = (a.row_hi > 0 && a.row_lo > ys) ? a.row_lo : ys;
         const long HWout = (long)a.Hout * a.Wout;
         const int ne = (a.Win + 1) >> 1, no = a.Win >> 1;
         const bool okm = q2 > 0, oke = q2 + 2 < ne, oko = q2 + 2 < no;
@@ -251,7 +255,8 @@ __global__ __launch_bounds__(256) void la_fir4x4_s1p_kernel(FirArgs a, float4 fx
         const Row r0 = load_row(y0 - 1), r1 = load_row(y0), r2 = load_row(y0 + 1);
         Row n0 = load_row(y0 + 2), n1 = load_row(y0 + 3);
         float4 h0 = hpass(r0), h1 = hpass(r1), h2 = hpass(r2);
-        const int y1 = y0 + ROWS < a.Hout ? y0 + ROWS : a.Hout;
+        int y1 = ys + ROWS < a.Hout ? ys + ROWS : a.Hout;
+        if (a.row_hi > 0 && a.row_hi < y1) y1 = a.row_hi;
 #pragma unroll 4
         for (int y = y0; y < y1; ++y) {
             const float4 h3 = hpass(n0);
@@ -446,8 +451,10 @@ __global__ __launch_bounds__(256) void la_fir4x4_down2_kernel(FirArgs a) {    //
 static int fir_launch_inner(const FirArgs& a, hipStream_t stream);
 static int fir_launch(const FirArgs& a, hipStream_t stream) {
     // launch profiler: one read of the input planes + one write of the output planes
-    const int slot = la_prof_open(LA_PC_FIR, 2.0 * a.fw * a.fh * (double)a.P * a.Hout * a.Wout,
-                                  4.0 * a.P * ((double)a.Hin * a.Win + (double)a.Hout * a.Wout), stream);
+    double f = 1.0;      // (row window: the wanted rows only)
+    if (a.row_hi > 0 && a.in_xhalf > 0) { const int lo = a.row_lo > 0 ? a.row_lo : 0, hi = a.row_hi < a.Hout ? a.row_hi : a.Hout; f = hi > lo ? (double)(hi - lo) / a.Hout : 0.0; }
+    const int slot = la_prof_open(LA_PC_FIR, f * 2.0 * a.fw * a.fh * (double)a.P * a.Hout * a.Wout,
+                                  f * 4.0 * a.P * ((double)a.Hin * a.Win + (double)a.Hout * a.Wout), stream);
     const int rc = fir_launch_inner(a, stream);
     la_prof_close(slot, stream);
     return rc;
@@ -538,7 +545,7 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
                                   const float* demod, int demod_stride, const float* noise, long noise_bstride,
                                   float noise_strength, const float* bias, int act, float alpha, float gain,
                                   float clamp, hipStream_t stream, float* pmax, int in_pitch, long in_plane, int in_xhalf, float* xs_out,
-                                  const float* xs_mult) {
+                                  const float* xs_mult, int row_lo, int row_hi) {
     FirArgs a; int ho, wo;
     int rc = fir_fill(a, in, out, B, C, Hin, Win, f_host, fh, fw, 1, 1, 1, 1, padx0, padx1, pady0, pady1, 0, fir_gain,
                       &ho, &wo);
@@ -550,6 +557,7 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
     if (in_pitch > 0) { a.in_pitch = in_pitch; a.in_plane = in_plane; a.in_xhalf = in_xhalf; }
     LA_CHECK_ARG(!xs_out || (fw == 4 && fh == 4), "upfirdn2d: the operand-scale hand-over exists for the 4x4 stride-1 kernels only");
     a.xs_out = xs_out; a.xs_mult = xs_mult;
+    if (in_xhalf > 0) { a.row_lo = row_lo; a.row_hi = row_hi; }      // (the planar vector kernel honours the window; the others compute every row)
     return fir_launch(a, stream);
 }
 

@@ -328,6 +328,15 @@ class LatentAug:
         # (`opt.overlap_criteria = False`): bit-identical results, la_latent_opt_set_overlap
         self.overlap_criteria = bool(getattr(opt, 'overlap_criteria', True))
         _lib.check(lib.la_latent_opt_set_overlap(h, int(self.overlap_criteria)), 'la_latent_opt_set_overlap')
+        # rows of the image that the loop's criteria read: the pixel criterion its centre crop (util_dataset.py:317-323), the perceptual
+        # criterion a crop_size_aug window inside that crop when preprocess_aug is one of the centre modes -- the loop steps then
+        # synthesise only what those rows depend on (la_latent_opt_set_row_window; `opt.loop_window = False`: whole frames in every step).
+        # The discriminator reads whole frames: no window.
+        self.loop_window = None
+        if getattr(opt, 'loop_window', True) and self.w_disc <= 0 and (self.w_pix > 0 or self.w_lpips > 0) and \
+                (self.w_lpips <= 0 or self.preprocess in ('center_crop', 'center_random_crop')):
+            self.loop_window = (off, off + crop)
+            _lib.check(lib.la_latent_opt_set_row_window(h, off, off + crop), 'la_latent_opt_set_row_window')
         self.disc = None
         if self.w_disc > 0:
             if discriminator is None:
