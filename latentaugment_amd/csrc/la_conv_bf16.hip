@@ -546,7 +546,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             int t1 = ((a.row_hi < a.Gy ? a.row_hi : a.Gy) * a.Gx + NT - 1) / NT;
             t1 = t1 < tall ? t1 : tall;
             nt = t1 - t0;
-            if ((int)blockIdx.x >= nt) return;
+            if ((int)blockIdx.x >= nt) {      // this workgroup stands for one of the tiles outside the window: [0, t0) then [t0 + nt, tall)
+                const int j = (int)blockIdx.x - nt;
+                if (j < tall - nt) la_conv_zero_partials<MT>(a, bz, m0, j < t0 ? j : j + nt);
+                return;
+            }
         }
         if ((nt & 7) == 0) ntile = (blockIdx.x & 7) * (nt >> 3) + (blockIdx.x >> 3);
         ntile += t0;
@@ -565,6 +569,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     const int gx_l = nvalid ? g_l - gy_l * a.Gx : 0;
     const int iy0 = gy_l * a.in_sy, ix0 = gx_l * a.in_sx;
     const unsigned HWin = (unsigned)(a.Hin * a.Win);
+    const int vy0 = a.in_row_hi > 0 ? a.in_row_lo : 0, vy1 = a.in_row_hi > 0 ? a.in_row_hi : a.Hin;      // valid input rows (LaConvArgs::in_row_lo)
     // fp16 pieces: load k of a thread is the 16-byte piece tid & 7 of the 128-byte record of pixel k * 32 + (tid >> 3) -- pieces 0-3 are
     // the h terms of channels 0-7 / 8-15 / 16-23 / 24-31 of the chunk, pieces 4-7 their l terms (la_presplit_t_kernel, la_fir4x4_adj_pack) --
     // so that the 8 lanes of a pixel read its whole record (a wave instruction touches 8 lines instead of 64) and a piece IS one 16-byte
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
 #pragma unroll
             for (int t = 0; t < LA_CONV_MAX_TAPS; ++t) {
                 const int iy = py + a.tap_dy[t], ix = px + a.tap_dx[t];
-                const bool bad = !pv || iy < 0 || iy >= a.Hin || ix < 0 || ix >= a.Win;
+                const bool bad = !pv || iy < vy0 || iy >= vy1 || ix < 0 || ix >= a.Win;
                 m |= (bad ? 1u : 0u) << t;
             }
             pinv[k] = m;
@@ -647,7 +652,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             return;
         }
         const int iy = iy0 + (int)((dypack >> (4 * t)) & 15u) - 8, ix = ix0 + (int)((dxpack >> (4 * t)) & 15u) - 8;
-        ok_r = nvalid && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        ok_r = nvalid && iy >= vy0 && iy < vy1 && ix >= 0 && ix < a.Win;
         const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
         const unsigned vo = lane_base + (unsigned)(iyc * a.Win + ixc) * (KCB * EB);
         const unsigned so = (unsigned)cc * HWin * (KCB * EB);
@@ -1099,7 +1104,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     if (a.row_hi > 0) {
         const int r0 = a.row_lo >> 2, r1 = ((a.row_hi < a.Gy ? a.row_hi : a.Gy) + 3) >> 2;
         t0 = r0 * tpr; nt = (r1 - r0) * tpr;
-        if ((int)blockIdx.x >= nt) return;
+        if ((int)blockIdx.x >= nt) {      // this workgroup stands for one of the tiles outside the window: [0, t0) then [t0 + nt, all)
+            const int j = (int)blockIdx.x - nt;
+            la_conv_zero_partials<MT>(a, (int)blockIdx.z, (int)blockIdx.y * MT, j < t0 ? j : j + nt);
+            return;
+        }
     }
     int ntile = blockIdx.x;
     if ((nt & 7) == 0) ntile = (blockIdx.x & 7) * (nt >> 3) + (blockIdx.x >> 3);   // XCD-contiguous tile runs
@@ -1110,6 +1119,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     const int tyb = ntile / tpr, txb = ntile - tyb * tpr;
     const int y0 = tyb * 4 - 1, x0 = txb * 32 - 1;              // grid coordinates of halo pixel (0, 0)
     const unsigned HWin = (unsigned)(a.Hin * a.Win);
+    const int vy0 = a.in_row_hi > 0 ? a.in_row_lo : 0, vy1 = a.in_row_hi > 0 ? a.in_row_hi : a.Hin;      // valid input rows (LaConvArgs::in_row_lo)
     const int nck = (a.C + KCB - 1) / KCB;
     const long term_elems = a.wgt_bf16_term_elems;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -1141,7 +1151,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         const int c4 = u / HALO_PX, hp = u - c4 * HALO_PX;
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
         const int iy = y0 + hy, ix = x0 + hx;
-        sl.ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        sl.ok = iy >= vy0 && iy < vy1 && ix >= 0 && ix < a.Win;
         const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
         const unsigned off = (unsigned)(iyc * a.Win + ixc) * EB;
         const int swz = M16 ? ((hp >> 2) & 1) << 1 : (hp >> 2);
@@ -1210,7 +1220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         const int hp = ps_act ? tid : 0;
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
         const int iy = y0 + hy, ix = x0 + hx;
-        ps_ok = ps_act && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        ps_ok = ps_act && iy >= vy0 && iy < vy1 && ix >= 0 && ix < a.Win;
         const int iyc = iy < 0 ? 0 : (iy >= a.Hin ? a.Hin - 1 : iy), ixc = ix < 0 ? 0 : (ix >= a.Win ? a.Win - 1 : ix);
         ps_off = ps_ok ? (unsigned)(iyc * a.Win + ixc) * EB : 0x7ffffff0u;      // (raw buffer: voffset >= num_records reads as 0)
         ps_row = hp * HPITCH;

@@ -16,6 +16,22 @@ __device__ __forceinline__ float la_conv_epi_fwd(const LaConvArgs& a, float v, f
 
 // TILE2D: the 128 pixels of a tile are 4 rows x 32 columns of the output grid (halo kernel) instead of 128 consecutive
 // grid positions; wave N-subtile (wn, j) is then row wn*2 + j of the tile.
+// A pixel tile outside the row window of a backward launch (LaConvArgs::row_lo): its gradient is exactly zero and nothing of it is computed
+// or stored, but the one-pass style finish sums the per-tile partials of EVERY tile -- they are zeroed here by the workgroup that returns.
+template <int MT>
+__device__ __forceinline__ void la_conv_zero_partials(const LaConvArgs& a, int b, int m0, int tile) {
+    const int tid = threadIdx.x;
+    if (a.epi != LA_EPI_BWD || tid >= MT || m0 + tid >= a.M) return;
+    const long slot = ((long)b * a.M + m0 + tid) * a.tiles_per_sample + tile;
+    if (a.ds_part) a.ds_part[slot] = 0.f;
+    if (a.seam_ddn_part) {
+        a.seam_ddn_part[slot] = 0.f;
+        if (a.seam_pmax) a.seam_pmax[slot] = 0.f;
+        if (a.seam_dweff_part)
+            for (int c = 0; c < a.seam_imgc && c < 4; ++c) a.seam_dweff_part[(((long)b * a.seam_imgc + c) * a.M + m0 + tid) * a.tiles_per_sample + tile] = 0.f;
+    }
+}
+
 template <int MT, bool SPLIT, bool TILE2D = false, int WM_ = 2>
 __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&acc)[MT / (32 * WM_)][WM_], float (*red)[MT],   // red: [WN_ > 2 ? 6 : 4][MT] LDS floats
                                                  int ntile, int m0, int G, int Ntot, int b_sel = -1) {

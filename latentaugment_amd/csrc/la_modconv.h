@@ -53,9 +53,13 @@ struct LaSeamFuse {
     const float* wrgb; const float* s_rgb; int s_rgb_stride;
     float* dweff_part;       // [B][imgc][cin][la_modconv_ds_tiles(res)]
 };
+// Row windows of a backward launch (la_synth.hip; null = whole planes): rows [in_lo, in_hi) of gz are valid -- the others hold older
+// contents of a shared buffer where the gradient is exactly zero, and read as zeros -- and only rows [out_lo, out_hi) of gx are wanted
+// (0 / 0 = all; tiles outside write nothing but zero their style-gradient partials).  16-bit direct kernels; other forms ignore them.
+struct LaBwdRows { int in_lo, in_hi, out_lo, out_hi; };
 int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, const float* wb, const void* wq, int precision, const float* s, int s_stride,
                          const float* xin, long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
-                         int res, hipStream_t stream, const LaSeamFuse* seam = nullptr, const float* xscale = nullptr);
+                         int res, hipStream_t stream, const LaSeamFuse* seam = nullptr, const float* xscale = nullptr, const LaBwdRows* rows = nullptr);
 // xscale (optional, [B]): the fp16 operand scale of gz, already final when this launch starts (left by the producer of gz through
 // LaSeamFuse::xs_out / LaSeamArgs::xs_out) -- no plane-maxima reduction launch
 
@@ -64,7 +68,9 @@ int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, con
 int la_modconv3x3_up2_bwd_ex(const float* gz, const float* gz_pmax, int gz_nseg, const float* wb, const void* wq, int precision, const float* s,
                              int s_stride, const float* xin, long xin_bstride, const float* fir_host, float* scratch, float* gx,
                              float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, hipStream_t stream,
-                             const LaSeamFuse* seam = nullptr, const float* xscale = nullptr);      // seam of the block BELOW (its conv1 output is xin), incl. its ToRGB backward
+                             const LaSeamFuse* seam = nullptr, const float* xscale = nullptr, const LaBwdRows* rows = nullptr);
+// rows (fused fp16 path only): in = valid rows of gz (res rows), out = window of gx (res/2 rows); the FIR adjoint then writes the rows of
+// its (res+1)-row result that can be non-zero, [in_lo - 2, in_hi + 2), and the contraction reads the others as zeros      // seam of the block BELOW (its conv1 output is xin), incl. its ToRGB backward
 
 float la_modconv_up2_bwd_xs_mult(const float* fir_host);      // the `mult` of the operand scale an up layer's backward expects (LaSeamFuse::xs_mult)
 

@@ -179,7 +179,7 @@ static void set_seam(LaConvArgs& a, const LaSeamFuse* seam) {
 
 int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, const float* wb, const void* wq, int precision, const float* s, int s_stride,
                          const float* xin, long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
-                         int res, hipStream_t stream, const LaSeamFuse* seam, const float* xscale) {
+                         int res, hipStream_t stream, const LaSeamFuse* seam, const float* xscale, const LaBwdRows* rows) {
     LA_CHECK_ARG(gz && wb && gx, "modconv_bwd: null pointer");
     LA_CHECK_ARG(!seam || (precision != LA_PREC_F32 && xin && seam->ddn_part), "modconv_bwd: the fused seam needs a 16-bit contraction and xin");
     LaConvArgs a; base_args(a);
@@ -195,6 +195,10 @@ int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, con
     a.xin = xin; a.xin_bstride = xin_bstride;
     a.ds_part = ds_part; a.tiles_per_sample = la_conv_tiles_per_sample(res, res);
     set_seam(a, seam);
+    if (rows && precision != LA_PREC_F32) {
+        LA_CHECK_ARG(rows->in_lo >= 0 && rows->in_hi <= res && rows->out_lo >= 0 && rows->out_hi <= res, "modconv_bwd: bad row windows");
+        a.in_row_lo = rows->in_lo; a.in_row_hi = rows->in_hi; a.row_lo = rows->out_lo; a.row_hi = rows->out_hi;
+    }
     return la_conv_launch(a, stream);
 }
 
@@ -207,7 +211,7 @@ extern "C" int la_modconv3x3_bwd_f32(const float* gz, const float* wb, const voi
 int la_modconv3x3_up2_bwd_ex(const float* gz, const float* gz_pmax, int gz_nseg, const float* wb, const void* wq, int precision, const float* s,
                              int s_stride, const float* xin, long xin_bstride, const float* fir_host, float* scratch, float* gx,
                              float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout, int res, hipStream_t stream,
-                             const LaSeamFuse* seam, const float* xscale_in) {
+                             const LaSeamFuse* seam, const float* xscale_in, const LaBwdRows* rows) {
     LA_CHECK_ARG(gz && wb && gx && scratch && fir_host, "modconv_up2_bwd: null pointer");
     LA_CHECK_ARG(!seam || (precision != LA_PREC_F32 && xin && seam->ddn_part && (seam->imgc == 0 || (seam->g_img && seam->wrgb && seam->s_rgb && seam->dweff_part))),
                  "modconv_up2_bwd: the fused seam needs a 16-bit contraction, xin and its output buffers");
@@ -239,7 +243,14 @@ int la_modconv3x3_up2_bwd_ex(const float* gz, const float* gz_pmax, int gz_nseg,
             if ((rc = la_conv_xscale_from_pmax(gz_pmax, gz_nseg, nullptr, 0, la_modconv_up2_bwd_xs_mult(fir_host), xs, B, cout, stream))) return rc;
             xscale = xs; xs_fan = 1;
         }
-        if ((rc = la_fir4x4_adjoint_pack_f16(gz, q, xscale, xs_fan, B, cout, res, res, fir_host, 4.f, stream))) return rc;
+        int zlo = 0, zhi = 0;
+        if (rows && rows->in_hi > 0) {      // rows of the adjoint that can be non-zero: 4 taps, pad 2
+            LA_CHECK_ARG(rows->in_lo >= 0 && rows->in_hi <= res && rows->out_lo >= 0 && rows->out_hi <= hin, "modconv_up2_bwd: bad row windows");
+            zlo = rows->in_lo - 2 > 0 ? rows->in_lo - 2 : 0; zhi = rows->in_hi + 2 < res + 1 ? rows->in_hi + 2 : res + 1;
+            a.in_row_lo = zlo; a.in_row_hi = zhi;
+        }
+        if (rows) { a.row_lo = rows->out_lo; a.row_hi = rows->out_hi; }
+        if ((rc = la_fir4x4_adjoint_pack_f16(gz, q, xscale, xs_fan, B, cout, res, res, fir_host, 4.f, stream, 0, rows ? rows->in_lo : 0, rows ? rows->in_hi : 0, zlo, zhi))) return rc;
         a.in = gz;                       // (not read: the launch takes its operand from in_q)
         a.in_q = q; a.acc_scale_x = xscale; a.acc_scale_fan = xs_fan;
         a.ws = static_cast<char*>(ws) + fused_need; a.ws_bytes = ws_bytes - fused_need;

@@ -44,6 +44,8 @@ struct LaSeamArgs {
     float* dweff_part;       // [B][imgc][C][slabs]
     float* pmax_out;         // optional [B][C][slabs]: partial max |gz| per plane (one per workgroup)
     float* xs_out; float xs_mult;      // optional slot rows [B][LA_XS_FAN] (la_common.h): fp16 operand scale of gz for its consumer, pow2 scale of xs_mult * max|gz|
+    long p_lo, p_hi;         // pixel window (multiples of 4; 0 / 0 = the whole plane): only pixels [p_lo, p_hi) of every plane are read and written --
+                             // the incoming gradient is zero outside them (la_synth.hip: row windows); the slabs share the window
 };
 
 int la_pack_conv_weights(const float* w, float* wf, float* wb, float* wsq, int cout, int cin, int ktaps, hipStream_t,

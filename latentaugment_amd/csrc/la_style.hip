@@ -389,8 +389,9 @@ __global__ __launch_bounds__(256) void la_seam_bwd_kernel(LaSeamArgs a) {
     __shared__ float red[4];
     const int c = blockIdx.y, b = blockIdx.z, slab = blockIdx.x;
     const long HW = a.HW;
-    const long per = (HW / 4 + gridDim.x - 1) / gridDim.x;   // float4 groups per slab
-    const long q0 = slab * per, q1 = (q0 + per < HW / 4) ? q0 + per : HW / 4;
+    const long w0 = a.p_hi > 0 ? a.p_lo / 4 : 0, w1 = a.p_hi > 0 ? a.p_hi / 4 : HW / 4;      // float4 groups of the pixel window (LaSeamArgs::p_lo)
+    const long per = (w1 - w0 + gridDim.x - 1) / gridDim.x;   // float4 groups per slab
+    const long q0 = w0 + slab * per < w1 ? w0 + slab * per : w1, q1 = (q0 + per < w1) ? q0 + per : w1;
     const long plane = ((long)b * a.C + c) * HW;
     const float dm = a.demod ? a.demod[(long)b * a.demod_stride + c] : 1.f;
     const float bv = a.bias ? a.bias[c] : 0.f;
@@ -491,9 +492,11 @@ int la_seam_slabs(long HW) {
 int la_seam_backward(const LaSeamArgs& a, int B, int imgc, hipStream_t stream) {
     LA_CHECK_ARG(a.HW % 4 == 0, "seam: H*W must be a multiple of 4");
     LA_CHECK_ARG(imgc >= 0 && imgc <= 4, "seam: img_channels must be 0..4");
+    LA_CHECK_ARG(a.p_hi == 0 ? a.p_lo == 0 : (a.p_lo >= 0 && a.p_lo < a.p_hi && a.p_hi <= a.HW && a.p_lo % 4 == 0 && a.p_hi % 4 == 0), "seam: bad pixel window");
     dim3 grid(la_seam_slabs(a.HW), a.C, B);
     // launch profiler: read y and the incoming gradient, write gz (+ the image-sized ToRGB operands)
-    const int pslot = la_prof_open(LA_PC_SEAM, 0.0, 4.0 * B * ((double)a.C * a.HW * (a.gx_next ? 3.0 : 2.0) + 2.0 * imgc * (double)a.HW), stream);
+    const double wf = a.p_hi > 0 ? (double)(a.p_hi - a.p_lo) / (double)a.HW : 1.0;
+    const int pslot = la_prof_open(LA_PC_SEAM, 0.0, wf * 4.0 * B * ((double)a.C * a.HW * (a.gx_next ? 3.0 : 2.0) + 2.0 * imgc * (double)a.HW), stream);
 #define LAUNCH(N) hipLaunchKernelGGL(la_seam_bwd_kernel<N>, grid, dim3(256), 0, stream, a)
     switch (imgc) { case 0: LAUNCH(0); break; case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH

@@ -64,6 +64,7 @@ struct la_synth {
     int precision;
     float* final_img;   // where the last forward put the full-resolution image
     int win_lo, win_hi;  // row window of the image the next forward passes are asked for (la_synth_set_row_window; 0 / 0 = the whole image)
+    int fw_lo[2 * MAX_BLOCKS], fw_hi[2 * MAX_BLOCKS];      // row windows of the conv outputs in the LAST forward pass (0 / 0 = whole plane)
 };
 
 static size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }
@@ -366,6 +367,7 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
             img_hi = (img_hi >> 1) + 1; if (img_hi > res / 2) img_hi = res / 2;
         }
     }
+    for (int i = 0; i < h->nconv; ++i) { h->fw_lo[i] = wlo[i]; h->fw_hi[i] = whi[i]; }
     int ci = 0;
     const float* x = h->cst;
     long x_bstride = 0;
@@ -458,9 +460,25 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
     const float up_mult = la_modconv_up2_bwd_xs_mult(h->fir);
     auto xs_slot = [&](int conv_index) { return xs_hand ? h->xs_bwd + (long)conv_index * B * LA_XS_FAN : nullptr; };
     bool seam2_done = false;      // this block's conv1 seam was already applied by the epilogue of the up layer's backward above it
+    // Row windows (la_synth_set_row_window): the gradient of a conv output is non-zero only inside the rows its forward window covers (the
+    // window IS the cone of the image window), so the backward pass of a windowed forward pass reads, computes and writes those rows only:
+    // a producer writes its window, its consumer reads everything outside it as zeros (LaBwdRows) -- the ping-pong buffers G0 / G1 hold
+    // older contents there.  Default path only (fused seams, slot rows); needs an image gradient that is zero outside the image window.
+    const bool bw = xs_hand && !no_fuse && !no_fuse2 && h->precision != LA_PREC_F32;
+    auto r4 = [](int lo, int hi, int res, int* o_lo, int* o_hi) { *o_lo = lo & ~3; *o_hi = (hi + 3) & ~3; if (*o_hi > res) *o_hi = res; };
     for (int k = h->nblocks - 1; k >= 0; --k) {
         const int res = 4 << k;
         const long HW = (long)res * res;
+        // W1 = window of this block's conv1 output (= valid rows of the gradient G0 that reaches it), R1 = the 4-row tiles around the
+        // window of conv0's output (what conv1's backward contraction writes into G1), Wb = window of the block below's conv1 output
+        const bool win = bw && k > 0 && h->fw_hi[ci] > 0;
+        LaBwdRows rw1{0, 0, 0, 0}, rw0{0, 0, 0, 0};
+        if (win) {
+            rw1.in_lo = h->fw_lo[ci]; rw1.in_hi = h->fw_hi[ci];
+            r4(h->fw_lo[ci - 1], h->fw_hi[ci - 1], res, &rw1.out_lo, &rw1.out_hi);
+            rw0.in_lo = rw1.out_lo; rw0.in_hi = rw1.out_hi;
+            if (ci - 2 >= 0 && h->fw_hi[ci - 2] > 0) { rw0.out_lo = h->fw_lo[ci - 2]; rw0.out_hi = h->fw_hi[ci - 2]; }
+        }
         RgbLayer& T = h->rgb[k];
         ConvLayer& L1 = h->conv[ci];
         const int slabs = la_seam_slabs(HW);
@@ -479,6 +497,7 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
             s.s_rgb = h->s_all + T.s_off; s.s_stride = h->S; s.dweff_part = T.dwep;
             if (xs_hand) { s.xs_out = xs_slot(ci); s.xs_mult = 1.f; }      // the seam kernel lowers the slot row of the contraction that follows ...
             else if (f16) s.pmax_out = h->pmax;                              // ... or leaves the plane maxima of gz for it
+            if (win) { s.p_lo = (long)rw1.in_lo * res; s.p_hi = (long)rw1.in_hi * res; }
             if ((rc = la_seam_backward(s, B, h->imgc, stream))) return rc;
         }
         {
@@ -504,7 +523,7 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
             }
             if ((rc = la_modconv3x3_bwd_ex(h->G0, f16 ? (seam2_done ? h->pmax3 : h->pmax) : nullptr, nseg1, L1.wb, L1.wqb, h->precision, h->s_all + L1.s_off,
                                            h->S, xin, xin_bs, h->G1, L1.dsp, h->cws, h->cws_bytes, B, L1.cin, L1.cout, res, stream,
-                                           fuse_seam ? &sf : nullptr, xs_slot(ci))))
+                                           fuse_seam ? &sf : nullptr, xs_slot(ci), win ? &rw1 : nullptr)))
                 return rc;
             fin_conv(L1, tiles1, nseg1);
         }
@@ -549,7 +568,7 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
             }
             if ((rc = la_modconv3x3_up2_bwd_ex(h->G1, f16 ? (fuse_seam ? h->pmax2 : h->pmax) : nullptr, nseg0, L0.wb, L0.wqb, h->precision, h->s_all + L0.s_off, h->S,
                                                h->conv[ci - 1].y, (long)L0.cin * hin * hin, h->fir, h->zT, h->G0, L0.dsp, h->cws, h->cws_bytes, B,
-                                               L0.cin, L0.cout, res, stream, fuse_seam2 ? &sf2 : nullptr, xs_slot(ci))))
+                                               L0.cin, L0.cout, res, stream, fuse_seam2 ? &sf2 : nullptr, xs_slot(ci), win ? &rw0 : nullptr)))
                 return rc;
             fin_conv(L0, tiles, nseg0);
         }

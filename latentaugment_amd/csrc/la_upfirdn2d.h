@@ -35,5 +35,6 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
 // FIR adjoint of an up-sampling layer written straight into the stride-2 backward contraction's operand format (fp16 mode):
 // q [B][ceil(C/32)][(H+1)*(W+1)][32 channels] = {h | l << 16} of xscale[b] * adjoint(in); see la_upfirdn2d.hip
 int la_fir4x4_adjoint_pack_f16(const float* in, unsigned* q, const float* xscale, int xs_fan, int B, int C, int H, int W, const float* f_host,
-                               float gain, hipStream_t stream, int flip_taps = 0);
+                               float gain, hipStream_t stream, int flip_taps = 0, int in_lo = 0, int in_hi = 0, int out_lo = 0, int out_hi = 0);
+// in_lo / in_hi: valid rows of `in` (the others read as zeros); out_lo / out_hi: row window of the (H+1)-row output (0 / 0 = all)
 // flip_taps = 1: the forward 4x4 FIR with pad 2 (same geometry: (H+1) x (W+1) outputs) instead of the adjoint of the pad-1 FIR

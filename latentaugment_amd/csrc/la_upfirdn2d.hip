@@ -580,6 +580,8 @@ struct FirPackArgs {
     int xs_fan;
     int B, C, H, W, Hz, Wz, nck, pad;
     float f[16];           // effective correlation taps (flip and gain folded in)
+    int in_lo, in_hi;      // valid rows of `in` (0 / 0 = all): the others read as zeros (a windowed producer left older contents there)
+    int out_lo, out_hi;    // row window of the output (0 / 0 = all): 8-row workgroup tiles without a wanted row write nothing
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void la_fir4x4_adj_pack_kernel(FirPackArgs a) {
@@ -588,6 +590,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void l
     const int xg = tid & 15, rs = (tid >> 4) & 1, cg = tid >> 5;
     const int b = blockIdx.z / a.nck, ck = blockIdx.z - b * a.nck;
     const int Xb = blockIdx.x * 64, Yb = blockIdx.y * 8;
+    if (a.out_hi > 0 && (Yb + 8 <= a.out_lo || Yb >= a.out_hi)) return;      // row window of the output: nothing wanted in these 8 rows
+    const int vin0 = a.in_hi > 0 ? a.in_lo : 0, vin1 = a.in_hi > 0 ? a.in_hi : a.H;
     const int X0 = Xb + xg * 4, Y0 = Yb + rs * 4;
     const float xs = la_xs_get(a.xscale, b, a.xs_fan);
     unsigned pk[4][4][4];                                 // [row][col][channel of the group]: {h | l << 16}
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void l
                 float v[8];                               // v[t] = in[iy][X0 - 2 + t], t = 0..6
 #pragma unroll
                 for (int t = 0; t < 8; ++t) v[t] = 0.f;
-                if (iy >= 0 && iy < a.H) {
+                if (iy >= vin0 && iy < vin1) {
                     const float* rp = ip + (long)iy * a.W;
                     if (lo_ok) { const float4 q = *reinterpret_cast<const float4*>(rp + X0 - 4); v[0] = q.z; v[1] = q.w; }
                     if (mid_ok) { const float4 q = *reinterpret_cast<const float4*>(rp + X0); v[2] = q.x; v[3] = q.y; v[4] = q.z; v[5] = q.w; }
@@ -674,11 +678,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void l
 
 // in [B][C][H][W] -> q [B][ceil(C/32)][(H+1)*(W+1)][32] packed fp16 pairs of  xscale[b] * (FIR adjoint of `in`)
 int la_fir4x4_adjoint_pack_f16(const float* in, unsigned* q, const float* xscale, int xs_fan, int B, int C, int H, int W, const float* f_host,
-                               float gain, hipStream_t stream, int flip_taps) {
+                               float gain, hipStream_t stream, int flip_taps, int in_lo, int in_hi, int out_lo, int out_hi) {
     LA_CHECK_ARG(in && q && xscale && f_host, "fir_adjoint_pack: null pointer");
     LA_CHECK_ARG(W % 4 == 0 && (((size_t)in | (size_t)q) & 15) == 0, "fir_adjoint_pack: rows must be 16-byte aligned");
     FirPackArgs a;
     a.in = in; a.out = q; a.xscale = xscale; a.xs_fan = xs_fan; a.B = B; a.C = C; a.H = H; a.W = W; a.Hz = H + 1; a.Wz = W + 1; a.nck = la_cdiv(C, 32);
+    a.in_lo = in_lo; a.in_hi = in_hi; a.out_lo = out_lo; a.out_hi = out_hi;
     a.pad = 2;         // adjoint of pad (1,1,1,1): fw - 1 - pad = 2 per side (upfirdn2d.py:255-266)
     // adjoint = correlation with the flipped filter = flip_filter of the forward op negated; the forward (flip_filter = False)
     // correlates with the flipped taps, so the adjoint correlates with the taps as given
@@ -687,7 +692,8 @@ int la_fir4x4_adjoint_pack_f16(const float* in, unsigned* q, const float* xscale
     for (int i = 0; i < 16; ++i) a.f[i] = gain * f_host[flip_taps ? 15 - i : i];
     dim3 grid(la_cdiv(a.Wz, 64), la_cdiv(a.Hz, 8), B * a.nck);
     LA_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "fir_adjoint_pack: grid too large");
-    const int slot = la_prof_open(LA_PC_FIR, 32.0 * B * C * (double)a.Hz * a.Wz, 4.0 * B * C * ((double)H * W + (double)a.Hz * a.Wz), stream);
+    const double wf = out_hi > 0 ? (double)((out_hi < a.Hz ? out_hi : a.Hz) - out_lo) / a.Hz : 1.0;
+    const int slot = la_prof_open(LA_PC_FIR, wf * 32.0 * B * C * (double)a.Hz * a.Wz, wf * 4.0 * B * C * ((double)H * W + (double)a.Hz * a.Wz), stream);
     hipLaunchKernelGGL(la_fir4x4_adj_pack_kernel, grid, dim3(256), 0, stream, a);
     la_prof_close(slot, stream);
     LA_CHECK_LAUNCH();
