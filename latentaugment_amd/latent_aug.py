@@ -493,10 +493,11 @@ class LatentAug:
 
     # ---- stream lanes: the local batch as two interleaved half-batch loops on two HIP streams
     def lanes_eligible(self, b):
-        """Two lanes need the FULL local batch (the criteria's 1/(m*n) is fixed per handle), an even one, and -- with the discriminator --
+        """Two lanes need the FULL local batch (the criteria's 1/(m*n) is fixed per handle), an even one of at least 4 (measured: +3 % at
+        4 x 256^2, +5 % at 4 x 512^2, +3.5 % at 16 x 256^2; four lanes lose), and -- with the discriminator --
         a multiple of 8: MinibatchStd groups sample n with n + b/4, n + 2b/4, n + 3b/4 (networks_stylegan2.py:577-592), and the even /
         odd halves of the batch keep exactly those groups only then."""
-        if self.stream_lanes == 1 or b != self._max_local or b < 8 or b % 2:
+        if self.stream_lanes == 1 or b != self._max_local or b < 4 or b % 2:
             return False
         if self.w_disc > 0 and b % 8:
             return False

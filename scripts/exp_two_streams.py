@@ -20,7 +20,8 @@ sys.argv = ['bench.py'] + sys.argv[2:]                                     # ben
 args = bench.apply_preset(bench.parse())
 sd, meta = synthetic.make_generator_state_dict(img_resolution=args.res, img_channels=2, channel_base=args.channel_base, seed=0)
 W, X = synthetic.make_banks(meta['num_ws'], res=args.res, M_w=args.M_w, M_x=args.M_x)
-w0 = synthetic.make_latents(8, seed=1).to(dev)
+NB = args.batch
+w0 = synthetic.make_latents(NB, seed=1).to(dev)
 
 
 extra = {}
@@ -40,8 +41,8 @@ def make(batch):
     return LatentAug('train', opt, '/tmp', [0], generator=sd, banks=banks, **extra)
 
 
-full = make(8)
-parts = [make(8 // NG) for _ in range(NG)]
+full = make(NB)
+parts = [make(NB // NG) for _ in range(NG)]
 streams = [torch.cuda.Stream(device=dev) for _ in range(NG)]
 random.seed(6)
 
@@ -52,7 +53,7 @@ def run_full():
 
 def run_parts(concurrent):
     outs = []
-    per = 8 // NG
+    per = NB // NG
     for k, (la, st) in enumerate(zip(parts, streams)):
         with torch.cuda.stream(st if concurrent else torch.cuda.current_stream()):
             if concurrent:
@@ -80,8 +81,8 @@ def timed(fn, n=6):
 t_full = timed(run_full)
 t_seq = timed(lambda: run_parts(False))
 t_con = timed(lambda: run_parts(True))
-print(f'one loop of 8: {1e3 * t_full:.1f} ms ({8 / t_full:.1f} images/s); {NG} loops of {8 // NG} one after the other: {1e3 * t_seq:.1f} ms '
-      f'({8 / t_seq:.1f}); on {NG} streams: {1e3 * t_con:.1f} ms ({8 / t_con:.1f} images/s)', flush=True)
+print(f'one loop of {NB}: {1e3 * t_full:.1f} ms ({NB / t_full:.1f} images/s); {NG} loops of {NB // NG} one after the other: {1e3 * t_seq:.1f} ms '
+      f'({NB / t_seq:.1f}); on {NG} streams: {1e3 * t_con:.1f} ms ({NB / t_con:.1f} images/s)', flush=True)
 a = run_parts(False); torch.cuda.synchronize()
 a2 = run_parts(False); torch.cuda.synchronize()
 b = run_parts(True); torch.cuda.synchronize()
@@ -116,7 +117,7 @@ if os.environ.get('LA_EXP_ONE_GRAPH', '1') != '0':
         for st in streams[1:]:
             cap.wait_stream(st)
     t_g = timed(g.replay)
-    print(f'both halves as branches of ONE captured graph: {1e3 * t_g:.1f} ms ({8 / t_g:.1f} images/s)', flush=True)
+    print(f'both halves as branches of ONE captured graph: {1e3 * t_g:.1f} ms ({NB / t_g:.1f} images/s)', flush=True)
     g.replay(); torch.cuda.synchronize()
     for k in range(NG):
         print(f'part {k}: one graph vs alone: max |d w| {float((a[k][1] - res[k][1]).abs().max()):.3e}', flush=True)
