@@ -92,6 +92,7 @@ def parse():
                         "the perceptual criterion is off; 1: never; 2: whenever the batch allows it)")
     p.add_argument('--whole-frames', action='store_true',
                    help='every loop step synthesises the whole frame (default: with the discriminator off, only the rows the criteria\'s centre crop depends on)')
+    p.add_argument('--no-window-columns', action='store_true', help='row windows only (the top block computes whole rows)')
     p.add_argument('--lanes-serial', action='store_true',
                    help='profiling aid: the two stream lanes one after the other on one stream (same launches, each alone on the chip)')
     p.add_argument('--no-overlap', action='store_true', help='discriminator and perceptual criterion one after the other instead of side by side')
@@ -125,7 +126,7 @@ def make_opt(args, local_rank, global_batch):
         preprocess_aug='center_random_crop', soft_aug=False, alpha=1.0, verbose_log=False, rand_aug=False,
         lower_bound_clip=False, p_thres=0.0, init_w='inv', final_noise_mode='random',
         precision=args.precision, hip_graph=not args.no_graph, overlap_criteria=not args.no_overlap,
-        stream_lanes=args.lanes if args.lanes == 'auto' else int(args.lanes), loop_window=not args.whole_frames)
+        stream_lanes=args.lanes if args.lanes == 'auto' else int(args.lanes), loop_window=not args.whole_frames, loop_window_columns=not args.no_window_columns)
 
 
 def cpu_model():

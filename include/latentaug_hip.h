@@ -167,6 +167,9 @@ int la_synth_set_operand_scale(la_synth* h, int from_data);
  * networks_stylegan2.py:270-330 followed down the blocks -- and leave the other rows of every buffer as they were.  la_synth_backward is
  * unchanged and expects an image gradient that is zero outside the window. */
 int la_synth_set_row_window(la_synth* h, int row_lo, int row_hi);
+/* Column window on top of the row window (0, 0 = all): the top block's conv1, the FIR in front of it and the FIR adjoint behind it follow it in
+ * whole 32-column tiles; every other kernel computes whole rows. */
+int la_synth_set_col_window(la_synth* h, int col_lo, int col_hi);
 int la_synth_get_precision(const la_synth* h);
 /* ws element (b,l,j) = ws[b*ws_bstride + l*ws_lstride + j] (ws_lstride = 0: W space, one w per sample).
  * noise_mode 0 'none', 1 'const', 2 explicit unit-variance tensors noises[layer] [B][res][res] ('random' drawn by the caller).
@@ -312,6 +315,8 @@ int la_latent_opt_set_overlap(la_latent_opt* h, int enable);
  * augmented latent (:303) is a whole frame.  Ignored while the discriminator (whole frame, :233-242) is active or per-step images are
  * traced.  Drops a captured step when the window changes. */
 int la_latent_opt_set_row_window(la_latent_opt* h, int row_lo, int row_hi);
+/* ... and the image columns [col_lo, col_hi) they read (the centre crop is a square: util_dataset.py:317-323); 0, 0 = all.  Used with the row window. */
+int la_latent_opt_set_col_window(la_latent_opt* h, int col_lo, int col_hi);
 /* verbose_log timers of the reference's first batch (time_latent / time_disc / time_pix / time_lpips / time_epoch,
  * util_latent_aug.py:221-272): with the time trace on, a run that asks for the loss scalars brackets the criteria of every step with
  * HIP events on the launch stream; la_latent_opt_get_times (after the stream has drained, or blocking) fills ms [steps][5] =

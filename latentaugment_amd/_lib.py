@@ -66,6 +66,7 @@ SIGNATURES = {
     'la_synth_set_precision': (_I, [_P, _I]),
     'la_synth_set_operand_scale': (_I, [_P, _I]),
     'la_synth_set_row_window': (_I, [_P, _I, _I]),
+    'la_synth_set_col_window': (_I, [_P, _I, _I]),
     'la_synth_get_precision': (_I, [_P]),
     'la_synth_forward': (_I, [_P, _P, _L, _L, _I, _I, _P, _P, _P]),
     'la_synth_backward': (_I, [_P, _P, _P, _P]),
@@ -114,6 +115,7 @@ SIGNATURES = {
     'la_latent_opt_set_grad_trace': (_I, [_P, _P]),
     'la_latent_opt_set_overlap': (_I, [_P, _I]),
     'la_latent_opt_set_row_window': (_I, [_P, _I, _I]),
+    'la_latent_opt_set_col_window': (_I, [_P, _I, _I]),
     'la_latent_opt_set_time_trace': (_I, [_P, _I]),
     'la_latent_opt_get_times': (_I, [_P, _P]),
     'la_latent_opt_set_lpips_preproc': (_I, [_P, _P, _P, _I]),

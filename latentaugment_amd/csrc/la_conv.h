@@ -121,6 +121,9 @@ struct LaConvArgs {
     // hold none of them return at once and write nothing (merged phases: the window counts rows of every phase's own grid).  The
     // caller guarantees that nobody reads the rows left out (la_synth.hip: the loop steps of a criterion that sees a crop only).
     int row_lo, row_hi;
+    // ... and a column window on top of it (halo kernel only; 0 / 0 = all columns): the wanted tiles are then the rectangle of 4 x 32 tiles
+    // that holds rows [row_lo, row_hi) x columns [col_lo, col_hi); needs a row window
+    int col_lo, col_hi;
     // Valid rows of the INPUT (16-bit direct kernels; 0 / 0 = all): rows outside [in_row_lo, in_row_hi) read as zeros, as rows outside the
     // image do -- the backward contractions behind a windowed producer, whose other rows hold older contents of a shared buffer while the
     // gradient there is exactly zero.  (Flat kernel: rows of the pre-split operand's grid.)

@@ -446,7 +446,8 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
         if (a.row_hi > 0 && a.Gy > 0) {      // row window: only the wanted rows are work (tiles hold 4 rows / 128 flattened pixels: counted as wanted)
             int lo = a.row_lo > 0 ? a.row_lo : 0, hi = a.row_hi < a.Gy ? a.row_hi : a.Gy;
             lo &= ~3; hi = (hi + 3) & ~3; if (hi > a.Gy) hi = a.Gy;
-            const double f = hi > lo ? (double)(hi - lo) / a.Gy : 0.0;
+            double f = hi > lo ? (double)(hi - lo) / a.Gy : 0.0;
+            if (a.col_hi > 0 && a.Gx > 0 && la_conv_bf16_uses_halo(a)) f *= (double)((((a.col_hi < a.Gx ? a.col_hi : a.Gx) + 31) & ~31) - (a.col_lo & ~31)) / a.Gx;
             gt *= f; gout *= f;
         }
         pflops = 2.0 * a.B * gt * a.M * (double)a.C;

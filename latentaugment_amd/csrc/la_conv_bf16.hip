@@ -1100,19 +1100,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     // row window (LaConvArgs::row_lo): the 4-row tiles that hold a wanted row are the run [t0, t0 + nt) of the row-major tile order; the
     // first nt workgroups of the launch take them -- in the XCD-aware order, so that the run is spread over all eight XCDs (a test on the
     // tile row alone left the XCDs that own the top and the bottom of the frame idle and the launch as long as before) -- the rest return
-    int t0 = 0, nt = (int)gridDim.x;
+    int nt = (int)gridDim.x;
+    int r0 = 0, c0 = 0, cw = tpr;                 // window rectangle in tiles: rows [r0, r1), columns [c0, c0 + cw)
     if (a.row_hi > 0) {
-        const int r0 = a.row_lo >> 2, r1 = ((a.row_hi < a.Gy ? a.row_hi : a.Gy) + 3) >> 2;
-        t0 = r0 * tpr; nt = (r1 - r0) * tpr;
-        if ((int)blockIdx.x >= nt) {      // this workgroup stands for one of the tiles outside the window: [0, t0) then [t0 + nt, all)
-            const int j = (int)blockIdx.x - nt;
-            la_conv_zero_partials<MT>(a, (int)blockIdx.z, (int)blockIdx.y * MT, j < t0 ? j : j + nt);
+        const int r1 = ((a.row_hi < a.Gy ? a.row_hi : a.Gy) + 3) >> 2;
+        r0 = a.row_lo >> 2;
+        if (a.col_hi > 0) { c0 = a.col_lo >> 5; cw = (((a.col_hi < a.Gx ? a.col_hi : a.Gx) + 31) >> 5) - c0; }
+        nt = (r1 - r0) * cw;
+        if ((int)blockIdx.x >= nt) {      // this workgroup stands for one of the tiles outside the window
+            int j = (int)blockIdx.x - nt, otile;
+            const int per = tpr - cw;             // outside tiles per window row
+            if (j < r0 * tpr) otile = j;
+            else if ((j -= r0 * tpr) < (r1 - r0) * per) { const int rr = j / per, k = j - rr * per; otile = (r0 + rr) * tpr + (k < c0 ? k : k + cw); }
+            else otile = r1 * tpr + (j - (r1 - r0) * per);
+            la_conv_zero_partials<MT>(a, (int)blockIdx.z, (int)blockIdx.y * MT, otile);
             return;
         }
     }
     int ntile = blockIdx.x;
     if ((nt & 7) == 0) ntile = (blockIdx.x & 7) * (nt >> 3) + (blockIdx.x >> 3);   // XCD-contiguous tile runs
-    ntile += t0;
+    if (a.row_hi > 0) { const int rr = ntile / cw; ntile = (r0 + rr) * tpr + c0 + (ntile - rr * cw); }
     const int m0 = blockIdx.y * MT;
     const int b = blockIdx.z;
     const int G = a.Gy * a.Gx;

@@ -35,6 +35,7 @@ int la_latent_opt_set_crop_pos(la_latent_opt* h, int x, int y);
 int la_latent_opt_set_graph(la_latent_opt* h, int enable);
 int la_latent_opt_set_overlap(la_latent_opt* h, int enable);
 int la_latent_opt_set_row_window(la_latent_opt* h, int row_lo, int row_hi);
+int la_latent_opt_set_col_window(la_latent_opt* h, int col_lo, int col_hi);
 int la_latent_opt_set_trace(la_latent_opt* h, float* w_trace, float* img_trace);
 int la_latent_opt_set_time_trace(la_latent_opt* h, int enable);
 int la_latent_opt_get_times(la_latent_opt* h, float* ms);

@@ -47,6 +47,7 @@ struct la_latent_opt {
     // feature net forward + backward) on a side stream, forked after the synthesis forward and joined before the crop gradient is
     // added into g_img -- same arithmetic, same summation order, captured into the step's graph as two parallel branches.  Possible
     // since no kernel of the library contains packed-FP32 arithmetic ('Two streams').
+    int wcol_lo, wcol_hi;   // ... and image columns (la_latent_opt_set_col_window)
     int win_lo, win_hi;     // image rows the criteria read (la_latent_opt_set_row_window; 0 / 0 = unknown: whole frames in every step)
     int overlap;            // 1 (default): fork / join when both criteria are active and no loss scalars / traces are asked for
     hipStream_t side_stream;
@@ -110,7 +111,7 @@ extern "C" int la_latent_opt_create(la_synth* g, int img_resolution, int img_cha
     la_adam_fill_table(h->adam_tab_host, cfg->steps, cfg->beta1, cfg->beta2);
     h->graph_mode = 1;
     h->overlap = 1;
-    h->win_lo = h->win_hi = 0;
+    h->win_lo = h->win_hi = 0; h->wcol_lo = h->wcol_hi = 0;
     *out = h;
     return LA_OK;
 }
@@ -151,6 +152,14 @@ extern "C" int la_latent_opt_set_row_window(la_latent_opt* h, int row_lo, int ro
     LA_CHECK_ARG(h && row_lo >= 0 && (row_hi == 0 ? row_lo == 0 : (row_hi > row_lo && row_hi <= h->R)), "latent_opt_set_row_window: bad window");
     if (row_lo != h->win_lo || row_hi != h->win_hi) drop_graph(h);
     h->win_lo = row_lo; h->win_hi = row_hi;
+    return LA_OK;
+}
+
+// ... and the image columns [col_lo, col_hi) they read (0, 0 = all): used together with the row window (la_synth_set_col_window)
+extern "C" int la_latent_opt_set_col_window(la_latent_opt* h, int col_lo, int col_hi) {
+    LA_CHECK_ARG(h && col_lo >= 0 && (col_hi == 0 ? col_lo == 0 : (col_hi > col_lo && col_hi <= h->R)), "latent_opt_set_col_window: bad window");
+    if (col_lo != h->wcol_lo || col_hi != h->wcol_hi) drop_graph(h);
+    h->wcol_lo = col_lo; h->wcol_hi = col_hi;
     return LA_OK;
 }
 
@@ -354,9 +363,10 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     // with per-step image snapshots, or with no window given
     const bool windowed = h->win_hi > 0 && !use_disc && !h->trace_img;
     struct WinGuard {      // (whole frames again on every way out, and for the final synthesis below)
-        la_synth* g; ~WinGuard() { (void)la_synth_set_row_window(g, 0, 0); }
+        la_synth* g; ~WinGuard() { (void)la_synth_set_row_window(g, 0, 0); (void)la_synth_set_col_window(g, 0, 0); }
     } win_guard{h->g};
     if ((rc = la_synth_set_row_window(h->g, windowed ? h->win_lo : 0, windowed ? h->win_hi : 0))) return rc;
+    if ((rc = la_synth_set_col_window(h->g, windowed ? h->wcol_lo : 0, windowed ? h->wcol_hi : 0))) return rc;
     if (want_losses && c.steps > 0) LA_HIP(hipMemsetAsync(h->losses, 0, (size_t)c.steps * 4 * sizeof(float), stream));
     // loss = -loss_latent - loss_pix - loss_lpips + loss_disc  (:270): the diversity terms enter with a minus sign
     const float lat_coef = h->Mw ? c.w_latent / ((float)h->Mw * nb * (float)h->num_ws * (float)wd) : 0.f;
@@ -482,7 +492,7 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
         }
     }
     if ((rc = la_broadcast_mix(h->w_opt, w0, w_aug_out, B, h->num_ws, wd, c.alpha, c.soft_aug, stream))) return rc;
-    if ((rc = la_synth_set_row_window(h->g, 0, 0))) return rc;      // the augmented image: a whole frame
+    if ((rc = la_synth_set_row_window(h->g, 0, 0)) || (rc = la_synth_set_col_window(h->g, 0, 0))) return rc;      // the augmented image: a whole frame
     if ((rc = la_synth_forward(h->g, w_aug_out, (long)h->num_ws * wd, wd, B, c.final_noise_mode, final_noises, img_out, stream)))
         return rc;
     if (losses_out && c.steps > 0)

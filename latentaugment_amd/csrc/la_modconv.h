@@ -20,15 +20,16 @@ int la_modconv3x3_fwd_ex(const float* x, long x_bstride, const float* in_pmax, i
                          int s_stride, const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                          const float* bias, int act, float alpha, float gain, float clamp, float* y, void* ws, size_t ws_bytes, int B,
                          int cin, int cout, int res, hipStream_t stream, const float* xscale = nullptr, const LaRgbFuse* rgb = nullptr,
-                         float* xs_out = nullptr, const float* xs_mult = nullptr, int row_lo = 0, int row_hi = 0);
-// row_lo / row_hi (0 / 0 = all): row window of the output, LaConvArgs::row_lo -- a hint: rows outside it may or may not be written
+                         float* xs_out = nullptr, const float* xs_mult = nullptr, int row_lo = 0, int row_hi = 0, int col_lo = 0, int col_hi = 0);
+// row_lo / row_hi, col_lo / col_hi (0 / 0 = all): row (and column) window of the output, LaConvArgs::row_lo / col_lo -- a hint: rows outside it may or may not be written
 // xs_out / xs_mult (optional): the operand scale of y for the contraction that consumes it (LaConvArgs::fwd_xs_out / fwd_xs_mult)
 int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, const void* wq, int precision, const float* s, int s_stride,
                              const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                              const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
                              float* scratch, float* y, float* y_pmax, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
                              hipStream_t stream, const float* xscale = nullptr, int scratch_pitch = 0, int scratch_xhalf = 0,
-                             float* xs_out = nullptr, const float* xs_mult = nullptr, int row_lo = 0, int row_hi = 0);
+                             float* xs_out = nullptr, const float* xs_mult = nullptr, int row_lo = 0, int row_hi = 0, int col_lo = 0, int col_hi = 0);
+// col_lo / col_hi: the FIR writes these columns of the row window only (the transposed conv computes whole rows)
 // row_lo / row_hi (0 / 0 = all; column-planar scratch only): row window of y -- the FIR writes exactly these rows, the transposed conv the
 // rows of its intermediate they read.  la_modconv3x3_up2_fwd_rows: the input rows such a call reads.
 void la_modconv3x3_up2_fwd_rows(int res, int row_lo, int row_hi, int* in_lo, int* in_hi);
@@ -56,7 +57,7 @@ struct LaSeamFuse {
 // Row windows of a backward launch (la_synth.hip; null = whole planes): rows [in_lo, in_hi) of gz are valid -- the others hold older
 // contents of a shared buffer where the gradient is exactly zero, and read as zeros -- and only rows [out_lo, out_hi) of gx are wanted
 // (0 / 0 = all; tiles outside write nothing but zero their style-gradient partials).  16-bit direct kernels; other forms ignore them.
-struct LaBwdRows { int in_lo, in_hi, out_lo, out_hi; };
+struct LaBwdRows { int in_lo, in_hi, out_lo, out_hi; int in_c0, in_c1, out_c0, out_c1; };      // (.. and columns: valid columns of gz, column window of gx; 0 / 0 = all)
 int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, const float* wb, const void* wq, int precision, const float* s, int s_stride,
                          const float* xin, long xin_bstride, float* gx, float* ds_part, void* ws, size_t ws_bytes, int B, int cin, int cout,
                          int res, hipStream_t stream, const LaSeamFuse* seam = nullptr, const float* xscale = nullptr, const LaBwdRows* rows = nullptr);

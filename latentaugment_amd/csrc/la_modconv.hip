@@ -42,8 +42,9 @@ int la_modconv3x3_fwd_ex(const float* x, long x_bstride, const float* in_pmax, i
                          int s_stride, const float* d, int d_stride, const float* noise, long noise_bstride, float noise_strength,
                          const float* bias, int act, float alpha, float gain, float clamp, float* y, void* ws, size_t ws_bytes, int B,
                          int cin, int cout, int res, hipStream_t stream, const float* xscale, const LaRgbFuse* rgb, float* xs_out,
-                         const float* xs_mult, int row_lo, int row_hi) {
+                         const float* xs_mult, int row_lo, int row_hi, int col_lo, int col_hi) {
     LA_CHECK_ARG(x && wf && y, "modconv_fwd: null pointer");
+    LA_CHECK_ARG(col_lo >= 0 && (col_hi == 0 || (row_hi > 0 && col_hi > col_lo && col_hi <= res)), "modconv_fwd: bad column window");
     LA_CHECK_ARG(row_lo >= 0 && (row_hi == 0 || (row_hi > row_lo && row_hi <= res)), "modconv_fwd: bad row window");
     LaConvArgs a; base_args(a);
     a.row_lo = row_lo; a.row_hi = row_hi;
@@ -82,10 +83,11 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
                              const float* bias, int act, float alpha, float gain, float clamp, const float* fir_host,
                              float* scratch, float* y, float* y_pmax, void* ws, size_t ws_bytes, int B, int cin, int cout, int res,
                              hipStream_t stream, const float* xscale, int scratch_pitch, int scratch_xhalf, float* xs_out, const float* xs_mult,
-                             int row_lo, int row_hi) {
+                             int row_lo, int row_hi, int col_lo, int col_hi) {
     LA_CHECK_ARG(x && wf && y && scratch && fir_host, "modconv_up2_fwd: null pointer");
     LA_CHECK_ARG(row_lo >= 0 && (row_hi == 0 || (row_hi > row_lo && row_hi <= res)), "modconv_up2_fwd: bad row window");
     if (scratch_xhalf == 0) row_lo = row_hi = 0;      // (only the planar FIR kernel honours a window)
+    if (row_hi == 0) col_lo = col_hi = 0;
     LA_CHECK_ARG(scratch_pitch == 0 || scratch_pitch >= res + 1, "modconv_up2_fwd: scratch pitch smaller than a row");
     LA_CHECK_ARG((scratch_xhalf == 0 && scratch_pitch == 0) || (scratch_xhalf >= res / 2 + 1 && scratch_pitch >= scratch_xhalf + res / 2),
                  "modconv_up2_fwd: bad column-planar scratch layout");
@@ -144,7 +146,7 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
     // FIR with pad (1,1,1,1) and gain up^2 = 4 (conv2d_resample.py:119-126), then the layer epilogue
     return la_upfirdn2d_modconv_epilogue(scratch, y, B, cout, res + 1, res + 1, fir_host, 4, 4, 1, 1, 1, 1, 4.f, d, d_stride,
                                          noise, noise_bstride, noise_strength, bias, act, alpha, gain, clamp, stream, y_pmax,
-                                         scratch_pitch, (long)scratch_pitch * (res + 1), scratch_xhalf, xs_out, xs_mult, row_lo, row_hi);
+                                         scratch_pitch, (long)scratch_pitch * (res + 1), scratch_xhalf, xs_out, xs_mult, row_lo, row_hi, col_lo, col_hi);
 }
 
 // input rows [in_lo, in_hi) (of the res/2-row input) that la_modconv3x3_up2_fwd_ex reads for the row window [row_lo, row_hi) of y: the phase
@@ -198,6 +200,7 @@ int la_modconv3x3_bwd_ex(const float* gz, const float* in_pmax, int in_nseg, con
     if (rows && precision != LA_PREC_F32) {
         LA_CHECK_ARG(rows->in_lo >= 0 && rows->in_hi <= res && rows->out_lo >= 0 && rows->out_hi <= res, "modconv_bwd: bad row windows");
         a.in_row_lo = rows->in_lo; a.in_row_hi = rows->in_hi; a.row_lo = rows->out_lo; a.row_hi = rows->out_hi;
+        if (rows->out_hi > 0) { a.col_lo = rows->out_c0; a.col_hi = rows->out_c1; }      // (gz is valid in every column here: no input column mask)
     }
     return la_conv_launch(a, stream);
 }
@@ -250,7 +253,8 @@ int la_modconv3x3_up2_bwd_ex(const float* gz, const float* gz_pmax, int gz_nseg,
             a.in_row_lo = zlo; a.in_row_hi = zhi;
         }
         if (rows) { a.row_lo = rows->out_lo; a.row_hi = rows->out_hi; }
-        if ((rc = la_fir4x4_adjoint_pack_f16(gz, q, xscale, xs_fan, B, cout, res, res, fir_host, 4.f, stream, 0, rows ? rows->in_lo : 0, rows ? rows->in_hi : 0, zlo, zhi))) return rc;
+        if ((rc = la_fir4x4_adjoint_pack_f16(gz, q, xscale, xs_fan, B, cout, res, res, fir_host, 4.f, stream, 0, rows ? rows->in_lo : 0, rows ? rows->in_hi : 0, zlo, zhi,
+                                             rows ? rows->in_c0 : 0, rows ? rows->in_c1 : 0))) return rc;
         a.in = gz;                       // (not read: the launch takes its operand from in_q)
         a.in_q = q; a.acc_scale_x = xscale; a.acc_scale_fan = xs_fan;
         a.ws = static_cast<char*>(ws) + fused_need; a.ws_bytes = ws_bytes - fused_need;

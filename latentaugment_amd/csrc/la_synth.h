@@ -16,6 +16,7 @@ void la_synth_destroy(la_synth* h);
 int la_synth_set_precision(la_synth* h, int precision);
 int la_synth_get_precision(const la_synth* h);
 int la_synth_set_row_window(la_synth* h, int row_lo, int row_hi);
+int la_synth_set_col_window(la_synth* h, int col_lo, int col_hi);
 int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, long ws_lstride, int B, int noise_mode,
                      const float* const* noises, float* img_out, hipStream_t stream);
 int la_synth_backward(la_synth* h, const float* g_img, float* dws, hipStream_t stream);

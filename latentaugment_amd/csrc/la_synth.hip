@@ -64,6 +64,8 @@ struct la_synth {
     int precision;
     float* final_img;   // where the last forward put the full-resolution image
     int win_lo, win_hi;  // row window of the image the next forward passes are asked for (la_synth_set_row_window; 0 / 0 = the whole image)
+    int wcol_lo, wcol_hi;      // ... and its column window (la_synth_set_col_window; top block only)
+    int fw_c0, fw_c1;          // column window (32-column tiles) of the top block's conv1 output in the LAST forward pass (0 / 0 = all)
     int fw_lo[2 * MAX_BLOCKS], fw_hi[2 * MAX_BLOCKS];      // row windows of the conv outputs in the LAST forward pass (0 / 0 = whole plane)
 };
 
@@ -256,7 +258,7 @@ extern "C" int la_synth_create(int img_resolution, int img_channels, int w_dim, 
     layout(h, workspace, workspace_bytes, &need);
     if (need > workspace_bytes) { free(h); la_set_error("synth_create: workspace too small"); return LA_ERR_WORKSPACE; }
     h->clamp = conv_clamp;
-    h->win_lo = h->win_hi = 0;
+    h->win_lo = h->win_hi = 0; h->wcol_lo = h->wcol_hi = 0; h->fw_c0 = h->fw_c1 = 0;
     // every buffer starts as zeros: a forward pass restricted to a row window (la_synth_set_row_window) leaves the other rows of its saved
     // activations as they were, and the backward pass multiplies them with gradients that are exactly zero there -- they must be finite
     if (hipMemsetAsync(workspace, 0, need, stream) != hipSuccess) { free(h); la_set_error("synth_create: clearing the workspace failed"); return LA_ERR_HIP; }
@@ -315,6 +317,15 @@ extern "C" int la_synth_set_row_window(la_synth* h, int row_lo, int row_hi) {
     return LA_OK;
 }
 
+// Column window of the image on top of the row window (0, 0 = all columns).  Only the TOP block follows it -- its conv1 (forward: the 32-column
+// tiles that hold the window; backward: the same tiles, the gradient of its input is non-zero one column further at most), the FIR that
+// feeds it and the FIR adjoint behind it (which reads the other columns as zeros); every other kernel computes whole rows.
+extern "C" int la_synth_set_col_window(la_synth* h, int col_lo, int col_hi) {
+    LA_CHECK_ARG(h && col_lo >= 0 && (col_hi == 0 ? col_lo == 0 : (col_hi > col_lo && col_hi <= h->R)), "synth_set_col_window: bad window");
+    h->wcol_lo = col_lo; h->wcol_hi = col_hi;
+    return LA_OK;
+}
+
 #ifdef LA_DEV
 // development build: the transposed-conv intermediate of the LAST up-sampling layer that ran (column-planar rows; scripts/exp_overlap_*.py)
 extern "C" const float* la_synth_dev_zt(const la_synth* h) { return h ? h->zT : nullptr; }
@@ -368,6 +379,17 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
         }
     }
     for (int i = 0; i < h->nconv; ++i) { h->fw_lo[i] = wlo[i]; h->fw_hi[i] = whi[i]; }
+    // column window: the top block's conv1 in whole 32-column tiles, the FIR in front of it one column more on either side.  Needs a tile
+    // column to spare on both sides (the gradient of conv1's input reaches one column beyond the image window: it must stay inside the tiles)
+    int c1lo = 0, c1hi = 0, c0lo = 0, c0hi = 0;
+    h->fw_c0 = h->fw_c1 = 0;
+    if (h->wcol_hi > 0 && whi[h->nconv - 1] > 0 && h->R >= 64) {
+        c1lo = h->wcol_lo & ~31; c1hi = (h->wcol_hi + 31) & ~31; if (c1hi > h->R) c1hi = h->R;
+        if (h->wcol_lo - 1 >= c1lo && h->wcol_hi + 1 <= c1hi && (c1lo > 0 || c1hi < h->R)) {
+            c0lo = c1lo - 1 > 0 ? c1lo - 1 : 0; c0hi = c1hi + 1 < h->R ? c1hi + 1 : h->R;
+            h->fw_c0 = c1lo; h->fw_c1 = c1hi;
+        } else c1lo = c1hi = 0;
+    }
     int ci = 0;
     const float* x = h->cst;
     long x_bstride = 0;
@@ -401,14 +423,15 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
                 rc = la_modconv3x3_fwd_ex(x, x_bstride, nullptr, 0, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                           L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f, sq2,
                                           h->clamp, L.y, h->cws, h->cws_bytes, B, L.cin, L.cout, res, stream, fwd_row(ci),
-                                          (fuse_rgb && q == nl - 1) ? &rf : nullptr, fwd_row(ci + 1), fwd_mult(ci + 1), wlo[ci], whi[ci]);
+                                          (fuse_rgb && q == nl - 1) ? &rf : nullptr, fwd_row(ci + 1), fwd_mult(ci + 1), wlo[ci], whi[ci],
+                                          ci == h->nconv - 1 ? c1lo : 0, ci == h->nconv - 1 ? c1hi : 0);
             } else {
                 rc = la_modconv3x3_up2_fwd_ex(x, x_bstride, L.wf, L.wqf, h->precision, h->s_all + L.s_off, h->S, h->d_all + L.d_off, h->Dt,
                                               L.noise_used, L.noise_bstride, L.noise_strength, L.bias, LA_ACT_LRELU, 0.2f,
                                               sq2, h->clamp, h->fir, h->zT, L.y, nullptr, h->cws, h->cws_bytes, B, L.cin,
                                               L.cout, res, stream, fwd_row(ci),
                                               zt_dense ? 0 : 2 * zt_xhalf(res), zt_dense ? 0 : zt_xhalf(res), fwd_row(ci + 1), fwd_mult(ci + 1),
-                                              wlo[ci], whi[ci]);
+                                              wlo[ci], whi[ci], ci == h->nconv - 2 ? c0lo : 0, ci == h->nconv - 2 ? c0hi : 0);
             }
             if (rc) return rc;
             x = L.y; x_bstride = (long)L.cout * res * res;
@@ -472,7 +495,10 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
         // W1 = window of this block's conv1 output (= valid rows of the gradient G0 that reaches it), R1 = the 4-row tiles around the
         // window of conv0's output (what conv1's backward contraction writes into G1), Wb = window of the block below's conv1 output
         const bool win = bw && k > 0 && h->fw_hi[ci] > 0;
-        LaBwdRows rw1{0, 0, 0, 0}, rw0{0, 0, 0, 0};
+        LaBwdRows rw1{0, 0, 0, 0, 0, 0, 0, 0}, rw0{0, 0, 0, 0, 0, 0, 0, 0};
+        if (win && k == h->nblocks - 1 && h->fw_c1 > 0) {      // top block: conv1's backward contraction writes the window's tile columns, the FIR adjoint reads the others as zeros
+            rw1.out_c0 = h->fw_c0; rw1.out_c1 = h->fw_c1; rw0.in_c0 = h->fw_c0; rw0.in_c1 = h->fw_c1;
+        }
         if (win) {
             rw1.in_lo = h->fw_lo[ci]; rw1.in_hi = h->fw_hi[ci];
             r4(h->fw_lo[ci - 1], h->fw_hi[ci - 1], res, &rw1.out_lo, &rw1.out_hi);

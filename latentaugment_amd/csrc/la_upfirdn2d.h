@@ -25,7 +25,7 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
                                   const float* demod, int demod_stride, const float* noise, long noise_bstride,
                                   float noise_strength, const float* bias, int act, float alpha, float gain,
                                   float clamp, hipStream_t stream, float* pmax = nullptr, int in_pitch = 0, long in_plane = 0, int in_xhalf = 0,
-                                  float* xs_out = nullptr, const float* xs_mult = nullptr, int row_lo = 0, int row_hi = 0);
+                                  float* xs_out = nullptr, const float* xs_mult = nullptr, int row_lo = 0, int row_hi = 0, int col_lo = 0, int col_hi = 0);
 // row_lo / row_hi (column-planar input only; 0 / 0 = all): only output rows [row_lo, row_hi) are computed and written
 // xs_out / xs_mult (optional): slot rows [B][LA_XS_FAN] of the fp16 operand scale of `out` for the contraction that consumes it
 // (la_common.h): lowered by the producing workgroups to pow2(xs_mult[b] * max |out|)
@@ -35,6 +35,6 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
 // FIR adjoint of an up-sampling layer written straight into the stride-2 backward contraction's operand format (fp16 mode):
 // q [B][ceil(C/32)][(H+1)*(W+1)][32 channels] = {h | l << 16} of xscale[b] * adjoint(in); see la_upfirdn2d.hip
 int la_fir4x4_adjoint_pack_f16(const float* in, unsigned* q, const float* xscale, int xs_fan, int B, int C, int H, int W, const float* f_host,
-                               float gain, hipStream_t stream, int flip_taps = 0, int in_lo = 0, int in_hi = 0, int out_lo = 0, int out_hi = 0);
+                               float gain, hipStream_t stream, int flip_taps = 0, int in_lo = 0, int in_hi = 0, int out_lo = 0, int out_hi = 0, int in_c0 = 0, int in_c1 = 0);
 // in_lo / in_hi: valid rows of `in` (the others read as zeros); out_lo / out_hi: row window of the (H+1)-row output (0 / 0 = all)
 // flip_taps = 1: the forward 4x4 FIR with pad 2 (same geometry: (H+1) x (W+1) outputs) instead of the adjoint of the pad-1 FIR

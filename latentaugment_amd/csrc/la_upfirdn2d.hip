@@ -27,6 +27,7 @@ struct FirArgs {
     float* xs_out;               // optional (4x4 stride-1 kernels): slot rows [B][LA_XS_FAN] of the fp16 operand scale of `out` for the
     const float* xs_mult;        //   contraction that consumes it: every wave lowers its sample's row to pow2(xs_mult[b] * its max |out|)
     int row_lo, row_hi;          // row window (planar vector kernel; 0 / 0 = all): only output rows [row_lo, row_hi) are computed and written
+    int col_lo, col_hi;          // ... and only the 4-column groups that hold a column of [col_lo, col_hi) (0 / 0 = all)
 };
 
 __global__ __launch_bounds__(256) void la_upfirdn2d_kernel(FirArgs a) {
@@ -168,7 +169,7 @@ static int fir_fill(FirArgs& a, const float* in, float* out, int B, int C, int H
     LA_CHECK_ARG(upW >= fw && upH >= fh, "upfirdn2d: upsampled image smaller than the filter");
     *Wout = (upW - fw + dnx) / dnx;   // upfirdn2d.cpp:35-36
     *Hout = (upH - fh + dny) / dny;
-    a.in = in; a.out = out; a.P = B * C; a.C = C; a.pmax = nullptr; a.xs_out = nullptr; a.xs_mult = nullptr; a.row_lo = a.row_hi = 0;
+    a.in = in; a.out = out; a.P = B * C; a.C = C; a.pmax = nullptr; a.xs_out = nullptr; a.xs_mult = nullptr; a.row_lo = a.row_hi = 0; a.col_lo = a.col_hi = 0;
     a.in_pitch = Win; a.in_plane = (long)Hin * Win; a.in_xhalf = 0;
     a.Hin = Hin; a.Win = Win; a.Hout = *Hout; a.Wout = *Wout;
     a.upx = upx; a.upy = upy; a.dnx = dnx; a.dny = dny; a.padx0 = padx0; a.pady0 = pady0;
@@ -201,7 +202,12 @@ __global__ __launch_bounds__(256) void la_fir4x4_s1p_kernel(FirArgs a, float4 fx
     const int per_plane = w4 * strips;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int p = (int)(gid / per_plane);
-    const bool live = p < a.P;
+    bool live = p < a.P;
+    if (live && a.col_hi > 0) {      // column window (FirArgs::col_lo): a 4-column group without a wanted column does nothing
+        const int within = (int)(gid - (long)p * per_plane);
+        const int xq = (within - (within / w4) * w4) * 4;
+        live = xq + 4 > a.col_lo && xq < a.col_hi;
+    }
     if (!live && !a.xs_out) return;
     const int b = (live ? p : a.P - 1) / a.C;
     float omax = 0.f;
@@ -453,6 +459,7 @@ static int fir_launch(const FirArgs& a, hipStream_t stream) {
     // launch profiler: one read of the input planes + one write of the output planes
     double f = 1.0;      // (row window: the wanted rows only)
     if (a.row_hi > 0 && a.in_xhalf > 0) { const int lo = a.row_lo > 0 ? a.row_lo : 0, hi = a.row_hi < a.Hout ? a.row_hi : a.Hout; f = hi > lo ? (double)(hi - lo) / a.Hout : 0.0; }
+    if (a.col_hi > 0 && a.in_xhalf > 0) f *= (double)((((a.col_hi < a.Wout ? a.col_hi : a.Wout) + 3) & ~3) - (a.col_lo & ~3)) / a.Wout;
     const int slot = la_prof_open(LA_PC_FIR, f * 2.0 * a.fw * a.fh * (double)a.P * a.Hout * a.Wout,
                                   f * 4.0 * a.P * ((double)a.Hin * a.Win + (double)a.Hout * a.Wout), stream);
     const int rc = fir_launch_inner(a, stream);
@@ -545,7 +552,7 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
                                   const float* demod, int demod_stride, const float* noise, long noise_bstride,
                                   float noise_strength, const float* bias, int act, float alpha, float gain,
                                   float clamp, hipStream_t stream, float* pmax, int in_pitch, long in_plane, int in_xhalf, float* xs_out,
-                                  const float* xs_mult, int row_lo, int row_hi) {
+                                  const float* xs_mult, int row_lo, int row_hi, int col_lo, int col_hi) {
     FirArgs a; int ho, wo;
     int rc = fir_fill(a, in, out, B, C, Hin, Win, f_host, fh, fw, 1, 1, 1, 1, padx0, padx1, pady0, pady1, 0, fir_gain,
                       &ho, &wo);
@@ -557,7 +564,7 @@ int la_upfirdn2d_modconv_epilogue(const float* in, float* out, int B, int C, int
     if (in_pitch > 0) { a.in_pitch = in_pitch; a.in_plane = in_plane; a.in_xhalf = in_xhalf; }
     LA_CHECK_ARG(!xs_out || (fw == 4 && fh == 4), "upfirdn2d: the operand-scale hand-over exists for the 4x4 stride-1 kernels only");
     a.xs_out = xs_out; a.xs_mult = xs_mult;
-    if (in_xhalf > 0) { a.row_lo = row_lo; a.row_hi = row_hi; }      // (the planar vector kernel honours the window; the others compute every row)
+    if (in_xhalf > 0) { a.row_lo = row_lo; a.row_hi = row_hi; a.col_lo = col_lo; a.col_hi = col_hi; }      // (the planar vector kernel honours the window; the others compute everything)
     return fir_launch(a, stream);
 }
 
@@ -581,6 +588,7 @@ struct FirPackArgs {
     int B, C, H, W, Hz, Wz, nck, pad;
     float f[16];           // effective correlation taps (flip and gain folded in)
     int in_lo, in_hi;      // valid rows of `in` (0 / 0 = all): the others read as zeros (a windowed producer left older contents there)
+    int in_c0, in_c1;      // valid columns of `in` likewise (multiples of 4; 0 / 0 = all)
     int out_lo, out_hi;    // row window of the output (0 / 0 = all): 8-row workgroup tiles without a wanted row write nothing
 };
 
@@ -595,7 +603,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void l
     const int X0 = Xb + xg * 4, Y0 = Yb + rs * 4;
     const float xs = la_xs_get(a.xscale, b, a.xs_fan);
     unsigned pk[4][4][4];                                 // [row][col][channel of the group]: {h | l << 16}
-    const bool lo_ok = X0 - 4 >= 0, mid_ok = X0 < a.W, hi_ok = X0 + 4 < a.W;
+    const int vc0 = a.in_c1 > 0 ? a.in_c0 : 0, vc1 = a.in_c1 > 0 ? a.in_c1 : a.W;
+    const bool lo_ok = X0 - 4 >= vc0 && X0 - 4 < vc1, mid_ok = X0 >= vc0 && X0 < vc1, hi_ok = X0 + 4 >= vc0 && X0 + 4 < vc1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = ck * 32 + cg * 4 + j;
@@ -678,12 +687,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void l
 
 // in [B][C][H][W] -> q [B][ceil(C/32)][(H+1)*(W+1)][32] packed fp16 pairs of  xscale[b] * (FIR adjoint of `in`)
 int la_fir4x4_adjoint_pack_f16(const float* in, unsigned* q, const float* xscale, int xs_fan, int B, int C, int H, int W, const float* f_host,
-                               float gain, hipStream_t stream, int flip_taps, int in_lo, int in_hi, int out_lo, int out_hi) {
+                               float gain, hipStream_t stream, int flip_taps, int in_lo, int in_hi, int out_lo, int out_hi, int in_c0, int in_c1) {
     LA_CHECK_ARG(in && q && xscale && f_host, "fir_adjoint_pack: null pointer");
     LA_CHECK_ARG(W % 4 == 0 && (((size_t)in | (size_t)q) & 15) == 0, "fir_adjoint_pack: rows must be 16-byte aligned");
     FirPackArgs a;
     a.in = in; a.out = q; a.xscale = xscale; a.xs_fan = xs_fan; a.B = B; a.C = C; a.H = H; a.W = W; a.Hz = H + 1; a.Wz = W + 1; a.nck = la_cdiv(C, 32);
-    a.in_lo = in_lo; a.in_hi = in_hi; a.out_lo = out_lo; a.out_hi = out_hi;
+    a.in_lo = in_lo; a.in_hi = in_hi; a.out_lo = out_lo; a.out_hi = out_hi; a.in_c0 = in_c0; a.in_c1 = in_c1;
+    LA_CHECK_ARG(in_c0 % 4 == 0 && in_c1 % 4 == 0, "fir_adjoint_pack: the column mask is in groups of 4");
     a.pad = 2;         // adjoint of pad (1,1,1,1): fw - 1 - pad = 2 per side (upfirdn2d.py:255-266)
     // adjoint = correlation with the flipped filter = flip_filter of the forward op negated; the forward (flip_filter = False)
     // correlates with the flipped taps, so the adjoint correlates with the taps as given

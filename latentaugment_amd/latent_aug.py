@@ -337,6 +337,8 @@ class LatentAug:
                 (self.w_lpips <= 0 or self.preprocess in ('center_crop', 'center_random_crop')):
             self.loop_window = (off, off + crop)
             _lib.check(lib.la_latent_opt_set_row_window(h, off, off + crop), 'la_latent_opt_set_row_window')
+            if getattr(opt, 'loop_window_columns', True):      # (the crop is a square; the top block follows its columns too)
+                _lib.check(lib.la_latent_opt_set_col_window(h, off, off + crop), 'la_latent_opt_set_col_window')
         self.disc = None
         if self.w_disc > 0:
             if discriminator is None:

@@ -16,6 +16,7 @@ from latentaugment_amd.latent_aug import LatentAug                          # no
 
 dev = torch.device('cuda', 0)
 NG = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+OFFSET_US = float(os.environ.get('LA_EXP_LANE_OFFSET_US', '0'))
 sys.argv = ['bench.py'] + sys.argv[2:]                                     # bench arguments after the stream count (--preset E, --w-disc 0.01)
 args = bench.apply_preset(bench.parse())
 sd, meta = synthetic.make_generator_state_dict(img_resolution=args.res, img_channels=2, channel_base=args.channel_base, seed=0)
@@ -58,6 +59,8 @@ def run_parts(concurrent):
         with torch.cuda.stream(st if concurrent else torch.cuda.current_stream()):
             if concurrent:
                 st.wait_stream(torch.cuda.default_stream(dev))
+                if k > 0 and OFFSET_US > 0:      # de-phasing experiment: lane k starts k * OFFSET_US later (LA_EXP_LANE_OFFSET_US)
+                    torch.cuda._sleep(int(k * OFFSET_US * 2100))
             outs.append(la.run_local(w0[k::NG].contiguous(), crop_pos=(0, 0))[:2])      # interleaved: keeps D's MinibatchStd groups (n, n+2, ..)
         if not concurrent:
             torch.cuda.synchronize()
