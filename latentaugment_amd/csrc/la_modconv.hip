@@ -150,13 +150,14 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
 }
 
 // input rows [in_lo, in_hi) (of the res/2-row input) that la_modconv3x3_up2_fwd_ex reads for the row window [row_lo, row_hi) of y: the phase
-// rows of the window (above), widened by the 128-pixel granularity of the contraction's flattened tiles, plus the tap row above
+// rows of the window (above) plus the tap row above
 void la_modconv3x3_up2_fwd_rows(int res, int row_lo, int row_hi, int* in_lo, int* in_hi) {
     const int hin = res / 2;
     const int zlo = row_lo - 1 > 0 ? row_lo - 1 : 0, zhi = row_hi + 2 < res + 1 ? row_hi + 2 : res + 1;
     const int qlo = zlo >> 1, qhi = ((zhi - 1) >> 1) + 1;
-    const int slack = (128 + hin - 1) / hin;      // rows a 128-pixel tile can reach beyond the window (phase grids are hin or hin + 1 wide)
-    int lo = qlo - slack - 1, hi = qhi + slack;
+    // (the flattened 128-pixel tiles at the ends of the window reach into phase rows outside it; what they compute there from rows the
+    //  producer did not deliver lands in intermediate rows that the FIR never reads)
+    int lo = qlo - 1, hi = qhi;
     *in_lo = lo > 0 ? lo : 0; *in_hi = hi < hin ? hi : hin;
 }
 
