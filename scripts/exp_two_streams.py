@@ -45,6 +45,22 @@ def make(batch):
 full = make(NB)
 parts = [make(NB // NG) for _ in range(NG)]
 streams = [torch.cuda.Stream(device=dev) for _ in range(NG)]
+CU_MASK = os.environ.get('LA_EXP_CU_MASK', '')      # 'half': lane k gets CUs [128 k, 128 k + 128); 'alt': even / odd 32-bit words of the mask
+if CU_MASK:
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    streams = []
+    for k in range(NG):
+        words = [0] * 8
+        for wd in range(8):
+            if (CU_MASK == 'half' and (wd // (8 // NG)) == k) or (CU_MASK == 'alt' and wd % NG == k):
+                words[wd] = 0xFFFFFFFF
+        arr = (ctypes.c_uint32 * 8)(*words)
+        st = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, arr)
+        assert rc == 0, rc
+        streams.append(torch.cuda.ExternalStream(st.value, device=dev))
+    print('CU-masked streams:', CU_MASK, flush=True)
 random.seed(6)
 
 
