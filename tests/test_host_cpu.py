@@ -244,3 +244,29 @@ def test_curve_png_writer(tmp_path):
     assert first[:, 0].mean() > last[:, 0].mean() + 100           # image rows grow downwards: the last value sits far above the first
     write_curve_png(str(path), [3.0])                              # a single epoch still gives a picture
     write_curve_png(str(path), [])
+
+
+def test_stream_lane_rule():
+    """LatentAug.lanes_eligible (host logic, no GPU): two lanes take the FULL, even local batch of >= 4; with the discriminator a multiple
+    of 8 (MinibatchStd groups sample n with n + b/4, n + 2b/4, n + 3b/4: the even / odd halves keep them only then); 'auto' not with the
+    perceptual criterion (the discriminator and the perceptual branch run side by side inside one loop instead); 1 never."""
+    import types
+    from latentaugment_amd.latent_aug import LatentAug
+
+    def rule(b, max_local, lanes='auto', w_disc=0.0, w_lpips=0.0):
+        me = types.SimpleNamespace(stream_lanes=lanes, _max_local=max_local, w_disc=w_disc, w_lpips=w_lpips)
+        return LatentAug.lanes_eligible(me, b)
+
+    assert rule(8, 8) and rule(4, 4) and rule(16, 16) and rule(6, 6)
+    assert not rule(2, 2) and not rule(5, 5) and not rule(4, 8)            # too small, odd, not the full batch
+    assert rule(8, 8, w_disc=0.01) and rule(16, 16, w_disc=0.01) and not rule(4, 4, w_disc=0.01) and not rule(12, 12, w_disc=0.01)
+    assert not rule(8, 8, w_lpips=10.0) and rule(8, 8, lanes=2, w_lpips=10.0) and not rule(8, 8, lanes=1)
+    # the MinibatchStd claim itself: groups of the reference's reshape(G, -1, ...) against the groups inside the even / odd halves
+    for n in (8, 16, 24):
+        g = min(4, n)
+        groups = {frozenset(m + j * (n // g) for j in range(g)) for m in range(n // g)}
+        for half in (range(0, n, 2), range(1, n, 2)):
+            half = list(half)
+            gh = min(4, len(half))
+            for m in range(len(half) // gh):
+                assert frozenset(half[m + j * (len(half) // gh)] for j in range(gh)) in groups
