@@ -422,6 +422,7 @@ def main():
     barrier()
     elapsed = time.time() - t0
     assert out['A'].shape == (gb, 1, args.res, args.res)
+    lanes_used, launch_mode = aug.latent_aug.lanes_active, LAUNCH_MODES[aug.latent_aug.graph_state]      # (of the timed region: the roofline leg below also runs other modes)
     multi = None
     if use_dist:
         # what a scaling curve below the ideal is made of (rank 0 prints it): every rank's own time for the K steps, the time of its
@@ -463,8 +464,8 @@ def main():
                                f"reference's pairwise-L2 GEMM over the banks runs only when loss scalars are requested: the API returns none), "
                                f'contraction={args.precision}' + (', fp16 operand scales from the data of every pass (lowered by the producing kernels)' if args.precision == 'f16x2' else '') + ', '
                                f'timed call = set_input + LatentAugment.forward + get_output, '
-                               'launch mode = ' + LAUNCH_MODES[aug.latent_aug.graph_state] +
-                               (', two stream lanes (samples 0,2,4,.. and 1,3,5,.. as two half-batch loops on two HIP streams)' if aug.latent_aug.lanes_active else '') +
+                               'launch mode = ' + launch_mode +
+                               (', two stream lanes (samples 0,2,4,.. and 1,3,5,.. as two half-batch loops on two HIP streams)' if lanes_used else '') +
                                (', loop steps synthesise the rows the criteria read (image rows %d..%d, the centre crop, and what they depend on in the '
                                 'blocks at >= 64^2); the final synthesis is a whole frame' % (aug.latent_aug.loop_window[0], aug.latent_aug.loop_window[1] - 1)
                                 if aug.latent_aug.loop_window else ', whole frames in every loop step'),
