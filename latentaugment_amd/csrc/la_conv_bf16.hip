@@ -306,7 +306,7 @@ int la_conv_xscale_from_pmax(const float* pmax, int nseg, const float* scale, in
 // bf16: 8 B per element {h | m<<16, l}.  Channels past C are zeros.  The flat kernel's gather thread (pixel, 16-channel half) then reads its
 // operand as 64 / 128 contiguous bytes (4 / 8 dwordx4) instead of 16 strided dwords, and a stride-2 gather wastes no sectors.
 // One workgroup = 32 channels x 64 pixels, transposed through LDS.
-struct LaInMask { const float* y; int act; float alpha, gain, clamp, in_gain; };      // LaConvArgs::in_mask_* / in_gain
+struct LaInMask { const float* y; int act; float alpha, gain, clamp, in_gain; long p_lo, p_hi; };      // LaConvArgs::in_mask_* / in_gain; pixel range that is read (in_row_lo), 0 / 0 = all
 template <bool F16>
 __global__ __launch_bounds__(256) void la_presplit_t_kernel(const float* __restrict__ in, long in_bstride,
                                                            const float* __restrict__ scale, int scale_stride,
@@ -316,6 +316,7 @@ __global__ __launch_bounds__(256) void la_presplit_t_kernel(const float* __restr
     __shared__ unsigned tile[EW][64][33];
     const int cc = blockIdx.y, b = blockIdx.z, nck = gridDim.y;
     const long p0 = (long)blockIdx.x * 64;
+    if (mk.p_hi > 0 && (p0 + 64 <= mk.p_lo || p0 >= mk.p_hi)) return;      // rows the launch reads as zeros anyway (LaConvArgs::in_row_lo): not copied
     const float xs = F16 ? la_xs_get(xscale, b, xs_fan) : 1.f;
     {
         const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
@@ -444,7 +445,8 @@ int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
     char* base = static_cast<char*>(a.ws);
     const size_t ws_bytes = a.ws_bytes;
     const dim3 pgrid((unsigned)la_cdiv(HW, 64), (unsigned)la_cdiv(a.C, KCB), (unsigned)a.B);
-    const LaInMask mk{a.in_mask_y, a.in_mask_act, a.in_mask_alpha, a.in_mask_gain, a.in_mask_clamp, a.in_gain != 0.f ? a.in_gain : 1.f};
+    const LaInMask mk{a.in_mask_y, a.in_mask_act, a.in_mask_alpha, a.in_mask_gain, a.in_mask_clamp, a.in_gain != 0.f ? a.in_gain : 1.f,
+                      a.in_row_hi > 0 ? (long)a.in_row_lo * a.Win : 0, a.in_row_hi > 0 ? (long)a.in_row_hi * a.Win : 0};
     LA_CHECK_ARG((!a.in_mask_y && mk.in_gain == 1.f) || a.acc_scale_x || a.precision != LA_PREC_F16X2, "conv: an input mask needs a preset operand scale");
     if (a.precision == LA_PREC_F16X2) {
         int rc = prepare_scale(a, stream);

@@ -108,6 +108,8 @@ int la_modconv3x3_up2_fwd_ex(const float* x, long x_bstride, const float* wf, co
         // FIR output row y reads intermediate rows y - 1 .. y + 2; intermediate row Y = 2 q + py belongs to row q of phase py
         const int zlo = row_lo - 1 > 0 ? row_lo - 1 : 0, zhi = row_hi + 2 < res + 1 ? row_hi + 2 : res + 1;
         a.row_lo = zlo >> 1; a.row_hi = ((zhi - 1) >> 1) + 1;
+        // the input rows those phase rows read: nothing else is copied into the pre-split operand, and the contraction reads the rest as zeros
+        la_modconv3x3_up2_fwd_rows(res, row_lo, row_hi, &a.in_row_lo, &a.in_row_hi);
     }
     if (precision != LA_PREC_F32) {
         // split the (modulated) input once for the four phase launches

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_kernel(const float* __restri
                                                           const float* __restrict__ s, int s_stride,
                                                           const float* __restrict__ bias, const float* __restrict__ skip,
                                                           float* __restrict__ rgb_pre, float* __restrict__ img, int C,
-                                                          long HW, float clamp, LaTorgbMask mk) {
+                                                          long HW, float clamp, LaTorgbMask mk, long p_lo, long p_hi) {
     extern __shared__ float weff[];   // [IMGC][C]
     const int b = blockIdx.y;
     for (int k = threadIdx.x; k < IMGC * C; k += blockDim.x) {
@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_kernel(const float* __restri
     __syncthreads();
     const long p4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (p4 >= HW) return;
+    if (p_hi > 0 && (p4 < p_lo || p4 >= p_hi)) return;      // pixel window (rows nobody reads: la_synth.hip)
     const float* xb = x + (long)b * C * HW + p4;
     float4 acc[IMGC];
 #pragma unroll
@@ -345,8 +346,10 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_small_kernel(const float* __
 
 int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_stride, const float* bias,
                      const float* skip, float* rgb_pre, float* img, int B, int C, int imgc, int H, int W, float clamp,
-                     hipStream_t stream, const LaTorgbMask* mask) {
+                     hipStream_t stream, const LaTorgbMask* mask, int row_lo, int row_hi) {
     const long HW = (long)H * W;
+    LA_CHECK_ARG(row_lo >= 0 && (row_hi == 0 || (row_hi > row_lo && row_hi <= H)), "torgb: bad row window");
+    const long p_lo = (long)row_lo * W, p_hi = (long)row_hi * W;
     LaTorgbMask mk{nullptr, 0, 0.f, 0.f, 0.f};
     if (mask) mk = *mask;
     LA_CHECK_ARG(!mk.y || HW > 4096, "torgb: the fused activation backward exists for planes above 64x64 only");
@@ -369,7 +372,7 @@ int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_st
     }
     dim3 grid(la_cdiv(HW / 4, 256), B);
     const size_t lds = (size_t)imgc * C * sizeof(float);
-#define LAUNCH(N) hipLaunchKernelGGL(la_torgb_fwd_kernel<N>, grid, dim3(256), lds, stream, x, wrgb, s, s_stride, bias, skip, rgb_pre, img, C, HW, clamp, mk)
+#define LAUNCH(N) hipLaunchKernelGGL(la_torgb_fwd_kernel<N>, grid, dim3(256), lds, stream, x, wrgb, s, s_stride, bias, skip, rgb_pre, img, C, HW, clamp, mk, p_lo, p_hi)
     switch (imgc) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
     LA_CHECK_LAUNCH();

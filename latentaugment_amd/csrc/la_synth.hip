@@ -358,8 +358,9 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
     // row windows of the conv outputs for an image row window (la_synth_set_row_window), top block downwards until a window is the
     // whole plane: conv1 in 4-row tiles around what the image / the block above need, conv0 (FIR output) one row more on either side,
     // the block below what conv0's transposed conv reads (la_modconv3x3_up2_fwd_rows) and what the image up-sampling reads
-    int wlo[2 * MAX_BLOCKS], whi[2 * MAX_BLOCKS];
+    int wlo[2 * MAX_BLOCKS], whi[2 * MAX_BLOCKS], ilo[MAX_BLOCKS], ihi[MAX_BLOCKS];      // (ilo / ihi: image rows a block has to deliver)
     for (int i = 0; i < h->nconv; ++i) wlo[i] = whi[i] = 0;
+    for (int i = 0; i < MAX_BLOCKS; ++i) ilo[i] = ihi[i] = 0;
     if (h->win_hi > 0 && h->precision != LA_PREC_F32 && !zt_dense) {
         int img_lo = h->win_lo, img_hi = h->win_hi, up_lo = 0, up_hi = 0;      // needs of block k: image rows, rows read by block k + 1
         for (int k = h->nblocks - 1, c1 = h->nconv - 1; k >= 1; --k, c1 -= 2) {
@@ -371,6 +372,7 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
             if (hi > res) hi = res;
             if (lo <= 0 && hi >= res) break;                      // everything is needed from here down
             wlo[c1] = lo; whi[c1] = hi;
+            ilo[k] = img_lo; ihi[k] = img_hi;
             const int l0 = lo - 1 > 0 ? lo - 1 : 0, h0 = hi + 1 < res ? hi + 1 : res;
             wlo[c1 - 1] = l0; whi[c1 - 1] = h0;
             la_modconv3x3_up2_fwd_rows(res, l0, h0, &up_lo, &up_hi);
@@ -445,8 +447,9 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
                     return rc;
                 skip = T.g_img;
             }
+            const bool iw = ihi[k] > 0 && (long)res * res > 4096;      // (windowed block: only the image rows somebody reads)
             if ((rc = la_torgb_forward(x, T.weight, h->s_all + T.s_off, h->S, T.bias, skip, T.rgb_pre, rgb_dst, B, T.cin, h->imgc,
-                                       res, res, h->clamp, stream)))
+                                       res, res, h->clamp, stream, nullptr, iw ? ilo[k] : 0, iw ? ihi[k] : 0)))
                 return rc;
         }
         if (k == h->nblocks - 1) h->final_img = rgb_dst;
