@@ -164,7 +164,7 @@ int la_synth_set_precision(la_synth* h, int precision);
 int la_synth_set_operand_scale(la_synth* h, int from_data);
 /* Row window of the image for the forward passes that follow (rows [row_lo, row_hi) of img_resolution; 0, 0 = whole frames): the 16-bit
  * forward kernels of the blocks at >= 64^2 compute the rows that window depends on -- 3x3 / FIR taps and the up-sampling geometry of
- * networks_stylegan2.py:270-330 followed down the blocks -- and leave the other rows of every buffer as they were.  la_synth_backward is
+ * SynthesisBlock / SynthesisLayer geometry (conv2d_resample.py:112-134, upfirdn2d.py:342-348) followed down the blocks -- and leave the other rows of every buffer as they were.  la_synth_backward is
  * unchanged and expects an image gradient that is zero outside the window. */
 int la_synth_set_row_window(la_synth* h, int row_lo, int row_hi);
 /* Column window on top of the row window (0, 0 = all): the top block's conv1, the FIR in front of it and the FIR adjoint behind it follow it in

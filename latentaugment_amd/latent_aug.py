@@ -497,7 +497,7 @@ class LatentAug:
     def lanes_eligible(self, b):
         """Two lanes need the FULL local batch (the criteria's 1/(m*n) is fixed per handle), an even one of at least 4 (measured: +3 % at
         4 x 256^2, +5 % at 4 x 512^2, +3.5 % at 16 x 256^2; four lanes lose), and -- with the discriminator --
-        a multiple of 8: MinibatchStd groups sample n with n + b/4, n + 2b/4, n + 3b/4 (networks_stylegan2.py:577-592), and the even /
+        a multiple of 8: MinibatchStd groups sample n with n + b/4, n + 2b/4, n + 3b/4 (MinibatchStdLayer: `x.reshape(G, -1, F, c, H, W)`, group size 4, as the pickled discriminators of the reference carry it), and the even /
         odd halves of the batch keep exactly those groups only then."""
         if self.stream_lanes == 1 or b != self._max_local or b < 4 or b % 2:
             return False
