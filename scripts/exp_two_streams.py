@@ -44,7 +44,7 @@ def make(batch):
 
 full = make(NB)
 parts = [make(NB // NG) for _ in range(NG)]
-streams = [torch.cuda.Stream(device=dev) for _ in range(NG)]
+streams = [torch.cuda.Stream(device=dev, priority=(-1 if (k == 0 and os.environ.get('LA_EXP_LANE_PRIORITY')) else 0)) for k in range(NG)]      # LA_EXP_LANE_PRIORITY=1: lane 0 on a high-priority stream
 CU_MASK = os.environ.get('LA_EXP_CU_MASK', '')      # 'half': lane k gets CUs [128 k, 128 k + 128); 'alt': even / odd 32-bit words of the mask
 if CU_MASK:
     import ctypes
