@@ -56,18 +56,7 @@ CONTRACTION = {
 }
 # launch-profiler classes (include/latentaug_hip.h, la_prof_end_classes)
 LAUNCH_MODES = {1: 'captured step replayed (hipGraph)', 0: 'eager', -1: 'eager (step capture refused by the runtime)'}
-CLASSES = ['conv_halo', 'conv_flat', 'conv_splitk', 'conv_f32', 'operand_prep', 'fir', 'seam_bwd', 'torgb_fwd', 'bank']
-CLASS_KERNELS = {
-    'conv_halo': 'la_conv_bf16_halo_kernel (stride-1 3x3 layers >= 64^2, fp32 input read directly)',
-    'conv_flat': 'la_conv_bf16_kernel<split=false> (transposed-conv phases and stride-2 backward of the up-sampling layers)',
-    'conv_splitk': 'la_conv_bf16_kernel<split=true> + la_conv_splitk_finish_kernel (layers <= 32^2)',
-    'conv_f32': 'la_conv_igemm_kernel (exact fp32 MFMA)',
-    'operand_prep': 'la_presplit_t_kernel / la_plane_absmax_kernel / la_xscale*_kernel (fp16 operand scale and pre-split copy)',
-    'fir': 'la_fir4x4_s1_kernel / la_upfirdn2d_kernel (upfirdn2d family, fwd with the layer epilogue, adjoint)',
-    'seam_bwd': 'la_seam_bwd_kernel (bias_act backward + ToRGB backward + demod-gradient reductions)',
-    'torgb_fwd': 'la_torgb_fwd_kernel (1x1 modulated ToRGB + clamp + skip add)',
-    'bank': 'la_bank_* (criteria bank scans)',
-}
+from latentaugment_amd.kernel_classes import CLASSES, CLASS_KERNELS      # noqa: E402  (shared with scripts/pmc_classes.py)
 
 
 def parse():
@@ -184,6 +173,46 @@ def cpu_baseline(sd, meta, args):
     return out
 
 
+WITNESS_SLACK = 1.5      # the bound of tests/test_hip_fullsize.py::_check: error vs float64 <= 1.5 x the reference's own float32 error
+
+
+def witness(args, w_aug, out, lo, hi):
+    """Correctness witness of the TIMED batches: the last timed batch's augmented latents (and the image sub-grid) against the fixture
+    the full-size parity tests use -- tests/golden/fullsize_{B,F}.npz, made by running the reference's LatentAug.forward (float32) and
+    the float64 anchor on this very workload (the bench's G, banks, criteria and latents are the fixture's; with N ranks every rank's
+    shard repeats the fixture's eight latents).  Bound: error against float64 within 1.5 x the reference's own float32 error (rms), 3 x
+    on the single worst entry.  Returns None where no fixture matches the workload; `rows` = this rank's shard [lo, hi) of the batch."""
+    import numpy as np
+    name = 'B' if args.w_disc == 0 else ('F' if abs(args.w_disc - 0.01) < 1e-12 else None)
+    path = os.path.join(ROOT, 'tests', 'golden', f'fullsize_{name}.npz')
+    if (name is None or args.preset != 'B' or args.res != 256 or args.channel_base != 32768 or args.batch != 8 or args.latent_steps != 20
+            or not os.path.isfile(path)):
+        return None
+    fx = np.load(path)
+    o64, r32 = fx['o64_w'].astype(np.float64), fx['ref32_w'].astype(np.float64)
+    w = w_aug[:, 0].detach().cpu().numpy().astype(np.float64)
+    reps = w.shape[0] // 8
+    err = np.abs(w - np.tile(o64, (reps, 1)))
+    mine = err[lo:hi]
+    ref = np.abs(r32 - o64)
+    ref_rms, ref_max = float(np.sqrt((ref ** 2).mean())), float(ref.max())
+    rms_all, rms_mine = float(np.sqrt((err ** 2).mean())), float(np.sqrt((mine ** 2).mean())) if mine.size else 0.0
+    st = args.res // 64
+    img = np.concatenate([out['A'].numpy(), out['B'].numpy()], axis=1)[:, :, st // 2::st, st // 2::st].astype(np.float64)
+    ierr = np.abs(img - np.tile(fx['o64_img_sub'].astype(np.float64), (reps, 1, 1, 1)))
+    iref = np.abs(fx['ref32_img_sub'].astype(np.float64) - fx['o64_img_sub'])
+    scale = float(np.abs(fx['o64_img_sub']).max())
+    irms, iref_rms = float(np.sqrt((ierr ** 2).mean())), float(np.sqrt((iref ** 2).mean()))
+    ok = (rms_all <= WITNESS_SLACK * ref_rms + 1e-7 and rms_mine <= WITNESS_SLACK * ref_rms + 1e-7 and
+          float(err.max()) <= 2 * WITNESS_SLACK * ref_max + 1e-6 and irms <= WITNESS_SLACK * iref_rms + 1e-6 * scale and bool(np.isfinite(w).all()))
+    return {'ok': bool(ok), 'fixture': f'tests/golden/fullsize_{name}.npz (reference float32 run + float64 anchor of this workload)',
+            'checked': 'w_aug and the 64x64 image sub-grid of the LAST TIMED batch, every sample of the gathered batch',
+            'w_rms_vs_f64': rms_all, 'w_rms_vs_f64_own_shard': rms_mine, 'w_max_vs_f64': float(err.max()),
+            'reference_f32_rms_vs_f64': ref_rms, 'reference_f32_max_vs_f64': ref_max, 'img_rms_vs_f64': irms,
+            'reference_f32_img_rms_vs_f64': iref_rms, 'bound': f'rms <= {WITNESS_SLACK} x reference float32 rms, max <= {2 * WITNESS_SLACK} x reference max',
+            'w_checksum': float(w.sum())}
+
+
 def bracketed_batch(lib, _lib, one_step):
     """One extra batch with HIP events around every launch (eager launches of the same kernels): per-class sums, or None."""
     _lib.check(lib.la_prof_set_stride(1), 'la_prof_set_stride')
@@ -274,12 +303,21 @@ def roofline_leg(lib, _lib, args, one_step, elapsed_per_step):
                 'achieved': fl1[i] / (ms1[i] * 1e-3) / 1e12, 'frac': fl1[i] / (ms1[i] * 1e-3) / 1e12 / cm['peak'],
                 'all_contractions': {'achieved': cfl / (cms * 1e-3) / 1e12, 'frac': cfl / (cms * 1e-3) / 1e12 / cm['peak'], 'ms_per_batch': cms},
                 'bracketed_ms_per_batch': sum(ms1[j] for j in range(n1))}
-    # whole-pass HBM view: SURVEY 8(d) algorithmic bytes of the G pass per batch over the timed time per batch
+    # whole-pass HBM view.  `moved`: the algorithmic bytes of the launches the batch really makes (the brackets' byte counts follow the
+    # row / column windows of the loop steps); `whole_frame_equivalent`: SURVEY 8(d)'s figure for whole frames in every step -- the
+    # bytes the reference's schedule would move, NOT what this loop moves when windows are on -- both over the timed time per batch
+    moved = sum(by[i] for i in range(n))
+    roof['whole_pass'] = {'algorithmic_bytes_per_batch_moved': moved, 'achieved_gbs': moved / (elapsed_per_step * 1e-3) / 1e9,
+                          'hbm_frac': moved / (elapsed_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          'note': 'bytes = sum over the bracketed launch classes (contractions, operand preparation, FIR family, seam, ToRGB) of '
+                                  'input + output bytes of what each launch computes (windowed rows / tile columns where the loop windows are on)'}
     if args.preset == 'B' and args.res == 256 and args.channel_base == 32768 and args.w_disc == 0:
         alg = (args.batch * (args.latent_steps * 700.2e6 + 274.6e6) + (2 * args.latent_steps + 1) * 94e6)
-        roof['whole_pass'] = {'algorithmic_bytes_per_batch': alg, 'achieved_gbs': alg / (elapsed_per_step * 1e-3) / 1e9,
-                              'hbm_frac': alg / (elapsed_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              'note': 'SURVEY 8(d): 700.2 MB per image-step (fwd+bwd) + 274.6 MB final forward per image + shared weights'}
+        roof['whole_pass']['whole_frame_equivalent'] = {
+            'algorithmic_bytes_per_batch': alg, 'equivalent_gbs': alg / (elapsed_per_step * 1e-3) / 1e9,
+            'equivalent_hbm_frac': alg / (elapsed_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'note': 'SURVEY 8(d): 700.2 MB per image-step (fwd+bwd) + 274.6 MB final forward per image + shared weights, i.e. WHOLE frames in every '
+                    'step; an equivalent rate (work of the reference schedule / time), not bytes moved, whenever config.schedule.loop_window is set'}
     # HBM bytes per launch of the dominant class from the committed PMC passes of this workload (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate passes, scripts/make_profiles.sh): counters cannot be read from inside the process
     import glob
@@ -308,6 +346,8 @@ def self_launch(n):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
         env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+        env.setdefault('GLOO_SOCKET_IFNAME', 'lo')             # single node: the companion gloo group (control broadcast) stays on loopback
+        env.setdefault('NCCL_SOCKET_IFNAME', 'lo')             # ... and so does RCCL's bootstrap (the hostname of a container may not resolve)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     while True:
         rcs = [p.poll() for p in procs]
@@ -368,7 +408,9 @@ def main():
     sd, meta = synthetic.make_generator_state_dict(img_resolution=args.res, img_channels=2, channel_base=args.channel_base, seed=0)
     W, X = synthetic.make_banks(meta['num_ws'], res=args.res, M_w=args.M_w, M_x=args.M_x)
     data = synthetic.make_batch(gb, res=args.res, seed=2)
-    w0 = synthetic.make_latents(gb, seed=1)
+    # latents: the eight of the parity fixtures (seed 1), repeated per rank -- every rank's shard is the fixture's batch, so the witness
+    # below can check every rank's timed result against the reference's (samples are independent: timing does not depend on values)
+    w0 = synthetic.make_latents(args.batch, seed=1).repeat(world, 1, 1)
     codes = InMemoryLatentCodes({p: w0[i, 0].numpy() for i, p in enumerate(data['A_paths'])})
     opt = make_opt(args, local_rank, gb)
     opt.inject = dict(generator=sd, banks={'W': W, 'X': X}, latent_codes=codes, group=None)
@@ -445,6 +487,15 @@ def main():
         t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # correctness witness of the timed region's last batch (before the roofline legs run other schedules)
+    lo_w, hi_w = (rank * args.batch, (rank + 1) * args.batch) if use_dist else (0, gb)
+    wit = witness(args, aug.w_AB_aug, out, lo_w, hi_w)
+    if wit is not None and use_dist:
+        cdev = dev if args.dist_backend == 'nccl' else 'cpu'
+        t = torch.tensor([0.0 if wit['ok'] else 1.0, wit['w_rms_vs_f64_own_shard'], wit['w_max_vs_f64']], device=cdev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wit['all_ranks'] = {'ok': bool(t[0].item() == 0.0), 'worst_own_shard_w_rms_vs_f64': float(t[1].item()), 'worst_w_max_vs_f64': float(t[2].item())}
+        wit['ok'] = wit['all_ranks']['ok']
     roof = None
     if not args.no_roofline:
         roof = roofline_leg(lib, _lib, args, one_step, 1e3 * elapsed / args.steps)      # (every rank runs it: forward() is collective)
@@ -457,21 +508,27 @@ def main():
         'dtype': {'f32': 'f32', 'f16x2': 'f32 (scaled split-fp16x2 on fp16 MFMA, fp32 accumulate)',
                   'bf16x3': 'f32 (split-bf16x3 on bf16 MFMA, fp32 accumulate)',
                   'bf16x2': 'f32 (split-bf16x2 on bf16 MFMA, approximate)'}[args.precision], 'data': 'synthetic',
-        'config': {'workload': f'SG2 config-{"f" if args.channel_base == 32768 else "e"} {args.res}x{args.res} 2-ch, '
-                               f'random-init G, batch={args.batch}/GPU, {args.latent_steps} latent steps, '
-                               f'w_latent={args.w_latent:g} w_pix={args.w_pix:g} w_disc={args.w_disc:g} w_lpips={args.w_lpips:g} '
-                               f'(M_w={args.M_w}, M_x={args.M_x}), criteria gradients from bank column sums reduced once per handle (the '
-                               f"reference's pairwise-L2 GEMM over the banks runs only when loss scalars are requested: the API returns none), "
-                               f'contraction={args.precision}' + (', fp16 operand scales from the data of every pass (lowered by the producing kernels)' if args.precision == 'f16x2' else '') + ', '
-                               f'timed call = set_input + LatentAugment.forward + get_output, '
-                               'launch mode = ' + launch_mode +
-                               (', two stream lanes (samples 0,2,4,.. and 1,3,5,.. as two half-batch loops on two HIP streams)' if lanes_used else '') +
-                               (', loop steps synthesise the rows the criteria read (image rows %d..%d, the centre crop, and what they depend on in the '
-                                'blocks at >= 64^2); the final synthesis is a whole frame' % (aug.latent_aug.loop_window[0], aug.latent_aug.loop_window[1] - 1)
-                                if aug.latent_aug.loop_window else ', whole frames in every loop step'),
+        'config': {'workload': f'SG2 config-{"f" if args.channel_base == 32768 else "e"} {args.res}x{args.res} 2-ch, random-init G, '
+                               f'batch={args.batch}/GPU, {args.latent_steps} latent steps',
+                   'criteria': {'w_latent': args.w_latent, 'w_pix': args.w_pix, 'w_disc': args.w_disc, 'w_lpips': args.w_lpips, 'M_w': args.M_w,
+                                'M_x': args.M_x,
+                                'form': 'gradients from bank column sums reduced once per handle; the pairwise-L2 GEMM over the banks runs only '
+                                        'when loss scalars are requested (the API returns none)'},
+                   'schedule': {'timed_call': 'set_input + LatentAugment.forward + get_output', 'launch_mode': launch_mode,
+                                'stream_lanes': 2 if lanes_used else 1,
+                                'lanes_selfcheck': aug.latent_aug.lanes_selfcheck,
+                                'loop_window': ('image rows %d..%d (the centre crop) and what they depend on in the blocks at >= 64^2; final synthesis '
+                                                'whole frame' % (aug.latent_aug.loop_window[0], aug.latent_aug.loop_window[1] - 1))
+                                if aug.latent_aug.loop_window else None,
+                                'contraction': args.precision,
+                                'operand_scales': 'from the data of every pass (producing kernels)' if args.precision == 'f16x2' else None},
                    'global_batch': gb, 'parallelism': f'dp{world}'},
     }
+    if wit is not None:
+        line['witness'] = wit
     if multi is not None:
+        if wit is not None:
+            multi['witness'] = wit.get('all_ranks')
         line['multi_gpu'] = multi
     else:
         line['host_ms'] = 1e3 * host_s[0] / args.steps
@@ -485,7 +542,17 @@ def main():
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if wit is not None and not wit['ok']:
+        raise SystemExit('bench.py: the timed batches violate the correctness witness (see "witness" in the line above)')
 
 
 if __name__ == '__main__':
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:      # a rank that dies says which one it was (the launcher's own message only names the exit code)
+        import traceback
+        sys.stderr.write(f"[bench.py rank {os.environ.get('RANK', '0')} of {os.environ.get('WORLD_SIZE', '1')}] failed:\n{traceback.format_exc()}")
+        sys.stderr.flush()
+        sys.exit(1)

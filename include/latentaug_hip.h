@@ -135,6 +135,12 @@ int la_center_crop_f32(const float* src, float* dst, long planes, int R, int cc,
 int la_adam_step_f32(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1, float beta2,
                      float eps, la_stream_t stream);
 
+/* Unit normals for the explicit per-layer noise tensors of noise_mode='random' (the reference's SynthesisLayer draws torch.randn inside
+ * G.synthesis, call site augments/utils/util_latent_aug.py:308): out [rows][row_elems]; element e of GLOBAL sample row row0 + r of
+ * `layer` is a pure function of (seed, layer, row0 + r, e) -- Philox4x32-10 + Box-Muller -- so a rank generates only the rows of its
+ * shard and the gathered batch does not depend on the sharding. */
+int la_noise_normal_f32(float* out, long rows, long row_elems, unsigned long long seed, unsigned layer, long row0, la_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Synthesis network engine: replaces  G.synthesis(ws, noise_mode=...)  (call sites util_latent_aug.py:227,488) and the
  * autograd backward to ws that loss.backward() (:275) runs through it.  Architecture 'skip', fp32

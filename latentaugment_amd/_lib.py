@@ -58,6 +58,7 @@ SIGNATURES = {
     'la_pairwise_l2_f32': (_I, [_P, _I, _P, _L, _L, _P, _P, _P, _P]),
     'la_center_crop_f32': (_I, [_P, _P, _L, _I, _I, _I, _P]),
     'la_adam_step_f32': (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _P]),
+    'la_noise_normal_f32': (_I, [_P, _L, _L, C.c_ulonglong, C.c_uint, _L, _P]),
     'la_synth_num_ws': (_I, [_I]),
     'la_synth_num_params': (_I, [_I]),
     'la_synth_workspace_bytes': (_Z, [_I, _I, _I, _P, _I]),

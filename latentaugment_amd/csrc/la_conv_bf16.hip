@@ -433,6 +433,7 @@ int la_conv_prepare_input(LaConvArgs& a, hipStream_t stream) {
     // launch profiler: operand preparation = its own class (read the fp32 input once; the pre-split copy is written once)
     struct Bracket { int slot; hipStream_t st; ~Bracket() { la_prof_close(slot, st); } };
     if (la_conv_bf16_uses_halo(a)) {
+        if (a.precision != LA_PREC_F16X2 || a.acc_scale_x) return LA_OK;      // (scale known: nothing is launched, nothing is bracketed)
         Bracket br{la_prof_open(LA_PC_PRESPLIT, 0.0, a.in_pmax ? 0.0 : 4.0 * a.B * (double)a.C * HW * (a.in_bstride ? 1.0 : 1.0 / a.B), stream), stream};
         return prepare_scale(a, stream);
     }

@@ -22,6 +22,9 @@ int la_broadcast_mix(const float* w_opt, const float* w0, float* w_aug, int B, i
 int la_adam_step_tab(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                      const float* tab, const int* ctr, hipStream_t stream);
 int la_step_advance(int* ctr, hipStream_t stream);
+// la_latent_combine + la_adam_step_tab + la_step_advance in one launch (bit-identical); ticket: a zeroed device int of the handle
+int la_step_tail(const float* dws, const float* colsumW, float* dw, float* p, float* m, float* v, int B, int num_ws, int wdim, float lat2,
+                 float mrows, float lr, float beta1, float beta2, float eps, const float* tab, int* ctr, int* ticket, hipStream_t stream);
 void la_adam_fill_table(float* tab_host, int steps, float beta1, float beta2);
 extern "C" {
 long la_pairwise_l2_workspace_floats(int n, long m);

@@ -269,8 +269,11 @@ __global__ __launch_bounds__(256) void la_fromrgb_fwd_kernel(const float* __rest
 }
 
 // MinibatchStd (group G, 1 statistic channel): forward writes [N][C+1][HW]; sample n belongs to slot n % (N/G).
+// xs_rows (fp16 slot rows of the epilogue conv's input, or null): the statistic channel is a GROUP value -- bounded by the group's largest
+// member, not by sample n's own maximum, which is all that the producer of `x` lowered n's row with -- so every member's row is
+// lowered with it here (a sample much smaller than its group-mates would otherwise overflow its std-channel operand in fp16).
 __global__ __launch_bounds__(256) void la_mbstd_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int G,
-                                                          int C, int HW) {
+                                                          int C, int HW, float* __restrict__ xs_rows) {
     __shared__ float red[4];
     const int slot = blockIdx.x, M = N / G;
     const int CHW = C * HW;
@@ -314,6 +317,10 @@ __global__ __launch_bounds__(256) void la_mbstd_fwd_kernel(const float* __restri
         acc += sqrtf(var / (float)G + 1e-8f);
     }
     const float stat = la_block_sum_256(acc, red) / (float)CHW;
+    if (xs_rows && threadIdx.x < (unsigned)G) {
+        float* row = xs_rows + (long)((int)threadIdx.x * M + slot) * LA_XS_FAN + la_xs_sub((int)threadIdx.x);
+        la_xs_lower(row, la_xs_peek(row), 1.f, stat);
+    }
     for (int g = 0; g < G; ++g) {
         const long n = g * M + slot;
         int e = threadIdx.x;
@@ -563,7 +570,7 @@ extern "C" int la_disc_forward(la_disc* h, const float* img, int B, hipStream_t 
         }
     }
     const DBlock& last = h->blk[h->nblocks - 1];
-    hipLaunchKernelGGL(la_mbstd_fwd_kernel, dim3(B / G), dim3(256), 0, stream, last.sum, h->mb, B, G, h->C4, 16);
+    hipLaunchKernelGGL(la_mbstd_fwd_kernel, dim3(B / G), dim3(256), 0, stream, last.sum, h->mb, B, G, h->C4, 16, rows_x(h->nblocks));
     LA_CHECK_LAUNCH();
     if ((rc = conv_same(h, h->econv, false, h->mb, h->yc, B, 4, LA_ACT_LRELU, sq2, h->clamp, nullptr, nullptr, stream, nullptr, 0, rows_x(h->nblocks)))) return rc;
     if ((rc = la_fc_f32(h->yc, h->fc_w, h->fc_b, h->fc, B, h->C4 * 16, h->C4, 1.f, LA_ACT_LRELU, 0.2f, sq2, stream))) return rc;

@@ -32,11 +32,12 @@ struct la_latent_opt {
     float* adam_tab;        // device [steps][2]
     float* adam_tab_host;   // host copy (malloc), uploaded ONCE (first run; constant afterwards)
     int adam_tab_valid;
-    int* step_ctr;          // device
+    int* step_ctr;          // device (16 ints: [0] counter, [4..5] crop_dev, [8] ticket of la_step_tail)
     int* crop_dev;          // device {y0, x0}
     float* trace_dw;        // optional [steps][B][w_dim]: dL/dw of every step (la_latent_opt_set_grad_trace); forces eager launches
     int graph_mode;         // 0 eager, 1 replay a captured step (default)
     int graph_B;            // batch the captured step was built for (0: none)
+    int graph_win;          // ... and whether its synthesis passes were windowed
     int graph_refused;      // 1: stream capture / instantiation of the step failed once; the handle launches eagerly since
     hipGraph_t graph;
     hipGraphExec_t graph_exec;
@@ -119,7 +120,7 @@ extern "C" int la_latent_opt_create(la_synth* g, int img_resolution, int img_cha
 static void drop_graph(la_latent_opt* h) {
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
-    h->graph_B = 0;
+    h->graph_B = 0; h->graph_win = 0;
 }
 
 extern "C" void la_latent_opt_destroy(la_latent_opt* h) {
@@ -327,7 +328,7 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     LA_HIP(hipMemcpyAsync(h->w_opt, w0, nw * sizeof(float), hipMemcpyDeviceToDevice, stream));
     LA_HIP(hipMemsetAsync(h->m, 0, nw * sizeof(float), stream));
     LA_HIP(hipMemsetAsync(h->v, 0, nw * sizeof(float), stream));
-    LA_HIP(hipMemsetAsync(h->step_ctr, 0, sizeof(int), stream));
+    LA_HIP(hipMemsetAsync(h->step_ctr, 0, 16 * sizeof(int), stream));      // step counter [0], crop position [4..5] (set below), ticket of la_step_tail [8]
     if (c.steps > 0 && !h->adam_tab_valid) {      // constant after create: one (host-blocking, pageable) upload per handle, not per batch
         LA_HIP(hipMemcpyAsync(h->adam_tab, h->adam_tab_host, sizeof(float) * 2 * (size_t)c.steps, hipMemcpyHostToDevice, stream));
         LA_HIP(hipStreamSynchronize(stream));
@@ -361,7 +362,16 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     }
     // loop steps: the synthesis delivers the rows the criteria read (la_latent_opt_set_row_window); whole frames with the discriminator,
     // with per-step image snapshots, or with no window given
-    const bool windowed = h->win_hi > 0 && !use_disc && !h->trace_img;
+    // The window is a caller-supplied hint (la_latent_opt_set_row_window / _col_window): it is honoured only while every row and column the
+    // criteria of THIS run read lies inside it -- the pixel criterion's centre crop, the perceptual criterion's crop_size window at the
+    // position of la_latent_opt_set_crop_pos.  A window that does not contain them would optimise against stale rows of an earlier pass;
+    // such a run synthesises whole frames instead.
+    auto inside = [&](int y0, int y1, int x0, int x1) {
+        return y0 >= h->win_lo && y1 <= h->win_hi && (h->wcol_hi <= 0 || (x0 >= h->wcol_lo && x1 <= h->wcol_hi));
+    };
+    const bool win_covers = (c.w_pix == 0.f || inside(off, off + cc, off, off + cc)) &&
+                            (!use_lpips || inside(h->crop_y, h->crop_y + h->S, h->crop_x, h->crop_x + h->S));
+    const bool windowed = h->win_hi > 0 && !use_disc && !h->trace_img && win_covers;
     struct WinGuard {      // (whole frames again on every way out, and for the final synthesis below)
         la_synth* g; ~WinGuard() { (void)la_synth_set_row_window(g, 0, 0); (void)la_synth_set_col_window(g, 0, 0); }
     } win_guard{h->g};
@@ -387,7 +397,12 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
             if (h->Mw && (rc = la_l2_mean_from_bank(h->bankW, h->Mw, (long)h->num_ws * wd, h->w_opt, B, wd, wd, h->yx, h->yy,
                                                     h->xx, lat_coef, L + 0, 0, st)))
                 return rc;
-            if (h->Mw) mark(2);
+        }
+        // brackets of the per-criterion timers (la_latent_opt_get_times): [1,2) latent loss scalar, [2,3) pixel loss scalar + gradient,
+        // [3,4) discriminator, [4,5) perceptual; the latent criterion's GRADIENT is one fused launch with the total (la_latent_combine,
+        // after the synthesis backward) and sits in the epoch bracket only
+        mark(2);
+        if (L) {
             if (h->Mx) {
                 if ((rc = la_center_crop_f32(img, h->xc, (long)B * h->imgc, h->R, cc, off, st))) return rc;
                 for (int ch = 0; ch < h->imgc; ++ch)
@@ -397,7 +412,6 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
             }
         }
         const float* dws = nullptr;
-        if (!L || !h->Mw) mark(2);      // (no latent criterion / no loss scalars: empty bracket)
         if (img_crit) {
             if (c.w_pix != 0.f &&
                 (rc = la_pix_grad(img, h->colsumX, h->g_img, B, h->imgc, h->R, cc, off, -2.f * pix_coef, (float)h->Mx, st)))
@@ -446,11 +460,9 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
             if ((rc = la_synth_backward(h->g, h->g_img, h->dws, st))) return rc;
             dws = h->dws;
         } else { mark(3); mark(4); mark(5); }
-        if ((rc = la_latent_combine(dws, h->w_opt, h->Mw ? h->colsumW : nullptr, h->dw, B, h->num_ws, wd, -2.f * lat_coef,
-                                    (float)h->Mw, st)))
-            return rc;
-        if ((rc = la_adam_step_tab(h->w_opt, h->dw, h->m, h->v, nw, c.lr, c.beta1, c.beta2, c.eps, h->adam_tab, h->step_ctr, st))) return rc;
-        rc = la_step_advance(h->step_ctr, st);
+        // dw = sum_ws dws + latent gradient, Adam, step counter: one launch (la_step_tail)
+        rc = la_step_tail(dws, h->Mw ? h->colsumW : nullptr, h->dw, h->w_opt, h->m, h->v, B, h->num_ws, wd, -2.f * lat_coef, (float)h->Mw,
+                          c.lr, c.beta1, c.beta2, c.eps, h->adam_tab, h->step_ctr, h->step_ctr + 8, st);
         mark(6);
         return rc;
     };
@@ -461,7 +473,7 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     const bool tracing = h->trace_w || h->trace_img || h->trace_dw;
     const bool replay = h->graph_mode == 1 && !want_losses && !tracing && c.steps > 0 && !la_prof_enabled();
     int first_graph_step = 1;
-    if (replay && (!h->graph_exec || h->graph_B != B)) {
+    if (replay && (!h->graph_exec || h->graph_B != B || h->graph_win != (int)windowed)) {
         drop_graph(h);
         if ((rc = run_step(nullptr, stream))) return rc;          // step 1, eager
         first_graph_step = 2;
@@ -476,7 +488,7 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
             }
             if (ok) ok = hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0) == hipSuccess;
         }
-        if (ok) h->graph_B = B;
+        if (ok) { h->graph_B = B; h->graph_win = (int)windowed; }
         else { drop_graph(h); (void)hipGetLastError(); if (c.steps >= 2) { h->graph_mode = 0; h->graph_refused = 1; } }
     }
     for (int step = first_graph_step; step <= c.steps; ++step) {

@@ -140,6 +140,62 @@ int la_step_advance(int* ctr, hipStream_t stream) {
     LA_CHECK_LAUNCH();
     return LA_OK;
 }
+// Tail of an optimisation step in ONE launch (was three: la_latent_combine, la_adam_tab_kernel, la_step_advance -- each a 5 us link of
+// the step's serial chain): dw = sum over the ws slots of dws + the latent criterion's gradient (the arithmetic and its order are
+// la_latent_combine_kernel's), the Adam update with the bias corrections of step *ctr + 1 (la_adam_tab_kernel's), and the step
+// counter: every workgroup draws a ticket AFTER its threads have read *ctr; the one that draws the last ticket resets it and bumps
+// the counter -- nobody is left to read the old value.
+__global__ __launch_bounds__(256) void la_step_tail_kernel(const float* __restrict__ dws, const float* __restrict__ colsumW, float* __restrict__ dw,
+                                                          float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, int num_ws,
+                                                          int wdim, float lat2, float mrows, long total, float lr, float b1, float b2,
+                                                          float eps, const float2* __restrict__ tab, int* __restrict__ ctr,
+                                                          int* __restrict__ ticket) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float2 bc = tab[*ctr];
+    if (i < total) {
+        const long b = i / wdim;
+        const int j = (int)(i - b * wdim);
+        float acc = 0.f, cs = 0.f;
+        int l = 0;
+        for (; l + 7 < num_ws; l += 8) {      // (eight slots' loads in flight, added in slot order)
+            float a[8], c[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a[k] = dws ? dws[(b * num_ws + l + k) * wdim + j] : 0.f;
+                c[k] = colsumW ? colsumW[(long)(l + k) * wdim + j] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { if (dws) acc += a[k]; if (colsumW) cs += c[k]; }
+        }
+        for (; l < num_ws; ++l) {
+            if (dws) acc += dws[(b * num_ws + l) * wdim + j];
+            if (colsumW) cs += colsumW[(long)l * wdim + j];
+        }
+        const float pv = p[i];
+        if (colsumW) acc += lat2 * ((float)num_ws * mrows * pv - cs);
+        dw[i] = acc;
+        const float mv = b1 * m[i] + (1.f - b1) * acc;
+        const float vv = b2 * v[i] + (1.f - b2) * acc * acc;
+        m[i] = mv; v[i] = vv;
+        const float denom = sqrtf(vv) / bc.y + eps;
+        p[i] = pv - (lr / bc.x) * (mv / denom);
+    }
+    __syncthreads();      // every thread of the workgroup has read *ctr
+    if (threadIdx.x == 0) {
+        if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) { *ticket = 0; *ctr += 1; }
+    }
+}
+
+int la_step_tail(const float* dws, const float* colsumW, float* dw, float* p, float* m, float* v, int B, int num_ws, int wdim, float lat2,
+                 float mrows, float lr, float beta1, float beta2, float eps, const float* tab, int* ctr, int* ticket, hipStream_t stream) {
+    const long total = (long)B * wdim;
+    if (total == 0) return LA_OK;
+    hipLaunchKernelGGL(la_step_tail_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, stream, dws, colsumW, dw, p, m, v, num_ws, wdim, lat2,
+                       mrows, total, lr, beta1, beta2, eps, reinterpret_cast<const float2*>(tab), ctr, ticket);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
 void la_adam_fill_table(float* tab_host, int steps, float beta1, float beta2) {
     for (int t = 1; t <= steps; ++t) {
         tab_host[2 * (t - 1)] = 1.f - powf(beta1, (float)t);
@@ -155,6 +211,58 @@ extern "C" int la_adam_step_f32(float* p, const float* g, float* m, float* v, lo
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(la_adam_kernel, dim3(la_cdiv(n, 256)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps,
                        bc1, bc2s, 1.f);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Counter-based unit normals for the explicit noise tensors of noise_mode='random' (the reference draws torch.randn per layer inside
+// G.synthesis, util_latent_aug.py:308 / SURVEY 3.4 defect g; a draw cannot be bit-equal to another library's stream, it only has to
+// be N(0, 1) and reproducible).  Element e of GLOBAL sample row r of layer l under `seed` is a pure function of (seed, l, r, e):
+// Philox4x32-10 (Salmon et al., SC'11) with counter (e / 4, r, l, 0) and key (seed low, seed high) gives four 32-bit words, two
+// Box-Muller pairs turn them into elements 4 (e / 4) .. 4 (e / 4) + 3.  A rank that holds rows [row0, row0 + rows) of a batch
+// therefore generates exactly its rows -- nothing of the other ranks' -- and the gathered batch does not depend on the sharding.
+__device__ __forceinline__ void la_philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__global__ __launch_bounds__(256) void la_noise_normal_kernel(float* __restrict__ out, long rows, long row_elems, unsigned k0, unsigned k1,
+                                                             unsigned layer, long row0) {
+    const long q4 = (row_elems + 3) >> 2;                      // 4-element groups per row
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= rows * q4) return;
+    const long r = g / q4, q = g - r * q4;
+    unsigned x[4];
+    la_philox4x32_10((unsigned)q, (unsigned)(row0 + r), layer, (unsigned)((unsigned long long)q >> 32), k0, k1, x);
+    float z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)(x[2 * h] >> 8) + 0.5f) * (1.f / 16777216.f);      // (0, 1): 24 bits, exactly representable
+        const float u2 = ((float)(x[2 * h + 1] >> 8) + 0.5f) * (1.f / 16777216.f);
+        const float rad = sqrtf(-2.f * logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        z[2 * h] = rad * cs; z[2 * h + 1] = rad * sn;
+    }
+    float* o = out + r * row_elems + 4 * q;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (4 * q + k < row_elems) o[k] = z[k];
+}
+
+extern "C" int la_noise_normal_f32(float* out, long rows, long row_elems, unsigned long long seed, unsigned layer, long row0, hipStream_t stream) {
+    LA_CHECK_ARG(out && rows >= 0 && row_elems >= 1 && row0 >= 0, "noise_normal: bad arguments");
+    LA_CHECK_ARG(row0 + rows <= 0xffffffffl, "noise_normal: row index exceeds 32 bits");
+    if (rows == 0) return LA_OK;
+    const long n = rows * ((row_elems + 3) >> 2);
+    hipLaunchKernelGGL(la_noise_normal_kernel, dim3((unsigned)la_cdiv(n, 256)), dim3(256), 0, stream, out, rows, row_elems, (unsigned)seed,
+                       (unsigned)(seed >> 32), layer, row0);
     LA_CHECK_LAUNCH();
     return LA_OK;
 }

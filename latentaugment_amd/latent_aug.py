@@ -249,7 +249,7 @@ class LatentAug:
         self.stats_time = {}
         self._verbose_flag = bool(opt.verbose_log)      # the reference logs the FIRST batch only (:189-191, :297-300)
 
-        if banks is None and getattr(opt, 'interim_dir', None) and getattr(opt, 'dataset_aug', None):
+        if banks is None and _shared is None and getattr(opt, 'interim_dir', None) and getattr(opt, 'dataset_aug', None):
             # real-data banks from the interim zips (reference :137-158), cached as DatasetStats pickles
             from . import formats
             root = os.path.join(opt.interim_dir, opt.dataset_aug)
@@ -312,8 +312,8 @@ class LatentAug:
         self._max_local = max_local
         self._opt, self._discriminator, self._feature_net = opt, discriminator, feature_net
         # stream lanes: a full local batch as two interleaved half-batch loops on two HIP streams, each with its own loop /
-        # synthesis / discriminator handles.  `opt.stream_lanes`: 'auto' (default: two lanes for a full batch of >= 8 samples when the
-        # perceptual criterion is off -- with it on, the discriminator and the perceptual branch already run side by side inside ONE
+        # synthesis / discriminator handles.  `opt.stream_lanes`: 'auto' (default: two lanes for a full, even batch of >= 4 samples -- with
+        # the discriminator a multiple of 8 -- when the perceptual criterion is off -- with it on, the discriminator and the perceptual branch already run side by side inside ONE
         # loop, which measures faster), 1 (never) or 2 (whenever the batch allows it).
         self.stream_lanes = getattr(opt, 'stream_lanes', 'auto')
         assert self.stream_lanes in ('auto', 1, 2), "opt.stream_lanes: 'auto', 1 or 2"
@@ -321,6 +321,13 @@ class LatentAug:
         self._lane_stream = None
         self.lanes_active = False           # the last batch went through the lanes
         self.lanes_concurrent = True        # False: the lanes one after the other on one stream (bench.py's per-launch brackets)
+        # First-batch self-check of the concurrent lanes (`opt.lanes_selfcheck`, default on): the first full batch runs through the lanes
+        # one after the other AND side by side; the two must agree bit for bit (they are the same launches), otherwise this handle
+        # warns and keeps the lanes serial.  Why: rounds 2-3 saw wrong results whenever two queues of this library overlapped; round 4
+        # traced it to packed-FP32 instructions and removed them (DESIGN 8 'Two streams'), but the hardware mechanism is not pinned
+        # down, so the product checks the property it relies on where it relies on it instead of trusting one toolchain's codegen.
+        self._lanes_check = bool(getattr(opt, 'lanes_selfcheck', True))
+        self.lanes_selfcheck = None         # None: not run yet | 'bit-identical' | 'differs: lanes serial from now on' | 'off'
         # launch mode of the step loop: one captured step replayed (default) or every launch eager (`opt.hip_graph = False`)
         self.hip_graph = bool(getattr(opt, 'hip_graph', True))
         _lib.check(lib.la_latent_opt_set_graph(h, int(self.hip_graph)), 'la_latent_opt_set_graph')
@@ -380,6 +387,9 @@ class LatentAug:
                                                    float(shift[0]), _lib.ptr(self._lpips_ws), nb), 'la_latent_opt_set_lpips')
             _lib.check(lib.la_latent_opt_set_lpips_preproc(h, (C.c_float * 3)(*scale), (C.c_float * 3)(*shift), 3),
                        'la_latent_opt_set_lpips_preproc')
+        # the lanes' handles and workspaces exist from construction on (an allocation failure surfaces here, not inside the first batch)
+        if _shared is None and self.lanes_eligible(self._max_local):
+            self.build_lanes()
 
     def _build_feature_banks(self, opt):
         """fea_<mode> banks (reference :160-171 / extract_features_mode_torchscript :565-580): per real image and modality,
@@ -513,9 +523,11 @@ class LatentAug:
         opt.verbose_log, opt.stream_lanes = False, 1
         shared = {'banks': {'W': self.W, 'fea': list(self.Fbank) if self.feat is not None else None}, 'Xc': self.Xc,
                   'Fbank': self.Fbank if self.feat is not None else None}
+        # (banks={}: a lane never builds banks of its own -- neither from `banks` nor from the interim zips -- it gets the parent's
+        #  device-resident tensors through _shared)
         self._lanes = [LatentAug(self.phase, opt, self.save_dir, [self.device.index], generator=self._generator,
-                                 discriminator=self._discriminator, latent_codes=self.stats_dataset_w, feature_net=self._feature_net,
-                                 _shared=shared) for _ in range(2)]
+                                 discriminator=self._discriminator, banks={}, latent_codes=self.stats_dataset_w,
+                                 feature_net=self._feature_net, _shared=shared) for _ in range(2)]
         self._lane_stream = torch.cuda.Stream(device=self.device)
 
     def run_lanes(self, w, final_noises=None, crop_pos=None, concurrent=True):
@@ -558,9 +570,39 @@ class LatentAug:
     def run_batch(self, w, final_noises=None):
         """The local batch through two stream lanes when it qualifies (lanes_eligible), through the single loop otherwise."""
         self.lanes_active = self.lanes_eligible(w.shape[0])
-        if self.lanes_active:
-            return self.run_lanes(w, final_noises, concurrent=self.lanes_concurrent)
-        return self.run_local(w, final_noises)
+        if not self.lanes_active:
+            return self.run_local(w, final_noises)
+        if self.lanes_selfcheck is None and self.lanes_concurrent:
+            return self._lanes_first_batch(w, final_noises)
+        return self.run_lanes(w, final_noises, concurrent=self.lanes_concurrent)
+
+    def _lanes_first_batch(self, w, final_noises):
+        """The first full batch of a handle: lanes one after the other, then side by side, on the same inputs; bit-identical or the
+        handle stays serial (see __init__).  Costs one extra batch, once."""
+        if not self._lanes_check:
+            self.lanes_selfcheck = 'off'
+            return self.run_lanes(w, final_noises, concurrent=True)
+        if self._lanes is None:
+            self.build_lanes()
+        if self._cfg.final_noise_mode == 2 and final_noises is None:
+            final_noises = self.engine.make_noises(w.shape[0])      # one draw for both runs
+        crop_pos = None
+        if self.feat is not None:
+            cp = getattr(self, 'crop_params', None)
+            crop_pos = cp['crop_pos'] if cp else get_params(self.res, self.crop_size, self.preprocess)['crop_pos']
+        ref_img, ref_w, _ = self.run_lanes(w, final_noises, crop_pos=crop_pos, concurrent=False)
+        img, w_aug, _ = self.run_lanes(w, final_noises, crop_pos=crop_pos, concurrent=True)
+        if torch.equal(img, ref_img) and torch.equal(w_aug, ref_w):
+            self.lanes_selfcheck = 'bit-identical'
+            return img, w_aug, None
+        import warnings
+        dw = float((w_aug - ref_w).abs().max())
+        self.lanes_selfcheck = 'differs: lanes serial from now on'
+        self.lanes_concurrent = False
+        warnings.warn(f'latentaugment_amd: the two stream lanes side by side did not reproduce the lanes one after the other on the first '
+                      f'batch (max |dw| {dw:.3e}); this handle runs them one after the other from now on (opt.stream_lanes = 1 avoids the '
+                      f'lanes altogether)')
+        return ref_img, ref_w, None
 
     # ---- verbose_log artefacts of the first batch (reference :278-300, :620-655)
     def _log_first_batch(self, losses, elapsed, trace, fname, times=None):

@@ -147,13 +147,16 @@ class SynthesisEngine:
 
     def make_noises(self, batch, generator=None, batch_seed=None, rows=None):
         """Unit-variance noise tensors for noise_mode='random': one [B,res,res] per SynthesisLayer, None where the layer's
-        noise_strength is 0 (the term vanishes, nothing is drawn).  With `batch_seed` the draw is a pure function of (seed, layer,
-        batch): one generator and one randn of the WHOLE batch per layer; `rows = (lo, hi)` returns samples lo..hi-1 of it, so that a
-        rank holding a shard of a batch of `batch` samples gets exactly the rows a single process would (one launch per layer,
-        whatever the shard: the per-sample generators of round 2 cost 2 launches per sample and layer on the host's critical path)."""
+        noise_strength is 0 (the term vanishes, nothing is drawn).  Without `batch_seed`: torch.randn on the device generator (or
+        `generator`).  With `batch_seed` the draw is a pure function of (seed, layer, GLOBAL sample row, element) -- the counter-based
+        generator of the library (la_noise_normal_f32: Philox4x32-10 + Box-Muller) -- and `rows = (lo, hi)` generates samples
+        lo..hi-1 of a batch of `batch` ONLY: a rank holding a shard draws its rows and nothing else (one launch per layer, no
+        transient of the global batch's size; rounds 3-4 drew the whole batch with torch.randn on every rank and kept a slice),
+        and the gathered batch does not depend on how it was sharded."""
         lo, hi = (0, batch) if rows is None else rows
         assert 0 <= lo <= hi <= batch
         out = []
+        lib = _lib.load()
         for li, (r, ns) in enumerate(zip(self.layer_resolutions, self.noise_strengths)):
             if ns == 0.0:
                 out.append(None)
@@ -161,9 +164,11 @@ class SynthesisEngine:
                 assert rows is None
                 out.append(torch.randn([batch, r, r], device=self.device, generator=generator))
             else:
-                g = torch.Generator(device=self.device).manual_seed((int(batch_seed) * 64 + li) & 0x7FFFFFFFFFFFFFFF)
-                t = torch.randn([batch, r, r], device=self.device, generator=g)
-                out.append(t if (lo, hi) == (0, batch) else t[lo:hi].contiguous())
+                t = torch.empty([hi - lo, r, r], device=self.device, dtype=torch.float32)
+                with torch.cuda.device(self.device):
+                    _lib.check(lib.la_noise_normal_f32(_lib.ptr(t), hi - lo, r * r, int(batch_seed) & 0xFFFFFFFFFFFFFFFF, li, lo,
+                                                       _lib.stream_ptr()), 'la_noise_normal_f32')
+                out.append(t)
         return out
 
     def noise_pointer_array(self, noises):

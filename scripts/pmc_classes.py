@@ -11,21 +11,9 @@ import json
 import sqlite3
 import sys
 
-CLASS_OF = [
-    ('la_conv_bf16_halo_kernel', 'conv_halo'), ('la_conv_splitk_finish', 'conv_splitk'), ('la_conv_igemm', 'conv_f32'),
-    ('la_presplit', 'operand_prep'), ('la_plane_absmax', 'operand_prep'), ('la_xscale', 'operand_prep'),
-    ('la_fir4x4', 'fir'), ('la_upfirdn2d_kernel', 'fir'), ('la_seam_bwd', 'seam_bwd'), ('la_torgb_fwd', 'torgb_fwd'), ('la_bank', 'bank'),
-]
-LAUNCH_KERNEL = {'conv_splitk': 'la_conv_bf16_kernel'}      # launches of a split-K class = launches of the contraction, not the finish pass
-
-
-def cls(name):
-    if 'la_conv_bf16_kernel' in name:
-        return 'conv_splitk' if ', true,' in name else 'conv_flat'
-    for pat, c in CLASS_OF:
-        if pat in name:
-            return c
-    return None
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from latentaugment_amd.kernel_classes import LAUNCH_KERNEL, class_of as cls      # noqa: E402  (the map bench.py's brackets follow)
 
 
 def totals(path, counter):

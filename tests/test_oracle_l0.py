@@ -98,3 +98,18 @@ def test_modconv_fused_equals_unfused():
         b = ops.modulated_conv2d(x, w, s, noise=nz, up=up, padding=1, resample_filter=f, flip_weight=(up == 1),
                                  fused_modconv=False)
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_philox4x32_10_known_answers():
+    """oracle/noise_ref.py (the checker of la_noise_normal_f32) against the known-answer vectors of the Random123 distribution
+    (kat_vectors: philox4x32 10 rounds): zero counter / key, all ones, and the digits-of-pi counter."""
+    import numpy as np
+    from oracle import noise_ref
+    kat = [((0, 0, 0, 0), (0, 0), '6627e8d5 e169c58d bc57ac4c 9b00dbd8'),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, '408f276d 41c83b0e a20bc7c6 6d5451fd'),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), 'd16cfe09 94fdcceb 5001e420 24126ea1')]
+    for c, k, want in kat:
+        got = noise_ref.philox4x32_10(*[np.uint32(v) for v in c], *k)
+        assert ' '.join(f'{int(v):08x}' for v in got) == want
+    z = noise_ref.noise_normal(16, 16384, seed=99, layer=2)
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.var()) - 1.0) < 0.01
