@@ -498,6 +498,27 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
         }
     }
     if (as.ksplit == 1) {
+        // a windowed 16-bit launch holds the window's tiles only (rounded up to a multiple of 8: one run of tiles per XCD); the kernels
+        // derive the same counts from row_lo / row_hi / col_lo / col_hi
+        if (bf && a.row_hi > 0) {
+            int nt = 0;
+            if (la_conv_bf16_uses_halo(as)) {
+                const int tpr = a.Gx >> 5, r0 = a.row_lo >> 2, r1 = ((a.row_hi < a.Gy ? a.row_hi : a.Gy) + 3) >> 2;
+                int cw = tpr;
+                if (a.col_hi > 0) cw = (((a.col_hi < a.Gx ? a.col_hi : a.Gx) + 31) >> 5) - (a.col_lo >> 5);
+                nt = (r1 - r0) * cw;
+            } else {
+                for (int p = 0; p < (nphase > 0 ? nphase : 1); ++p) {
+                    const int Gy = nphase > 0 ? a.ph[p].Gy : a.Gy, Gx = nphase > 0 ? a.ph[p].Gx : a.Gx;
+                    const int tall = la_cdiv(Gy * Gx, NT), t0 = (a.row_lo * Gx) / NT;
+                    int t1 = la_cdiv((a.row_hi < Gy ? a.row_hi : Gy) * Gx, NT);
+                    if (t1 > tall) t1 = tall;
+                    if (t1 - t0 > nt) nt = t1 - t0;
+                }
+            }
+            const int n8 = (nt + 7) & ~7;
+            if (nt > 0 && n8 < tiles) tiles = n8;
+        }
         dim3 grid(tiles, mtiles, a.B * (nphase > 0 ? nphase : 1));
         if (bf) pcls = la_conv_bf16_uses_halo(as) ? LA_PC_CONV_HALO : LA_PC_CONV_FLAT;
         pslot = la_prof_open(pcls, pflops, pbytes, stream);

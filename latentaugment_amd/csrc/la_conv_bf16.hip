@@ -38,6 +38,9 @@ __device__ __forceinline__ f32x16 la_mma(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 
 #define KCB 32                 // channels per chunk
+#ifndef LA_MF3_DW
+#define LA_MF3_DW 5
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // weight packing: W[o][i][t] (fp32) -> out[term][t][cc][m/32][k/16][lane][8] with (m,k) = (o,i) forward or (i,o) backward.
@@ -493,7 +496,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     constexpr int MF = MFX & 15;
     constexpr bool ABL_PIX = (MFX & 16) != 0, ABL_WGT = (MFX & 32) != 0;
     constexpr bool ABL_BAR = (MFX & 64) != 0, ABL_LDSW = (MFX & 128) != 0;      // (same status) no barrier per step / no LDS write per step
-    static_assert(MF == 0 || (WV == 3 && FMT == FMT_F16X2 && MT == 128), "the 16x16x32 form exists for the three-wave fp16 x2 kernel on 128-row tiles");
+    static_assert(MF == 0 || ((WV == 3 || ((MF == 3 || MF == 4) && WV <= 2)) && FMT == FMT_F16X2 && MT == 128), "the 16x16x32 form exists for the fp16 x2 kernel on 128-row tiles");
+    // MF = 3 (round 5, split-K launches, two waves per SIMD): MF = 1 with the operand loads FOUR steps ahead instead of one.  A K slice of
+    // the small grids is 9-72 (chunk, tap) steps of 48 MFMAs (0.3 us) walked by one or two workgroups per CU: with the weights of step
+    // s + 1 requested during step s (MF 1) every step waited a memory round trip (1.2 us per step at 4^2 .. 16^2, whose weights come from
+    // beyond L2, each byte once) -- nothing else is resident to cover it.  Here the weight fragments of steps s .. s + 3 and the pixel
+    // pieces of steps s + 1 .. s + 3 are in registers / in flight (rings of four, loop unrolled by four so that the slots are static;
+    // 128 more registers, hence two waves per SIMD), in ONE issue order in the prologue and in the loop so that every wait is a count.
     // MF = 2: MF = 1 on THREE pixel buffers.  The barrier at the end of step s then publishes the buffer of step s + 2, so the buffer of
     // step s + 1 is already complete while step s computes: its first fragments are read under the last MFMAs of step s, and no LDS
     // read latency is left exposed behind the barrier (two buffers: every step began with eight fragment reads nothing could cover).
@@ -544,18 +553,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         // first nt workgroups of the launch take them (in the XCD-aware order below, so the run is spread over all XCDs), the rest return
         int t0 = 0, nt = (int)gridDim.x;
         if (a.row_hi > 0) {
+            // (round 5, as the halo kernel: the launch holds the window's tiles only, rounded up to a multiple of eight -- for merged phases
+            //  those of the phase with the most -- and its workgroups zero the partials of the tiles outside the window in turn)
             const int tall = (G + NT - 1) / NT;
             t0 = (a.row_lo * a.Gx) / NT;
             int t1 = ((a.row_hi < a.Gy ? a.row_hi : a.Gy) * a.Gx + NT - 1) / NT;
             t1 = t1 < tall ? t1 : tall;
             nt = t1 - t0;
-            if ((int)blockIdx.x >= nt) {      // this workgroup stands for one of the tiles outside the window: [0, t0) then [t0 + nt, tall)
-                const int j = (int)blockIdx.x - nt;
-                if (j < tall - nt) la_conv_zero_partials<MT>(a, bz, m0, j < t0 ? j : j + nt);
-                return;
-            }
-        }
-        if ((nt & 7) == 0) ntile = (blockIdx.x & 7) * (nt >> 3) + (blockIdx.x >> 3);
+            for (int j = (int)blockIdx.x; j < tall - nt; j += (int)gridDim.x) la_conv_zero_partials<MT>(a, bz, m0, j < t0 ? j : j + nt);
+            const int n8 = (int)gridDim.x;
+            if ((n8 & 7) == 0) ntile = (blockIdx.x & 7) * (n8 >> 3) + (blockIdx.x >> 3);
+            if (ntile >= nt) return;
+        } else if ((nt & 7) == 0) ntile = (blockIdx.x & 7) * (nt >> 3) + (blockIdx.x >> 3);
         ntile += t0;
     }
     if (!SPLIT && (long)ntile * NT >= G) return;          // merged phases: the launch is sized for the largest phase
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     // ---- B gather of one step: 16 channels of this thread's pixel = 64 / 128 contiguous bytes
     unsigned ex[16], ey[NTERM == 3 ? 16 : 1];
     bool ok_r = false;
-    auto load_b = [&](int cc, int t) {
+    auto load_b = [&](int cc, int t, unsigned kill = 0u) {      // kill = OOB (uniform): the pieces read as zeros whatever the tap (MF 3's padding steps)
         if constexpr (ABL_PIX) { if (t != 0) return; }
         if constexpr (PIECES) {
             const int dy = (int)((dypack >> (4 * t)) & 15u) - 8, dx = (int)((dxpack >> (4 * t)) & 15u) - 8;
@@ -649,7 +658,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int bad = __builtin_amdgcn_sbfe((int)pinv[k], (unsigned)t, 1u);      // -1: the tap is outside the image for this piece
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (plin[k] + delta) | ((unsigned)bad & OOB), so, 0);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (plin[k] + delta) | ((unsigned)bad & OOB) | kill, so, 0);
                 ex[4 * k] = v.x; ex[4 * k + 1] = v.y; ex[4 * k + 2] = v.z; ex[4 * k + 3] = v.w;
             }
             return;
@@ -793,7 +802,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         };
         f16x8 a16[2][2], b16[4][2];
         const int c0 = c1, t0 = t1;      // (prologue in the loop's issue order: see the 32x32x16 form below)
-      if constexpr (MF == 2) {
+      if constexpr (MF == 3 || MF == 4) {
+        constexpr int DW = MF == 4 ? 9 : 3;            // weight ring depth = unroll factor (9-tap slices: no padding step).  MF 4 (one wave per SIMD,
+                                                       // launches of at most one workgroup per CU): a whole 9-step slice's weights are requested up front
+        f16x8 wr[DW][2][2];                            // weight fragments [slot][16-row half][term]
+        // The loop walks the steps three at a time in straight-line code (static ring slots, one entry and one exit: the waits stay counts
+        // and the accumulators keep one home); a slice whose step count is not a multiple of three is padded with steps whose pixel
+        // pieces read as zeros (out-of-range buffer offsets) under re-loaded weights: they add exact zeros.
+        // Issue order, prologue and loop alike:  P(0) | W(0) W(1) | [P(0) -> LDS] P(1) W(2) | iteration s: [P(s+1) -> LDS] P(s+2) W(s+3)
+        // -- the wait for P(s+1) covers the weights up to step s+1 and leaves W(s+2) in flight: two steps for a weight fragment to arrive
+        // where MF 1 gives it half a step.
+        int cw = ck_beg, tw = 0;
+        auto load_w = [&](int d) {                     // (d: a constant after unrolling)
+            load_a16(cw, tw, 0, wr[d][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a16(cw, tw, 1, wr[d][1]); adv(cw, tw);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        load_b(c0, t0);
+        adv(c1, t1);                                   // (c1, t1) = step 1
+        int c2 = c1, t2 = t1;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < DW - 1; ++d) load_w(d);
+        write_b(smem);                                 // step 0 -> buffer 0
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(c1, t1, nstep > 1 ? 0u : OOB);          // step 1
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(DW - 1);
+        __syncthreads();
+        adv(c2, t2);                                   // (c2, t2) = step 2
+        auto body = [&](int D, int s) {                // (D: a constant after unrolling)
+            const unsigned char* cur = smem + (s & 1) * BBUF;
+            unsigned char* nxt = smem + ((s + 1) & 1) * BBUF;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) read_b16(cur, n, b16[n]);
+            write_b(nxt);                              // step s+1 (requested during step s-1)
+            load_b(c2, t2, s + 2 < nstep ? 0u : OOB); adv(c2, t2);      // step s+2 (zeros past the slice's last step)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    f16x8 (&bs)[2] = b16[n & 3];
+                    acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[D][mi][1], bs[0], acc16[mi][n], 0, 0, 0);   // lh
+                    acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[D][mi][0], bs[1], acc16[mi][n], 0, 0, 0);   // hl
+                    acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[D][mi][0], bs[0], acc16[mi][n], 0, 0, 0);   // hh
+                    if (n < 4) read_b16(cur, n + 4, bs);
+                    else if (mi == 0) read_b16(cur, n - 4, bs);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                load_a16(cw, tw, mi, wr[D][mi]);       // this half's weights of step s+3
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            adv(cw, tw);
+            __syncthreads();
+        };
+#pragma unroll 1
+        for (int s = 0; s < nstep; s += DW) {
+#pragma unroll
+            for (int d = 0; d < DW; ++d) body(d, s + d);
+        }
+      } else if constexpr (MF == 2) {
         load_b(c0, t0);
         adv(c1, t1);                                   // (c1, t1) = step 1
         int c2 = c1, t2 = t1;
@@ -1103,26 +1173,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     // row window (LaConvArgs::row_lo): the 4-row tiles that hold a wanted row are the run [t0, t0 + nt) of the row-major tile order; the
     // first nt workgroups of the launch take them -- in the XCD-aware order, so that the run is spread over all eight XCDs (a test on the
     // tile row alone left the XCDs that own the top and the bottom of the frame idle and the launch as long as before) -- the rest return
+    // Round 5: the launch holds the window's tiles ONLY, rounded up to a multiple of eight workgroups (la_conv_window_tiles; round 4 launched
+    // a workgroup per tile of the whole frame and let those outside the window return: a launch with 1 104 wanted tiles of 2 048 took
+    // ~30 us longer than the wanted tiles alone).  Workgroup x of the launch takes tile (x & 7) * (n8 / 8) + (x >> 3) of the window's
+    // row-major run -- a contiguous run of tiles per XCD whatever the tile count (round 4 fell back to the plain order whenever the
+    // count was not a multiple of eight: the 256^2 and 64^2 windows of config B) -- and the per-tile partials of the tiles outside
+    // the window, which the one-pass style finish sums, are zeroed by the launch's workgroups in turn.
     int nt = (int)gridDim.x;
     int r0 = 0, c0 = 0, cw = tpr;                 // window rectangle in tiles: rows [r0, r1), columns [c0, c0 + cw)
+    int ntile = blockIdx.x;
     if (a.row_hi > 0) {
         const int r1 = ((a.row_hi < a.Gy ? a.row_hi : a.Gy) + 3) >> 2;
         r0 = a.row_lo >> 2;
         if (a.col_hi > 0) { c0 = a.col_lo >> 5; cw = (((a.col_hi < a.Gx ? a.col_hi : a.Gx) + 31) >> 5) - c0; }
         nt = (r1 - r0) * cw;
-        if ((int)blockIdx.x >= nt) {      // this workgroup stands for one of the tiles outside the window
-            int j = (int)blockIdx.x - nt, otile;
+        const int tall = (a.Gy >> 2) * tpr, n_out = tall - nt;
+        for (int j = (int)blockIdx.x; j < n_out; j += (int)gridDim.x) {      // tiles outside the window, in row-major order
+            int otile, k = j;
             const int per = tpr - cw;             // outside tiles per window row
-            if (j < r0 * tpr) otile = j;
-            else if ((j -= r0 * tpr) < (r1 - r0) * per) { const int rr = j / per, k = j - rr * per; otile = (r0 + rr) * tpr + (k < c0 ? k : k + cw); }
-            else otile = r1 * tpr + (j - (r1 - r0) * per);
+            if (k < r0 * tpr) otile = k;
+            else if ((k -= r0 * tpr) < (r1 - r0) * per) { const int rr = k / per, kk = k - rr * per; otile = (r0 + rr) * tpr + (kk < c0 ? kk : kk + cw); }
+            else otile = r1 * tpr + (k - (r1 - r0) * per);
             la_conv_zero_partials<MT>(a, (int)blockIdx.z, (int)blockIdx.y * MT, otile);
-            return;
         }
-    }
-    int ntile = blockIdx.x;
-    if ((nt & 7) == 0) ntile = (blockIdx.x & 7) * (nt >> 3) + (blockIdx.x >> 3);   // XCD-contiguous tile runs
-    if (a.row_hi > 0) { const int rr = ntile / cw; ntile = (r0 + rr) * tpr + c0 + (ntile - rr * cw); }
+        const int n8 = (int)gridDim.x;            // (host: the window's tile count rounded up to a multiple of 8, or the whole frame's)
+        if ((n8 & 7) == 0) ntile = (blockIdx.x & 7) * (n8 >> 3) + (blockIdx.x >> 3);
+        if (ntile >= nt) return;
+        const int rr = ntile / cw;
+        ntile = (r0 + rr) * tpr + c0 + (ntile - rr * cw);
+    } else if ((nt & 7) == 0) ntile = (blockIdx.x & 7) * (nt >> 3) + (blockIdx.x >> 3);   // XCD-contiguous tile runs
     const int m0 = blockIdx.y * MT;
     const int b = blockIdx.z;
     const int G = a.Gy * a.Gx;
@@ -1739,6 +1818,17 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
 #endif
             if (three && !split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT_F16X2, 3, 2>), grid, dim3(256), lds_3, stream, as);
             else if (fk == 2 && split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT_F16X2, 3, 2>), grid, dim3(256), lds_3, stream, as);
+#ifdef LA_DEV
+            else if (split && (fk == 11 || fk == 12)) {
+                // round-5 experiment, measured and NOT faster (profiles/r05_exp_splitk_prefetch.txt): weights three steps ahead (MF 3, two
+                // waves per SIMD; knob 11), and on top of it launches of at most one workgroup per CU whose slices are whole 9-tap chunks with a
+                // slice's first nine steps of weights requested up front, at one wave per SIMD (MF 4; knob 12).  Bit-identical to MF 1.
+                const long wgs = (long)grid.x * grid.y * grid.z;
+                const bool whole9 = as.nphase == 0 && as.ntaps == 9;
+                if (fk == 12 && wgs <= 256 && whole9) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT_F16X2, 1, 4>), grid, dim3(256), lds_mf, stream, as);
+                else hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT_F16X2, 2, 3>), grid, dim3(256), lds_mf, stream, as);
+            }
+#endif
             else if (split) hipLaunchKernelGGL((la_conv_bf16_kernel<128, true, FMT_F16X2, 3, 1>), grid, dim3(256), lds_mf, stream, as);
             else hipLaunchKernelGGL((la_conv_bf16_kernel<128, false, FMT_F16X2, 3, 1>), grid, dim3(256), lds_mf, stream, as);
             return LA_OK;

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void la_noise_normal_kernel(float* __restrict_
 }
 
 extern "C" int la_noise_normal_f32(float* out, long rows, long row_elems, unsigned long long seed, unsigned layer, long row0, hipStream_t stream) {
-    LA_CHECK_ARG(out && rows >= 0 && row_elems >= 1 && row0 >= 0, "noise_normal: bad arguments");
+    LA_CHECK_ARG((out || rows == 0) && rows >= 0 && row_elems >= 1 && row0 >= 0, "noise_normal: bad arguments");
     LA_CHECK_ARG(row0 + rows <= 0xffffffffl, "noise_normal: row index exceeds 32 bits");
     if (rows == 0) return LA_OK;
     const long n = rows * ((row_elems + 3) >> 2);
