@@ -3,9 +3,19 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import sg2_networks as nets
+from latentaugment_amd import _lib
+if os.environ.get('LA_LIB'):
+    import ctypes
+    _lib.LIB_PATH = os.environ['LA_LIB']
+    import torch as _t  # noqa
+    _probe = ctypes.CDLL(_lib.LIB_PATH)
+    for _k in list(_lib.SIGNATURES):
+        if not hasattr(_probe, _k):
+            del _lib.SIGNATURES[_k]
 from latentaugment_amd.synthesis import DiscriminatorEngine
 dev = torch.device('cuda:0')
-for shrink in (1.0, 2.0 ** -4, 2.0 ** -8, 2.0 ** -13):
+MODE = os.environ.get('DL_MODE', 'rand')
+for shrink in (1.0, 2.0 ** -13):
     D = nets.make_discriminator(img_resolution=64, img_channels=2, channel_base=4096, channel_max=128, seed=2)
     with torch.no_grad():
         for n, p in D.named_parameters():
@@ -16,6 +26,11 @@ for shrink in (1.0, 2.0 ** -4, 2.0 ** -8, 2.0 ** -13):
     x = torch.randn([4, 2, 64, 64], generator=gen)
     x[2] *= shrink
     dl = torch.randn([4, 1], generator=gen)
+    if MODE == 'ones':
+        dl = torch.ones([4, 1])
+    elif MODE == 'flip':
+        dl = dl.flip(0).contiguous()
+    print('dl', dl.flatten().tolist())
     res = {}
     for dt in (torch.float32, torch.float64):
         Dd = D.to(dt)
