@@ -63,7 +63,8 @@ int la_demod_forward(const LaDemodTable& t, const float* s_all, int s_stride, in
 struct LaTorgbMask { const float* y; int act; float alpha, gain, clamp; };
 int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_stride, const float* bias,
                      const float* skip, float* rgb_pre, float* img, int B, int C, int imgc, int H, int W, float clamp,
-                     hipStream_t, const LaTorgbMask* mask = nullptr, int row_lo = 0, int row_hi = 0);
+                     hipStream_t, const LaTorgbMask* mask = nullptr, int row_lo = 0, int row_hi = 0, const float* skip_lo = nullptr,
+                     const float* fir_host = nullptr);      // skip_lo + fir_host: the block below's image, up-sampled inside the kernel
 // row_lo / row_hi (planes above 64x64; 0 / 0 = all): only these rows of rgb_pre / img are computed and written
 int la_seam_slabs(long HW);
 int la_seam_backward(const LaSeamArgs& a, int B, int imgc, hipStream_t);

@@ -189,12 +189,44 @@ int la_xscale_from_bounds(const LaDemodTable& t, const float* s_all, int s_strid
 // ToRGB forward (+ skip add):  rgb_pre[b][c][p] = sum_i wrgb[c][i] * s[b][i] * x[b][i][p] + bias[c]
 //                              img[b][c][p]     = clamp(rgb_pre) + (skip ? skip[b][c][p] : 0)
 // Streams x once (HBM-bound); lanes = consecutive pixels, 4 pixels per thread (float4).
+// Skip image of a ToRGB layer computed on the fly (round 5): img = upsample2d(img_prev) + rgb needs the up-sampled image of the block
+// below at the pixels this thread writes -- four consecutive pixels of one row read 2 x 4 values of the (tiny, 2-channel) low-resolution
+// image.  Arithmetic = la_fir4x4_up2_kernel's (la_upfirdn2d.hip: taps in ascending row, column order), so the image equals the one the
+// separate up-2 launch + skip read produced; that launch (one 5 us link of a step's serial chain per block) is gone for every block
+// whose ToRGB is its own kernel.
+struct LaSkipUp { const float* lo; int Hl, Wl; float f[16]; };      // lo: [B][imgc][Hl][Wl] (null: none); f: the up-2 taps (gain included)
+__device__ __forceinline__ float4 la_up2_quad(const float* __restrict__ ip, int Hl, int Wl, const float* f, int Y, int x0) {
+    const int i = Y >> 1, py = Y & 1, j0 = x0 >> 1;
+    float v[2][4];                                               // in[i + py - 1 + ua][j0 - 1 .. j0 + 2], zero outside
+#pragma unroll
+    for (int ua = 0; ua < 2; ++ua) {
+        const int iy = i - 1 + py + ua;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ix = j0 - 1 + c;
+            v[ua][c] = (iy >= 0 && iy < Hl && ix >= 0 && ix < Wl) ? ip[(long)iy * Wl + ix] : 0.f;
+        }
+    }
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int px = k & 1, jj = k >> 1;
+        float s = 0.f;
+#pragma unroll
+        for (int ua = 0; ua < 2; ++ua)
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub) s += v[ua][jj + px + ub] * f[(py + 2 * ua) * 4 + px + 2 * ub];
+        o[k] = s;
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+
 template <int IMGC>
 __global__ __launch_bounds__(256) void la_torgb_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wrgb,
                                                           const float* __restrict__ s, int s_stride,
                                                           const float* __restrict__ bias, const float* __restrict__ skip,
                                                           float* __restrict__ rgb_pre, float* __restrict__ img, int C,
-                                                          long HW, float clamp, LaTorgbMask mk, long p_lo, long p_hi) {
+                                                          long HW, float clamp, LaTorgbMask mk, long p_lo, long p_hi, LaSkipUp su) {
     extern __shared__ float weff[];   // [IMGC][C]
     const int b = blockIdx.y;
     for (int k = threadIdx.x; k < IMGC * C; k += blockDim.x) {
@@ -263,6 +295,10 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_kernel(const float* __restri
         if (skip) {
             const float4 sv = *reinterpret_cast<const float4*>(skip + o);
             v.x += sv.x; v.y += sv.y; v.z += sv.z; v.w += sv.w;
+        } else if (su.lo) {
+            const int W = 2 * su.Wl;
+            const float4 sv = la_up2_quad(su.lo + ((long)b * IMGC + c) * su.Hl * su.Wl, su.Hl, su.Wl, su.f, (int)(p4 / W), (int)(p4 % W));
+            v.x += sv.x; v.y += sv.y; v.z += sv.z; v.w += sv.w;
         }
         *reinterpret_cast<float4*>(img + o) = v;
     }
@@ -275,7 +311,7 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_small_kernel(const float* __
                                                                 const float* __restrict__ s, int s_stride,
                                                                 const float* __restrict__ bias, const float* __restrict__ skip,
                                                                 float* __restrict__ rgb_pre, float* __restrict__ img, int C,
-                                                                long HW, float clamp, int px_lanes) {
+                                                                long HW, float clamp, int px_lanes, LaSkipUp su) {
     extern __shared__ float sm[];     // weff [IMGC][C]  then  comb [parts][px_lanes][IMGC] float4
     float* weff = sm;
     float4* comb = reinterpret_cast<float4*>(sm + ((IMGC * C + 3) & ~3));
@@ -339,6 +375,10 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_small_kernel(const float* __
         if (skip) {
             const float4 sv = *reinterpret_cast<const float4*>(skip + o);
             v.x += sv.x; v.y += sv.y; v.z += sv.z; v.w += sv.w;
+        } else if (su.lo) {
+            const int W = 2 * su.Wl;
+            const float4 sv = la_up2_quad(su.lo + ((long)b * IMGC + c) * su.Hl * su.Wl, su.Hl, su.Wl, su.f, (int)(p4 / W), (int)(p4 % W));
+            v.x += sv.x; v.y += sv.y; v.z += sv.z; v.w += sv.w;
         }
         *reinterpret_cast<float4*>(img + o) = v;
     }
@@ -346,7 +386,17 @@ __global__ __launch_bounds__(256) void la_torgb_fwd_small_kernel(const float* __
 
 int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_stride, const float* bias,
                      const float* skip, float* rgb_pre, float* img, int B, int C, int imgc, int H, int W, float clamp,
-                     hipStream_t stream, const LaTorgbMask* mask, int row_lo, int row_hi) {
+                     hipStream_t stream, const LaTorgbMask* mask, int row_lo, int row_hi, const float* skip_lo, const float* fir_host) {
+    // skip_lo (instead of skip): the image of the block below [B][imgc][H/2][W/2]; its upsample2d (up 2, pad (2,1,2,1), gain 4, upfirdn2d.py:342-348)
+    // is computed inside the kernel (la_up2_quad) with the 4x4 filter fir_host
+    LaSkipUp su; su.lo = nullptr; su.Hl = H / 2; su.Wl = W / 2;
+    for (int k = 0; k < 16; ++k) su.f[k] = 0.f;
+    if (skip_lo) {
+        LA_CHECK_ARG(!skip && fir_host && H % 2 == 0 && W % 4 == 0, "torgb: the on-the-fly skip image needs the filter, even rows and W % 4 == 0");
+        su.lo = skip_lo;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) su.f[i * 4 + j] = 4.f * fir_host[(3 - i) * 4 + (3 - j)];      // (fir_fill: gain * flipped filter)
+    }
     const long HW = (long)H * W;
     LA_CHECK_ARG(row_lo >= 0 && (row_hi == 0 || (row_hi > row_lo && row_hi <= H)), "torgb: bad row window");
     const long p_lo = (long)row_lo * W, p_hi = (long)row_hi * W;
@@ -364,7 +414,7 @@ int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_st
         while (px_lanes < 64 && px_lanes * 2 <= nq) px_lanes *= 2;
         dim3 grid((unsigned)la_cdiv(nq, px_lanes), B);
         const size_t lds = (size_t)((imgc * C + 3) & ~3) * sizeof(float) + (size_t)256 * imgc * sizeof(float4);
-#define LAUNCH(N) hipLaunchKernelGGL(la_torgb_fwd_small_kernel<N>, grid, dim3(256), lds, stream, x, wrgb, s, s_stride, bias, skip, rgb_pre, img, C, HW, clamp, px_lanes)
+#define LAUNCH(N) hipLaunchKernelGGL(la_torgb_fwd_small_kernel<N>, grid, dim3(256), lds, stream, x, wrgb, s, s_stride, bias, skip, rgb_pre, img, C, HW, clamp, px_lanes, su)
         switch (imgc) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
         LA_CHECK_LAUNCH();
@@ -372,7 +422,7 @@ int la_torgb_forward(const float* x, const float* wrgb, const float* s, int s_st
     }
     dim3 grid(la_cdiv(HW / 4, 256), B);
     const size_t lds = (size_t)imgc * C * sizeof(float);
-#define LAUNCH(N) hipLaunchKernelGGL(la_torgb_fwd_kernel<N>, grid, dim3(256), lds, stream, x, wrgb, s, s_stride, bias, skip, rgb_pre, img, C, HW, clamp, mk, p_lo, p_hi)
+#define LAUNCH(N) hipLaunchKernelGGL(la_torgb_fwd_kernel<N>, grid, dim3(256), lds, stream, x, wrgb, s, s_stride, bias, skip, rgb_pre, img, C, HW, clamp, mk, p_lo, p_hi, su)
     switch (imgc) { case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; default: LAUNCH(4); }
 #undef LAUNCH
     LA_CHECK_LAUNCH();

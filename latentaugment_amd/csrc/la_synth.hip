@@ -439,17 +439,12 @@ extern "C" int la_synth_forward(la_synth* h, const float* ws, long ws_bstride, l
             x = L.y; x_bstride = (long)L.cout * res * res;
         }
         if (!fuse_rgb) {
-            if (k > 0) {
-                // img = upsample2d(img_prev, f): up 2, pad (2,1,2,1), gain 4 (upfirdn2d.py:342-348); result parked in g_img scratch
-                RgbLayer& P = h->rgb[k - 1];
-                if ((rc = la_upfirdn2d_ex(P.img, T.g_img, B, h->imgc, res / 2, res / 2, h->fir, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1, 0,
-                                          4.f, nullptr, stream)))
-                    return rc;
-                skip = T.g_img;
-            }
+            // img = upsample2d(img_prev, f) + torgb(x): up 2, pad (2,1,2,1), gain 4 (upfirdn2d.py:342-348) -- the up-sampled image of the block
+            // below is computed inside the ToRGB kernel (la_up2_quad; round 4: a launch of its own per block, parked in g_img)
+            const float* skip_lo = k > 0 ? h->rgb[k - 1].img : nullptr;
             const bool iw = ihi[k] > 0 && (long)res * res > 4096;      // (windowed block: only the image rows somebody reads)
-            if ((rc = la_torgb_forward(x, T.weight, h->s_all + T.s_off, h->S, T.bias, skip, T.rgb_pre, rgb_dst, B, T.cin, h->imgc,
-                                       res, res, h->clamp, stream, nullptr, iw ? ilo[k] : 0, iw ? ihi[k] : 0)))
+            if ((rc = la_torgb_forward(x, T.weight, h->s_all + T.s_off, h->S, T.bias, nullptr, T.rgb_pre, rgb_dst, B, T.cin, h->imgc,
+                                       res, res, h->clamp, stream, nullptr, iw ? ilo[k] : 0, iw ? ihi[k] : 0, skip_lo, h->fir)))
                 return rc;
         }
         if (k == h->nblocks - 1) h->final_img = rgb_dst;
@@ -486,6 +481,7 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
     const float up_mult = la_modconv_up2_bwd_xs_mult(h->fir);
     auto xs_slot = [&](int conv_index) { return xs_hand ? h->xs_bwd + (long)conv_index * B * LA_XS_FAN : nullptr; };
     bool seam2_done = false;      // this block's conv1 seam was already applied by the epilogue of the up layer's backward above it
+    bool pyramid_done = false;    // the image-gradient levels below the current block exist already (la_image_grad_pyramid)
     // Row windows (la_synth_set_row_window): the gradient of a conv output is non-zero only inside the rows its forward window covers (the
     // window IS the cone of the image window), so the backward pass of a windowed forward pass reads, computes and writes those rows only:
     // a producer writes its window, its consumer reads everything outside it as zeros (LaBwdRows) -- the ping-pong buffers G0 / G1 hold
@@ -574,9 +570,18 @@ extern "C" int la_synth_backward(la_synth* h, const float* g_img, float* dws, hi
         // ---- image gradient one level down: adjoint of upsample2d = FIR (flipped) + decimate 2, pad (1,1,1,1), gain 4
         // (before the up layer's backward contraction: its epilogue may apply the block below's ToRGB backward)
         RgbLayer& P = h->rgb[k - 1];
-        if ((rc = la_upfirdn2d_ex(gi, P.g_img, B, h->imgc, res, res, h->fir, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1, 1, 4.f, nullptr,
-                                  stream)))
-            return rc;
+        if (!pyramid_done) {
+            if ((rc = la_upfirdn2d_ex(gi, P.g_img, B, h->imgc, res, res, h->fir, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1, 1, 4.f, nullptr,
+                                      stream)))
+                return rc;
+            // every level below in ONE launch (la_image_grad_pyramid: the levels depend on the image gradient only), from <= 256^2 inputs
+            if (k >= 2 && res / 2 <= 256) {
+                float* outs[MAX_BLOCKS];
+                for (int q = k - 2; q >= 0; --q) outs[k - 2 - q] = h->rgb[q].g_img;
+                if ((rc = la_image_grad_pyramid(P.g_img, outs, k - 1, B * h->imgc, res / 2, h->fir, stream))) return rc;
+                pyramid_done = true;
+            }
+        }
         const bool fuse_seam2 = h->precision != LA_PREC_F32 && !no_fuse2;
         {
             const int hin = res / 2;

@@ -38,3 +38,7 @@ int la_fir4x4_adjoint_pack_f16(const float* in, unsigned* q, const float* xscale
                                float gain, hipStream_t stream, int flip_taps = 0, int in_lo = 0, int in_hi = 0, int out_lo = 0, int out_hi = 0, int in_c0 = 0, int in_c1 = 0);
 // in_lo / in_hi: valid rows of `in` (the others read as zeros); out_lo / out_hi: row window of the (H+1)-row output (0 / 0 = all)
 // flip_taps = 1: the forward 4x4 FIR with pad 2 (same geometry: (H+1) x (W+1) outputs) instead of the adjoint of the pad-1 FIR
+
+// The image-gradient pyramid of a synthesis backward pass in one launch: outs[l] [planes][R0 >> (l+1)]^2 = adjoint of upsample2d applied l + 1
+// times to g_top [planes][R0]^2 (per level exactly la_upfirdn2d_ex(.., down 2, pad (1,1,1,1), flip, gain 4)); R0 <= 256.
+int la_image_grad_pyramid(const float* g_top, float* const* outs, int nlev, int planes, int R0, const float* f_host, hipStream_t stream);

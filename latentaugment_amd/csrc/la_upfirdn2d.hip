@@ -2,6 +2,7 @@
 // Semantics follow models/stylegan3/torch_utils/ops/upfirdn2d.py:167-211 (ref) / upfirdn2d.cu:29-92.
 // HBM-bound: each output reads <= ceil(fh/up)*ceil(fw/up) inputs (L1/L2 hits), one coalesced store.
 #include "la_upfirdn2d.h"
+#include <atomic>
 #include <stdlib.h>
 
 #define FIR_MAX 8
@@ -452,6 +453,78 @@ __global__ __launch_bounds__(256) void la_fir4x4_down2_kernel(FirArgs a) {    //
     const long pos = (long)y * a.Wout + 2 * q;
     if (a.addend) { o[0] += a.addend[(long)p * HWout + pos]; o[1] += a.addend[(long)p * HWout + pos + 1]; }
     *reinterpret_cast<float2*>(a.out + (long)p * HWout + pos) = make_float2(o[0], o[1]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The image-gradient pyramid of a synthesis backward pass in ONE launch (round 5; was one la_fir4x4_down2_kernel launch per block:
+// six 5 us links on the serial chain of a step at 256^2).  The gradient of the image at level k-1 is the adjoint of upsample2d applied
+// to the gradient at level k (upfirdn2d.py:255-266 via :342-348: flipped 4x4 taps, decimate 2, pad (1,1,1,1), gain 4) and depends on
+// nothing else, so one workgroup per (sample, channel) plane walks the levels: the first level is read from global memory, every
+// later one from the LDS copy of the level above (ping-pong), each level is also written to its block's g_img.  (The caller keeps
+// the top level's own launch -- 256 workgroups against one per plane here -- and hands this kernel the levels from 128^2 down.)
+// Arithmetic per output = la_fir4x4_down2_kernel's (taps in ascending row, column order).  Levels whose OUTPUT exceeds 128^2
+// (generators above 256^2) keep their own launches.
+struct PyrArgs { const float* top; float* out[12]; int nlev, R0; float f[16]; };      // out[l]: [planes][R0 >> (l + 1)]^2
+__global__ __launch_bounds__(1024) void la_imgrad_pyramid_kernel(PyrArgs a) {
+    extern __shared__ float lds[];
+    const int p = blockIdx.x;
+    int Rin = a.R0;
+    float* bufA = lds;                                  // levels 0, 2, 4, ..  ([R0/2]^2 floats)
+    float* bufB = lds + (size_t)(a.R0 >> 1) * (a.R0 >> 1);      // levels 1, 3, ..  ([R0/4]^2 floats)
+    for (int l = 0; l < a.nlev; ++l) {
+        const int Ro = Rin >> 1;
+        const float* gin = l == 0 ? a.top + (size_t)p * Rin * Rin : nullptr;
+        const float* lin = l == 0 ? nullptr : ((l & 1) ? bufA : bufB);
+        float* lout = (l & 1) ? bufB : bufA;
+        float* gout = a.out[l] + (size_t)p * Ro * Ro;
+        for (int o = threadIdx.x; o < Ro * Ro; o += 1024) {
+            const int y = o / Ro, x = o - y * Ro;
+            float s = 0.f;
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta) {
+                const int iy = 2 * y - 1 + ta;
+                const bool rok = iy >= 0 && iy < Rin;
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb) {
+                    const int ix = 2 * x - 1 + tb;
+                    float v = 0.f;
+                    if (rok && ix >= 0 && ix < Rin) v = gin ? gin[(size_t)iy * Rin + ix] : lin[iy * Rin + ix];
+                    s += v * a.f[ta * 4 + tb];
+                }
+            }
+            lout[o] = s;
+            gout[o] = s;
+        }
+        __syncthreads();
+        Rin = Ro;
+    }
+}
+
+// outs[l] = gradient planes at resolution R0 >> (l + 1), l = 0 .. nlev-1; needs (R0/2)^2 * 4 <= 64 KB (R0 <= 256)
+int la_image_grad_pyramid(const float* g_top, float* const* outs, int nlev, int planes, int R0, const float* f_host, hipStream_t stream) {
+    LA_CHECK_ARG(g_top && outs && nlev >= 1 && nlev <= 12 && planes >= 1 && R0 >= 2 && R0 <= 256 && (R0 >> nlev) >= 1, "image_grad_pyramid: bad arguments");
+    FirArgs fa; int ho, wo;
+    int rc = fir_fill(fa, g_top, outs[0], planes, 1, R0, R0, f_host, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1, 1, 4.f, &ho, &wo);      // (the taps as the per-level launches build them)
+    if (rc) return rc;
+    PyrArgs a;
+    a.top = g_top; a.nlev = nlev; a.R0 = R0;
+    for (int l = 0; l < 12; ++l) a.out[l] = l < nlev ? outs[l] : nullptr;
+    for (int k = 0; k < 16; ++k) a.f[k] = fa.f[k];
+    const size_t ldsb = ((size_t)(R0 >> 1) * (R0 >> 1) + (size_t)(R0 >> 2) * (R0 >> 2)) * sizeof(float);
+    static std::atomic<bool> attr_done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (ldsb > 65536 && !attr_done[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&la_imgrad_pyramid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
+            la_set_error("image_grad_pyramid: hipFuncSetAttribute failed"); return LA_ERR_HIP;
+        }
+        attr_done[dev].store(true, std::memory_order_release);
+    }
+    const int slot = la_prof_open(LA_PC_FIR, 2.0 * 16 * planes * (double)(R0 / 2) * (R0 / 2) * 4.0 / 3.0, 4.0 * planes * (double)R0 * R0 * 1.67, stream);
+    hipLaunchKernelGGL(la_imgrad_pyramid_kernel, dim3(planes), dim3(1024), ldsb, stream, a);
+    la_prof_close(slot, stream);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
 }
 
 static int fir_launch_inner(const FirArgs& a, hipStream_t stream);
