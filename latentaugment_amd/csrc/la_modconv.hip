@@ -48,6 +48,7 @@ int la_modconv3x3_fwd_ex(const float* x, long x_bstride, const float* in_pmax, i
     LA_CHECK_ARG(row_lo >= 0 && (row_hi == 0 || (row_hi > row_lo && row_hi <= res)), "modconv_fwd: bad row window");
     LaConvArgs a; base_args(a);
     a.row_lo = row_lo; a.row_hi = row_hi;
+    a.col_lo = col_lo; a.col_hi = col_hi;      // (round 4 took the arguments and never passed them on: the forward conv1 of the top block computed every tile column)
     a.fwd_xs_out = xs_out; a.fwd_xs_mult = xs_mult;
     if (rgb) {
         LA_CHECK_ARG(rgb->imgc >= 1 && rgb->imgc <= 4 && rgb->w && rgb->s && rgb->rgb_pre && rgb->img && la_modconv3x3_fwd_fuses_rgb(precision, B, cin, cout, res),
