@@ -1197,8 +1197,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             la_conv_zero_partials<MT>(a, (int)blockIdx.z, (int)blockIdx.y * MT, otile);
         }
         const int n8 = (int)gridDim.x;            // (host: the window's tile count rounded up to a multiple of 8, or the whole frame's)
-        if ((n8 & 7) == 0) ntile = (blockIdx.x & 7) * (n8 >> 3) + (blockIdx.x >> 3);
-        if (ntile >= nt) return;
+        if ((n8 & 7) == 0) {
+            // eight runs of tiles, one per XCD, as even as the count allows (nt = 8 q + r: the first r runs hold q + 1 tiles); the run an
+            // XCD takes rotates with the sample, so that over the samples of a launch every XCD sees long and short runs alike (the
+            // 28-tile window at 64^2 with one fixed run per XCD: 4 4 4 4 4 4 4 0 tiles per sample; rotated: 28 per XCD over 8 samples)
+            const int q = nt >> 3, r = nt & 7, rot = gridDim.z >= 8 ? 1 : (gridDim.z >= 4 ? 2 : (gridDim.z >= 2 ? 4 : 0));
+            const int kv = (int)((blockIdx.x + blockIdx.z * rot) & 7), idx = (int)(blockIdx.x >> 3);
+            if (idx >= q + (kv < r ? 1 : 0)) return;
+            ntile = kv * q + (kv < r ? kv : r) + idx;
+        } else if (ntile >= nt) return;
         const int rr = ntile / cw;
         ntile = (r0 + rr) * tpr + c0 + (ntile - rr * cw);
     } else if ((nt & 7) == 0) ntile = (blockIdx.x & 7) * (nt >> 3) + (blockIdx.x >> 3);   // XCD-contiguous tile runs

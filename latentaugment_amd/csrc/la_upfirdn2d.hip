@@ -198,17 +198,21 @@ static int fir_fill(FirArgs& a, const float* in, float* out, int B, int C, int H
 template <int EPI, int ROWS>
 __global__ __launch_bounds__(256) void la_fir4x4_s1p_kernel(FirArgs a, float4 fx, float4 fy) {
     __shared__ unsigned smx[64];                   // xs_out: max |out| per sample of this workgroup (bit patterns: non-negative floats order like unsigned ints)
+    // Work items = (plane, row strip, 4-column group) of the WANTED part of the output only (round 5): with a row / column window
+    // (FirArgs::row_lo / col_lo) the grid holds the strips and column groups that contain a wanted row / column -- round 4 kept the
+    // whole plane's items and let those outside return, which left the launch as long as the whole-frame one (123 us for 56 % of the
+    // bytes at 256^2: the live lanes were spread thinly over the same number of waves).
     const int w4 = a.Wout >> 2;
     const int strips = (a.Hout + ROWS - 1) / ROWS;
-    const int per_plane = w4 * strips;
+    int s_lo = 0, s_hi = strips, g_lo = 0, g_hi = w4;
+    const int ybase = a.row_hi > 0 ? a.row_lo : 0;      // strips are counted from the window's first row: no nearly empty strip at its top
+    if (a.row_hi > 0) s_hi = ((a.row_hi < a.Hout ? a.row_hi : a.Hout) - ybase + ROWS - 1) / ROWS;
+    if (a.col_hi > 0) { g_lo = a.col_lo >> 2; g_hi = ((a.col_hi < a.Wout ? a.col_hi : a.Wout) + 3) >> 2; }
+    const int gw = g_hi - g_lo;
+    const int per_plane = gw * (s_hi - s_lo);
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int p = (int)(gid / per_plane);
-    bool live = p < a.P;
-    if (live && a.col_hi > 0) {      // column window (FirArgs::col_lo): a 4-column group without a wanted column does nothing
-        const int within = (int)(gid - (long)p * per_plane);
-        const int xq = (within - (within / w4) * w4) * 4;
-        live = xq + 4 > a.col_lo && xq < a.col_hi;
-    }
+    const bool live = p < a.P;
     if (!live && !a.xs_out) return;
     const int b = (live ? p : a.P - 1) / a.C;
     float omax = 0.f;
@@ -218,11 +222,11 @@ __global__ __launch_bounds__(256) void la_fir4x4_s1p_kernel(FirArgs a, float4 fx
     }
     if (live) {
         const int within = (int)(gid - (long)p * per_plane);
-        const int strip = within / w4, xg = within - strip * w4;
+        const int strip = s_lo + within / gw, xg = g_lo + (within - (within / gw) * gw);
         const int x0 = xg * 4, q2 = xg * 2;
         // row window (FirArgs::row_lo, 0 / 0 = all): the strip shrinks to the wanted rows, a strip without one does nothing
-        const int ys = strip * ROWS;
-        const int y0 = (a.row_hi > 0 && a.row_lo > ys) ? a.row_lo : ys;
+        const int ys = ybase + strip * ROWS;
+        const int y0 = ys;
         const long HWout = (long)a.Hout * a.Wout;
         const int ne = (a.Win + 1) >> 1, no = a.Win >> 1;
         const bool okm = q2 > 0, oke = q2 + 2 < ne, oko = q2 + 2 < no;
@@ -549,9 +553,17 @@ static int fir_launch_inner(const FirArgs& a, hipStream_t stream) {
                          (((size_t)a.in | (size_t)a.out | (size_t)a.noise | (size_t)a.addend | (size_t)a.yref) & 15) == 0 && fir_separable(a.f, fx, fy),
                      "upfirdn2d: column-planar input needs the 4x4 pad-1 separable FIR on aligned planes (W % 4 == 0, no plane maxima)");
         // rows per thread: 16 where that still leaves every SIMD >= 4 waves' worth of threads, else 4 (short serial chains on small planes)
-        int rows = (long)a.P * (a.Wout / 4) * la_cdiv(a.Hout, 16) >= 256l * 4 * 4 * 64 ? 16 : 4;
+        // (work items of the wanted rows / columns only: the kernel derives the same strip and column-group ranges from the window)
+        auto live_items = [&](int rows) {
+            int s_lo = 0, s_hi = la_cdiv(a.Hout, rows), g_lo = 0, g_hi = a.Wout / 4;
+            if (a.row_hi > 0) s_hi = la_cdiv((a.row_hi < a.Hout ? a.row_hi : a.Hout) - a.row_lo, rows);
+            if (a.col_hi > 0) { g_lo = a.col_lo >> 2; g_hi = ((a.col_hi < a.Wout ? a.col_hi : a.Wout) + 3) >> 2; }
+            return (long)a.P * (g_hi - g_lo) * (s_hi - s_lo);
+        };
+        int rows = live_items(16) >= 256l * 4 * 4 * 64 ? 16 : 4;
         if (const char* e = la_dev_env("LA_FIR_ROWS")) rows = atoi(e) == 16 ? 16 : 4;      // (dev knob)
-        const long items = (long)a.P * (a.Wout / 4) * la_cdiv(a.Hout, rows);
+        const long items = live_items(rows);
+        LA_CHECK_ARG(items > 0, "upfirdn2d: empty window");
         LA_CHECK_ARG(items < (1l << 38), "upfirdn2d: too many planes");
         dim3 g((unsigned)((items + 255) / 256));
         const float4 vx = make_float4(fx[0], fx[1], fx[2], fx[3]), vy = make_float4(fy[0], fy[1], fy[2], fy[3]);
