@@ -55,6 +55,16 @@ int la_bias_act_f32(const float* x, const float* b, float* y, long n, long stepb
 int la_bias_act_grad_f32(const float* dy, const float* yref, float* dx, float* db, long n, long stepb, int nb, int act,
                          float alpha, float gain, float clamp, la_stream_t stream);
 
+/* The general form of the same plugin entry point (bias_act.cpp:32 `bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)`):
+ * every activation of bias_act.py:20-30 (act = its cuda_idx 1..9: linear relu lrelu tanh sigmoid elu selu softplus swish) and grad = 0
+ * (forward), 1 (x = incoming gradient: x * f' * gain * dy) or 2 (x = gradient of the gradient: x * f'' * gain * dy); f', f'' are formed
+ * from yref / gain (swish: from xref + b), results are zero where |yref| >= clamp.  b / xref / yref / dy may be NULL ("absent", the
+ * reference's empty tensors); dim enters as (stepb, nb): element i belongs to bias entry (i / stepb) % nb. */
+int la_bias_act_ex_f32(const float* x, const float* b, const float* xref, const float* yref, const float* dy, float* out, long n,
+                       long stepb, int nb, int grad, int act, float alpha, float gain, float clamp, la_stream_t stream);
+/* db [nb] = sum of dx over every axis but the bias axis (what bias_act.py:187,206 forms with Tensor.sum): element i -> (i / stepb) % nb. */
+int la_bias_sum_f32(const float* dx, float* db, long n, long stepb, int nb, la_stream_t stream);
+
 /* upfirdn2d.  Replaces upfirdn2d_plugin.upfirdn2d(x,f,upx,upy,downx,downy,padx0,padx1,pady0,pady1,flip,gain)
  * (upfirdn2d.cpp:16-98, kernels upfirdn2d.cu:29-200).  f_host: fh*fw taps in HOST memory (<= 8x8), as produced by
  * setup_filter (upfirdn2d.py:70-114).  Output size per axis: la_upfirdn2d_out_size (upfirdn2d.cpp:35-36).

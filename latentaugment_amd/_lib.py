@@ -42,6 +42,8 @@ SIGNATURES = {
     'la_abi_version': (_I, []),
     'la_bias_act_f32': (_I, [_P, _P, _P, _L, _L, _I, _I, _F, _F, _F, _P]),
     'la_bias_act_grad_f32': (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _F, _F, _F, _P]),
+    'la_bias_act_ex_f32': (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _F, _F, _F, _P]),
+    'la_bias_sum_f32': (_I, [_P, _P, _L, _L, _I, _P]),
     'la_upfirdn2d_out_size': (_I, [_I] * 6),
     'la_upfirdn2d_f32': (_I, [_P, _P, _P] + [_I] * 15 + [_F, _P]),
     'la_pack_conv_weights_f32': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

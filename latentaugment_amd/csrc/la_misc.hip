@@ -95,6 +95,104 @@ extern "C" int la_bias_act_grad_f32(const float* dy, const float* yref, float* d
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The general bias_act op: the plugin entry point  bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)  of the reference
+// (bias_act.cpp:32; activation table bias_act.py:20-30: linear, relu, lrelu, tanh, sigmoid, elu, selu, softplus, swish = ids 1..9) with
+// all three values of `grad` -- the SG2 path above only ever needs linear / relu / lrelu with grad <= 1 and has its own fused forms.
+//   grad 0:  out = clamp(f(x + b) * gain)                         (dy, if given, multiplies before the clamp, as the plugin does)
+//   grad 1:  out = x * f'  * gain * dy,  zero where |yref| >= clamp      (x = the incoming gradient, f' from yref / gain or xref + b)
+//   grad 2:  out = x * f'' * gain * dy,  zero where |yref| >= clamp      (x = the gradient of the gradient)
+// Each activation is one small function object: value, first and second derivative, the derivatives written in what the reference
+// saves for it -- the OUTPUT (bias_act.py `ref='y'`) or, for swish, the INPUT (`ref='x'`).
+#define LA_SELU_SCALE 1.0507009873554804934193349852946f
+#define LA_SELU_ALPHA 1.6732632423543772848170429916717f
+struct LaActV { float f, d1, d2; };
+// value at v (grad 0), or derivatives from the saved reference r (grad >= 1: r = yref / gain, or xref + b for swish)
+__device__ __forceinline__ float la_actfull_value(int act, float v, float alpha) {
+    switch (act) {
+        case 2: return v > 0.f ? v : 0.f;
+        case 3: return v > 0.f ? v : v * alpha;
+        case 4: return tanhf(v);
+        case 5: return 1.f / (1.f + expf(-v));
+        case 6: return v >= 0.f ? v : expm1f(v);
+        case 7: return v >= 0.f ? LA_SELU_SCALE * v : (LA_SELU_SCALE * LA_SELU_ALPHA) * expm1f(v);
+        case 8: return v > 80.f ? v : log1pf(expf(v));
+        case 9: return v / (1.f + expf(-v));
+        default: return v;
+    }
+}
+__device__ __forceinline__ void la_actfull_derivs(int act, float r, float alpha, float& d1, float& d2) {
+    d2 = 0.f;
+    switch (act) {
+        case 2: d1 = r > 0.f ? 1.f : 0.f; break;
+        case 3: d1 = r > 0.f ? 1.f : alpha; break;
+        case 4: d1 = 1.f - r * r; d2 = d1 * (-2.f * r); break;
+        case 5: d1 = r * (1.f - r); d2 = d1 * (1.f - 2.f * r); break;
+        case 6: d1 = r >= 0.f ? 1.f : r + 1.f; d2 = r >= 0.f ? 0.f : r + 1.f; break;
+        case 7: d1 = r >= 0.f ? LA_SELU_SCALE : r + LA_SELU_SCALE * LA_SELU_ALPHA; d2 = r >= 0.f ? 0.f : r + LA_SELU_SCALE * LA_SELU_ALPHA; break;
+        case 8: { const float e = expf(-r); d1 = 1.f - e; d2 = e * (1.f - e); break; }
+        case 9: {      // r = the pre-activation: sigma = 1 / (1 + e^-r);  f' = sigma (1 + r (1 - sigma));  f'' = sigma (1 - sigma) (2 + r (1 - 2 sigma))
+            const float sg = 1.f / (1.f + expf(-r));
+            d1 = sg * (1.f + r * (1.f - sg));
+            d2 = sg * (1.f - sg) * (2.f + r * (1.f - 2.f * sg));
+            break;
+        }
+        default: d1 = 1.f; break;
+    }
+}
+__global__ __launch_bounds__(256) void la_bias_act_full_kernel(const float* __restrict__ x, const float* __restrict__ b, const float* __restrict__ xref,
+                                                              const float* __restrict__ yref, const float* __restrict__ dy, float* __restrict__ out, long n,
+                                                              long stepb, int nb, int grad, int act, float alpha, float gain, float clamp) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float bv = b ? b[(i / stepb) % nb] : 0.f;
+        const float g = dy ? dy[i] : 1.f;
+        float v;
+        if (grad == 0) {
+            v = la_actfull_value(act, x[i] + bv, alpha) * gain * g;
+            if (clamp >= 0.f) v = fminf(fmaxf(v, -clamp), clamp);
+        } else {
+            float yr = yref ? yref[i] : 0.f;
+            float r = gain != 0.f ? yr / gain : 0.f;
+            if (act == 9) {      // swish keeps its input: the reference value and the clamp test are re-derived from it
+                r = (xref ? xref[i] : 0.f) + bv;
+                yr = la_actfull_value(9, r, alpha) * gain;
+            }
+            float d1, d2;
+            la_actfull_derivs(act, r, alpha, d1, d2);
+            v = x[i] * (grad == 1 ? d1 : d2) * gain * g;
+            if (clamp >= 0.f && !(yr > -clamp && yr < clamp)) v = 0.f;
+        }
+        out[i] = v;
+    }
+}
+
+extern "C" int la_bias_act_ex_f32(const float* x, const float* b, const float* xref, const float* yref, const float* dy, float* out, long n,
+                                  long stepb, int nb, int grad, int act, float alpha, float gain, float clamp, hipStream_t stream) {
+    if (n == 0) return LA_OK;
+    LA_CHECK_ARG(x && out && n > 0, "bias_act_ex: null pointer");
+    LA_CHECK_ARG(act >= 1 && act <= 9, "bias_act_ex: activation id must be 1..9 (bias_act.py:20-30)");
+    LA_CHECK_ARG(grad >= 0 && grad <= 2, "bias_act_ex: grad must be 0, 1 or 2");
+    LA_CHECK_ARG(grad == 0 || act == 9 || act == 1 || yref, "bias_act_ex: grad >= 1 needs the saved output yref");
+    LA_CHECK_ARG(grad == 0 || act != 9 || xref, "bias_act_ex: swish derives its gradients from the saved input xref");
+    LA_CHECK_ARG(!b || (stepb >= 1 && nb >= 1 && n % (stepb * nb) == 0), "bias_act_ex: bias does not tile the tensor");
+    if (!b) { stepb = 1; nb = 1; }
+    long blocks = la_cdiv(n, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(la_bias_act_full_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, b, xref, yref, dy, out, n, stepb, nb, grad, act,
+                       alpha, gain, clamp);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
+// db[c] = sum of dx over every axis but the bias axis (bias_act.py:187, :206): element i belongs to channel (i / stepb) % nb
+extern "C" int la_bias_sum_f32(const float* dx, float* db, long n, long stepb, int nb, hipStream_t stream) {
+    LA_CHECK_ARG(dx && db && n > 0 && stepb >= 1 && nb >= 1 && n % (stepb * nb) == 0, "bias_sum: bad arguments");
+    hipLaunchKernelGGL(la_bias_grad_kernel, dim3(nb), dim3(256), 0, stream, dx, db, n, stepb, nb);
+    LA_CHECK_LAUNCH();
+    return LA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam semantics as used at util_latent_aug.py:213,276): one fused elementwise update.
 __global__ void la_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float bc1,

@@ -3,8 +3,8 @@
 Same names, argument meaning and error behaviour as the reference's Python wrappers:
   bias_act(x, b, dim, act, alpha, gain, clamp)                      bias_act.py:52-86
   setup_filter / upfirdn2d / filter2d / upsample2d / downsample2d   upfirdn2d.py:70-387
-Each op is a torch.autograd.Function whose forward AND backward are HIP launches (first-order gradients, which is all
-the latent-optimisation path uses).  torch only owns the device memory and the stream.
+Each op is a torch.autograd.Function whose forward AND backward are HIP launches (bias_act: every activation of the reference's
+table with first- and second-order gradients; upfirdn2d: first order, which is all the latent-optimisation path uses).  torch only owns the device memory and the stream.
 """
 import math
 
@@ -13,57 +13,115 @@ import torch
 
 from . import _lib
 
-_ACT_IDS = {'linear': (1, 0.0, 1.0), 'relu': (2, 0.0, math.sqrt(2.0)), 'lrelu': (3, 0.2, math.sqrt(2.0))}
+# activation table of the reference (bias_act.py:20-30): name -> (plugin id, default alpha, default gain, what the backward is formed from,
+# whether a second derivative exists)
+_ACTS = {
+    'linear': (1, 0.0, 1.0, '', False), 'relu': (2, 0.0, math.sqrt(2.0), 'y', False), 'lrelu': (3, 0.2, math.sqrt(2.0), 'y', False),
+    'tanh': (4, 0.0, 1.0, 'y', True), 'sigmoid': (5, 0.0, 1.0, 'y', True), 'elu': (6, 0.0, 1.0, 'y', True), 'selu': (7, 0.0, 1.0, 'y', True),
+    'softplus': (8, 0.0, 1.0, 'y', True), 'swish': (9, 0.0, math.sqrt(2.0), 'x', True),
+}
 
 
-def _act(act, alpha, gain, clamp):
-    if act not in _ACT_IDS:
-        raise NotImplementedError(f'activation {act!r} is not on the SG2 latent-augmentation path (linear/relu/lrelu only)')
-    idx, def_alpha, def_gain = _ACT_IDS[act]
-    alpha = float(def_alpha if alpha is None else alpha)
-    gain = float(def_gain if gain is None else gain)
-    clamp = float(-1 if clamp is None else clamp)
-    return idx, alpha, gain, clamp
+def _bias_act_launch(x, b, xref, yref, dy, grad, stepb, nb, act, alpha, gain, clamp):
+    """One launch of the general op (include/latentaug_hip.h: la_bias_act_ex_f32 = the plugin's bias_act(x, b, xref, yref, dy, grad, ...))."""
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    _lib.check(lib.la_bias_act_ex_f32(_lib.ptr(x), _lib.ptr(b), _lib.ptr(xref), _lib.ptr(yref), _lib.ptr(dy), _lib.ptr(out), x.numel(), stepb, nb,
+                                      grad, act, alpha, gain, clamp, _lib.stream_ptr()), 'bias_act')
+    return out
+
+
+class _BiasSum(torch.autograd.Function):
+    """db = dx summed over every axis but the bias axis (bias_act.py:187,206), as a launch; its own gradient is a broadcast view."""
+
+    @staticmethod
+    def forward(ctx, dx, stepb, nb):
+        lib = _lib.load()
+        dx = dx.contiguous()
+        db = torch.empty([nb], device=dx.device, dtype=torch.float32)
+        if dx.numel():
+            _lib.check(lib.la_bias_sum_f32(_lib.ptr(dx), _lib.ptr(db), dx.numel(), stepb, nb, _lib.stream_ptr()), 'bias_sum')
+        else:
+            db.zero_()
+        ctx.meta = (tuple(dx.shape), stepb, nb)
+        return db
+
+    @staticmethod
+    def backward(ctx, d_db):
+        shape, stepb, nb = ctx.meta
+        lead = int(np.prod(shape)) // (stepb * nb) if stepb * nb else 0
+        return d_db.reshape(1, nb, 1).expand(lead, nb, stepb).reshape(shape), None, None
 
 
 class _BiasAct(torch.autograd.Function):
+    """Forward of the op; first- and second-order gradients as HIP launches too (the reference: bias_act.py:130-210)."""
+
     @staticmethod
-    def forward(ctx, x, b, dim, act, alpha, gain, clamp):
+    def forward(ctx, x, b, dim, act, alpha, gain, clamp, ref, has2):
         _lib.require_gpu(x)
-        lib = _lib.load()
         x = x.contiguous().float()
-        y = torch.empty_like(x)
         stepb, nb = 1, 1
         if b is not None:
             assert b.ndim == 1 and 0 <= dim < x.ndim and b.shape[0] == x.shape[dim]
             b = b.contiguous().float()
             nb = x.shape[dim]
             stepb = int(np.prod(x.shape[dim + 1:])) if dim + 1 < x.ndim else 1
-        _lib.check(lib.la_bias_act_f32(_lib.ptr(x), _lib.ptr(b), _lib.ptr(y), x.numel(), stepb, nb, act, alpha, gain,
-                                       clamp, _lib.stream_ptr()), 'bias_act')
-        ctx.save_for_backward(y)
-        ctx.meta = (stepb, nb, act, alpha, gain, clamp, b is not None)
+        y = _bias_act_launch(x, b, None, None, None, 0, stepb, nb, act, alpha, gain, clamp)
+        # (y is also kept for 'linear' when a clamp is set: the reference's CPU path -- `impl='ref'`, the parity target -- masks the gradient
+        #  where the clamp is active for every activation; its CUDA plugin, which saves no y for 'linear', does not)
+        ctx.save_for_backward(x if (ref == 'x' or has2) else None, b if (ref == 'x' or has2) else None,
+                              y if (ref == 'y' or has2 or clamp >= 0) else None)
+        ctx.meta = (stepb, nb, act, alpha, gain, clamp, b is not None, has2)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (y,) = ctx.saved_tensors
-        stepb, nb, act, alpha, gain, clamp, has_b = ctx.meta
-        lib = _lib.load()
-        dy = dy.contiguous()
-        dx = torch.empty_like(dy)
-        db = torch.empty([nb], device=dy.device, dtype=torch.float32) if has_b else None
-        _lib.check(lib.la_bias_act_grad_f32(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dx), _lib.ptr(db), dy.numel(), stepb, nb,
-                                            act, alpha, gain, clamp, _lib.stream_ptr()), 'bias_act_grad')
-        return dx, db, None, None, None, None, None
+        x, b, y = ctx.saved_tensors
+        stepb, nb, act, alpha, gain, clamp, has_b, has2 = ctx.meta
+        dx = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dx = _BiasActGrad.apply(dy.contiguous(), x, b, y, ctx.meta)
+        if ctx.needs_input_grad[1] and has_b:
+            db = _BiasSum.apply(dx, stepb, nb)
+        return dx, db, None, None, None, None, None, None, None
+
+
+class _BiasActGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, x, b, y, meta):
+        stepb, nb, act, alpha, gain, clamp, has_b, has2 = meta
+        dx = _bias_act_launch(dy, b, x, y, None, 1, stepb, nb, act, alpha, gain, clamp)
+        ctx.save_for_backward(dy if has2 else None, x, b, y)
+        ctx.meta = meta
+        return dx
+
+    @staticmethod
+    def backward(ctx, d_dx):
+        dy, x, b, y = ctx.saved_tensors
+        stepb, nb, act, alpha, gain, clamp, has_b, has2 = ctx.meta
+        d_dx = d_dx.contiguous()
+        d_dy = d_x = d_b = None
+        if ctx.needs_input_grad[0]:
+            d_dy = _BiasActGrad.apply(d_dx, x, b, y, ctx.meta)
+        if has2 and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            d_x = _bias_act_launch(d_dx, b, x, y, dy, 2, stepb, nb, act, alpha, gain, clamp)
+            if has_b and ctx.needs_input_grad[2]:
+                d_b = _BiasSum.apply(d_x, stepb, nb)
+        return d_dy, d_x, d_b, None, None
 
 
 def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, impl='hip'):
-    """Fused bias + activation + gain + clamp (reference: bias_act.py:52-86)."""
+    """Fused bias + activation + gain + clamp (reference: bias_act.py:52-86); every activation of the reference's table, first- and
+    second-order gradients."""
     assert isinstance(x, torch.Tensor)
     assert clamp is None or clamp >= 0
-    idx, alpha, gain, clamp = _act(act, alpha, gain, clamp)
-    return _BiasAct.apply(x, b, dim, idx, alpha, gain, clamp)
+    if act not in _ACTS:
+        raise KeyError(act)      # (the reference indexes its activation table the same way)
+    idx, def_alpha, def_gain, ref, has2 = _ACTS[act]
+    alpha = float(def_alpha if alpha is None else alpha)
+    gain = float(def_gain if gain is None else gain)
+    clamp = float(-1 if clamp is None else clamp)
+    return _BiasAct.apply(x, b, dim, idx, alpha, gain, clamp, ref, has2)
 
 
 def setup_filter(f, device=torch.device('cpu'), normalize=True, flip_filter=False, gain=1, separable=None):

@@ -70,8 +70,43 @@ def test_bias_act_ragged_and_empty(dev):
     close(ops.bias_act(x, b, act='lrelu', clamp=0.5), ref_ops.bias_act(x.cpu(), b.cpu(), act='lrelu', clamp=0.5))
     e = torch.empty([0, 5, 4, 4], device=dev)
     assert ops.bias_act(e, b).shape == (0, 5, 4, 4)
-    with pytest.raises(NotImplementedError):
-        ops.bias_act(x, b, act='tanh')
+    with pytest.raises(KeyError):
+        ops.bias_act(x, b, act='gelu')      # (not in the reference's activation table: it indexes a dict the same way)
+
+
+def test_bias_act_all_activations_first_and_second_order(dev):
+    """Every activation of the reference's table (bias_act.py:20-30) with default and explicit gain / clamp / alpha: forward, the gradient
+    of the op (plugin grad = 1) and the gradient of that gradient (grad = 2) against vectors made by RUNNING the reference's
+    `bias_act(..., impl='ref')` + autograd in float64 on float32 inputs (tests/golden/make_golden_bias_act.py).  Tolerance: float32
+    evaluation of exp / tanh / log1p (1e-5 relative to the tensor's scale); swish forms its derivatives from the saved input."""
+    import ast
+    from latentaugment_amd import ops
+    gb = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bias_act_full.npz'))
+    seen = set()
+    for rep in gb['cases']:
+        name, act, gain, clamp, alpha, def_alpha, def_gain, idx, ref, has2 = ast.literal_eval(str(rep))
+        seen.add(act)
+        assert ops._ACTS[act][0] == idx and ops._ACTS[act][3] == ref and ops._ACTS[act][4] == has2      # the table mirrors the reference's
+        assert abs(ops._ACTS[act][1] - def_alpha) < 1e-12 and abs(ops._ACTS[act][2] - def_gain) < 1e-12
+        kw = dict(act=act, gain=None if gain < 0 else gain, clamp=None if clamp < 0 else clamp, alpha=None if alpha < 0 else alpha)
+        x = torch.tensor(gb[f'{name}_x'], device=dev, requires_grad=True)
+        b = torch.tensor(gb[f'{name}_b'], device=dev, requires_grad=True)
+        dy = torch.tensor(gb[f'{name}_dy'], device=dev)
+        ddx = torch.tensor(gb[f'{name}_ddx'], device=dev)
+        y = ops.bias_act(x, b, dim=1, **kw)
+        (dx,) = torch.autograd.grad(y, [x], dy, create_graph=True)
+        sc = max(1.0, float(np.abs(gb[f'{name}_y']).max()))
+        close(y, gb[f'{name}_y'], rtol=1e-5, atol=1e-5 * sc)
+        close(dx, gb[f'{name}_dx'], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(gb[f'{name}_dx']).max())))
+        if has2:
+            (d2,) = torch.autograd.grad(dx, [x], ddx)
+            close(d2, gb[f'{name}_d2'], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(gb[f'{name}_d2']).max())))
+        else:
+            assert float(np.abs(gb[f'{name}_d2']).max()) == 0.0
+        # db of the first-order gradient = dx summed over the other axes
+        (gb1,) = torch.autograd.grad(ops.bias_act(x, b, dim=1, **kw), [b], dy)
+        close(gb1, gb[f'{name}_dx'].sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-4)
+    assert seen == set(ops._ACTS)
 
 
 def test_upfirdn2d_golden(dev, g):
