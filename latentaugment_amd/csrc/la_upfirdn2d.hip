@@ -163,7 +163,8 @@ static int fir_fill(FirArgs& a, const float* in, float* out, int B, int C, int H
                     int fh, int fw, int upx, int upy, int dnx, int dny, int padx0, int padx1, int pady0, int pady1,
                     int flip_filter, float gain, int* Hout, int* Wout) {
     LA_CHECK_ARG(in && out && f_host, "upfirdn2d: null pointer");
-    LA_CHECK_ARG(fh >= 1 && fw >= 1 && fh <= FIR_MAX && fw <= FIR_MAX, "upfirdn2d: filter larger than 8x8");
+    // (up to 8 x 8 taps, or one separable pass of up to 32: 1 x fw / fh x 1 -- the two-pass form of upfirdn2d.py:188-201 for 1-D filters)
+    LA_CHECK_ARG(fh >= 1 && fw >= 1 && fh * fw <= FIR_MAX * FIR_MAX && fh <= 32 && fw <= 32, "upfirdn2d: filter larger than 8x8 (or than 32 taps in one separable pass)");
     LA_CHECK_ARG(upx >= 1 && upy >= 1 && dnx >= 1 && dny >= 1, "upfirdn2d: bad up/down factor");
     LA_CHECK_ARG(B >= 1 && C >= 1 && Hin >= 1 && Win >= 1, "upfirdn2d: empty input");
     const int upW = Win * upx + padx0 + padx1, upH = Hin * upy + pady0 + pady1;

@@ -138,7 +138,9 @@ def setup_filter(f, device=torch.device('cpu'), normalize=True, flip_filter=Fals
     if f.ndim == 1 and not separable:
         f = torch.outer(f, f)
     if separable:
-        raise NotImplementedError('separable (>= 8 tap) filters are not used by SG2 and not implemented')
+        assert f.ndim == 1      # (kept 1-D: upfirdn2d then runs one pass per axis, upfirdn2d.py:188-201)
+        if f.numel() > 32:
+            raise NotImplementedError('separable filters of more than 32 taps')
     if normalize:
         f = f / f.sum()
     if flip_filter:
@@ -198,20 +200,31 @@ class _Upfirdn2d(torch.autograd.Function):
 
 
 def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='hip'):
-    """Pad, upsample, filter, downsample (reference: upfirdn2d.py:118-162)."""
+    """Pad, upsample, filter, downsample (reference: upfirdn2d.py:118-162).  A 1-D (separable) filter runs as one pass per axis,
+    each with the square root of the gain, exactly as the reference's plugin path applies it (upfirdn2d.py:188-201)."""
     assert isinstance(x, torch.Tensor) and x.ndim == 4
     if f is None:
         f = torch.ones([1, 1], dtype=torch.float32)
-    assert isinstance(f, torch.Tensor) and f.ndim == 2 and f.dtype == torch.float32
-    g = float(gain) ** (f.ndim / 2)
-    return _Upfirdn2d.apply(x, f.cpu(), _parse_scaling(up), _parse_scaling(down), tuple(_parse_padding(padding)),
-                            bool(flip_filter), g)
+    assert isinstance(f, torch.Tensor) and f.ndim in (1, 2) and f.dtype == torch.float32
+    (upx, upy), (dnx, dny) = _parse_scaling(up), _parse_scaling(down)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    if f.ndim == 1:
+        g = float(gain) ** 0.5
+        fc = f.cpu()
+        y = _Upfirdn2d.apply(x, fc[None, :], (upx, 1), (dnx, 1), (px0, px1, 0, 0), bool(flip_filter), g)
+        return _Upfirdn2d.apply(y, fc[:, None], (1, upy), (1, dny), (0, 0, py0, py1), bool(flip_filter), g)
+    return _Upfirdn2d.apply(x, f.cpu(), (upx, upy), (dnx, dny), (px0, px1, py0, py1), bool(flip_filter), float(gain))
+
+
+def _fshape(f):
+    """(fh, fw) of a 2-D or separable 1-D filter (upfirdn2d.py:55-66 _get_filter_size)."""
+    return (f.shape[0], f.shape[0]) if f.ndim == 1 else tuple(f.shape)
 
 
 def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl='hip'):
     """reference: upfirdn2d.py:277-309"""
     px0, px1, py0, py1 = _parse_padding(padding)
-    fh, fw = f.shape
+    fh, fw = _fshape(f)
     p = [px0 + fw // 2, px1 + (fw - 1) // 2, py0 + fh // 2, py1 + (fh - 1) // 2]
     return upfirdn2d(x, f, padding=p, flip_filter=flip_filter, gain=gain)
 
@@ -220,7 +233,7 @@ def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1, impl='hip'):
     """reference: upfirdn2d.py:313-348"""
     upx, upy = _parse_scaling(up)
     px0, px1, py0, py1 = _parse_padding(padding)
-    fh, fw = f.shape
+    fh, fw = _fshape(f)
     p = [px0 + (fw + upx - 1) // 2, px1 + (fw - upx) // 2, py0 + (fh + upy - 1) // 2, py1 + (fh - upy) // 2]
     return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * upx * upy)
 
@@ -229,7 +242,7 @@ def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1, impl='hip')
     """reference: upfirdn2d.py:352-387"""
     dnx, dny = _parse_scaling(down)
     px0, px1, py0, py1 = _parse_padding(padding)
-    fh, fw = f.shape
+    fh, fw = _fshape(f)
     p = [px0 + (fw - dnx + 1) // 2, px1 + (fw - dnx) // 2, py0 + (fh - dny + 1) // 2, py1 + (fh - dny) // 2]
     return upfirdn2d(x, f, down=down, padding=p, flip_filter=flip_filter, gain=gain)
 

@@ -109,6 +109,36 @@ def test_bias_act_all_activations_first_and_second_order(dev):
     assert seen == set(ops._ACTS)
 
 
+def test_upfirdn2d_separable_filters_vs_reference(dev):
+    """1-D (separable) filters -- what setup_filter keeps for >= 8 taps (upfirdn2d.py:101-104) -- through upfirdn2d / upsample2d /
+    downsample2d / filter2d: forward and input gradient against vectors made by RUNNING the reference's impl='ref' in float64
+    (tests/golden/make_golden_upfirdn_sep.py).  The op runs one pass per axis, as the reference's plugin path does (:188-201)."""
+    from latentaugment_amd import ops
+    gs = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'upfirdn_sep.npz'))
+    for rep in gs['cases']:
+        name, tname, op, kwrep = ast.literal_eval(str(rep))
+        kw = ast.literal_eval(kwrep)
+        f = ops.setup_filter(list(gs[f'{name}_taps']))
+        assert f.ndim == 1 and f.numel() >= 8
+        x = torch.tensor(gs[f'{name}_x'], device=dev, requires_grad=True)
+        y = getattr(ops, op)(x, f, **kw)
+        (dx,) = torch.autograd.grad(y, [x], torch.tensor(gs[f'{name}_dy'], device=dev))
+        close(y, gs[f'{name}_y'], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(gs[f'{name}_y']).max())))
+        close(dx, gs[f'{name}_dx'], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(gs[f'{name}_dx']).max())))
+
+
+def test_upfirdn2d_and_bias_act_take_non_contiguous_inputs(dev):
+    """channels_last and sliced views give the same results as their contiguous copies (the reference's plugin reads any strides,
+    upfirdn2d.cpp:25-30; this binding copies once)."""
+    from latentaugment_amd import ops
+    f = ops.setup_filter([1, 3, 3, 1])
+    x = torch.randn([2, 6, 12, 10], device=dev)
+    for v in (x.to(memory_format=torch.channels_last), x.transpose(2, 3), x[:, ::2]):
+        close(ops.upsample2d(v, f), ops.upsample2d(v.contiguous(), f), rtol=0, atol=0)
+        b = torch.randn([v.shape[1]], device=dev)
+        close(ops.bias_act(v, b, act='swish'), ops.bias_act(v.contiguous(), b, act='swish'), rtol=0, atol=0)
+
+
 def test_upfirdn2d_golden(dev, g):
     from latentaugment_amd import ops
     f = ops.setup_filter([1, 3, 3, 1])
