@@ -85,6 +85,9 @@ def parse():
     p.add_argument('--lanes-serial', action='store_true',
                    help='profiling aid: the two stream lanes one after the other on one stream (same launches, each alone on the chip)')
     p.add_argument('--no-overlap', action='store_true', help='discriminator and perceptual criterion one after the other instead of side by side')
+    p.add_argument('--overlap-mode', type=int, default=2, choices=[0, 1, 2],
+                   help='2 (default): discriminator and perceptual branch as parallel branches of the captured step; 1: the perceptual branch replayed as '
+                        'its own graph on a side stream (measured equal); 0 = --no-overlap')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true', help='skip the HIP-event leg (used under rocprofv3)')
     p.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
@@ -114,7 +117,7 @@ def make_opt(args, local_rank, global_batch):
         truncation_psi=1.0, w_pix=args.w_pix, w_lpips=args.w_lpips, w_latent=args.w_latent, w_disc=args.w_disc, crop_size_aug=64,
         preprocess_aug='center_random_crop', soft_aug=False, alpha=1.0, verbose_log=False, rand_aug=False,
         lower_bound_clip=False, p_thres=0.0, init_w='inv', final_noise_mode='random',
-        precision=args.precision, hip_graph=not args.no_graph, overlap_criteria=not args.no_overlap,
+        precision=args.precision, hip_graph=not args.no_graph, overlap_criteria=0 if args.no_overlap else args.overlap_mode,
         stream_lanes=args.lanes if args.lanes == 'auto' else int(args.lanes), loop_window=not args.whole_frames, loop_window_columns=not args.no_window_columns)
 
 

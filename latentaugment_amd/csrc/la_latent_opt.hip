@@ -41,6 +41,11 @@ struct la_latent_opt {
     int graph_refused;      // 1: stream capture / instantiation of the step failed once; the handle launches eagerly since
     hipGraph_t graph;
     hipGraphExec_t graph_exec;
+    // split replay (overlap mode 1, round 5): the step as FOUR graphs -- A: synthesis forward + pixel gradient, P: perceptual branch, D:
+    // discriminator branch, Z: crop gradient + synthesis backward + step tail -- with P replayed on the side stream beside D (events)
+    hipGraph_t seg_graph[4];
+    hipGraphExec_t seg_exec[4];
+    int seg_valid;
     hipStream_t cap_stream; // capture needs a non-default stream; the replay goes to the caller's stream
     float* trace_w;         // optional [steps][B][w_dim]: the latent after every step (verbose_log snapshots); forces eager launches
     float* trace_img;       // optional [steps][B][C][R][R]: the image synthesised in every step
@@ -111,7 +116,7 @@ extern "C" int la_latent_opt_create(la_synth* g, int img_resolution, int img_cha
     if (!h->adam_tab_host) { free(h); la_set_error("latent_opt_create: out of host memory"); return LA_ERR_ARG; }
     la_adam_fill_table(h->adam_tab_host, cfg->steps, cfg->beta1, cfg->beta2);
     h->graph_mode = 1;
-    h->overlap = 1;
+    h->overlap = 2;
     h->win_lo = h->win_hi = 0; h->wcol_lo = h->wcol_hi = 0;
     *out = h;
     return LA_OK;
@@ -120,6 +125,11 @@ extern "C" int la_latent_opt_create(la_synth* g, int img_resolution, int img_cha
 static void drop_graph(la_latent_opt* h) {
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    for (int k = 0; k < 4; ++k) {
+        if (h->seg_exec[k]) { (void)hipGraphExecDestroy(h->seg_exec[k]); h->seg_exec[k] = nullptr; }
+        if (h->seg_graph[k]) { (void)hipGraphDestroy(h->seg_graph[k]); h->seg_graph[k] = nullptr; }
+    }
+    h->seg_valid = 0;
     h->graph_B = 0; h->graph_win = 0;
 }
 
@@ -139,7 +149,11 @@ extern "C" void la_latent_opt_destroy(la_latent_opt* h) {
 // Results are bit-identical either way (same launches, same accumulation order into the image gradient).
 extern "C" int la_latent_opt_set_overlap(la_latent_opt* h, int enable) {
     LA_CHECK_ARG(h, "latent_opt_set_overlap: null handle");
-    h->overlap = enable ? 1 : 0;
+    // 0: criteria one after the other; 2 (the handle's default): fork / join captured as parallel branches of ONE step graph; 1: split
+    // replay -- the perceptual branch as a graph of its own on the side stream beside the discriminator branch (round 5: measured equal)
+    const int mode = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+    if (h->overlap != mode) drop_graph(h);
+    h->overlap = mode;
     drop_graph(h);
     return LA_OK;
 }
@@ -225,7 +239,7 @@ extern "C" int la_latent_opt_invalidate_banks(la_latent_opt* h) {
 // capture of the step was refused by the runtime (la_latent_opt_set_graph(h, 1) re-arms it)
 extern "C" int la_latent_opt_graph_state(const la_latent_opt* h) {
     if (!h) return 0;
-    return h->graph_exec ? 1 : (h->graph_refused ? -1 : 0);
+    return (h->graph_exec || h->seg_valid) ? 1 : (h->graph_refused ? -1 : 0);
 }
 
 extern "C" int la_latent_opt_set_graph(la_latent_opt* h, int enable) {
@@ -385,81 +399,96 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     // one optimisation step; L = this step's row of loss scalars or null.  Everything it launches is independent of the step
     // number (the Adam bias corrections and the LPIPS window position are read from device memory), so the same launch
     // sequence can be captured once and replayed.
-    auto run_step = [&](float* L, hipStream_t st, int step_index = -1) -> int {
+    // seg: which parts of the step to launch (1 = A: synthesis forward, loss scalars, pixel gradient; 2 = P: perceptual branch; 4 = D:
+    // discriminator branch; 8 = Z: crop gradient, synthesis backward, step tail).  15 = the whole step; the split replay captures the four
+    // parts as graphs of their own.  sl_over: the stream of part P when it is launched alone.
+    auto run_step = [&](float* L, hipStream_t st, int step_index = -1, int seg = 15) -> int {
         int rc;
+        const bool segA = seg & 1, segP = seg & 2, segD = seg & 4, segZ = seg & 8;
         hipEvent_t* tev = (h->time_trace && h->tev && L && step_index >= 0 && step_index < h->tev_steps) ? h->tev + (size_t)step_index * LA_TEV : nullptr;
         auto mark = [&](int k) { if (tev) (void)hipEventRecord(tev[k], st); };
-        mark(0);
-        if ((rc = la_synth_forward(h->g, h->w_opt, wd, 0, B, c.loop_noise_mode, nullptr, nullptr, st))) return rc;
-        const float* img = la_synth_image(h->g);
-        mark(1);
-        if (L) {
-            if (h->Mw && (rc = la_l2_mean_from_bank(h->bankW, h->Mw, (long)h->num_ws * wd, h->w_opt, B, wd, wd, h->yx, h->yy,
-                                                    h->xx, lat_coef, L + 0, 0, st)))
-                return rc;
-        }
-        // brackets of the per-criterion timers (la_latent_opt_get_times): [1,2) latent loss scalar, [2,3) pixel loss scalar + gradient,
-        // [3,4) discriminator, [4,5) perceptual; the latent criterion's GRADIENT is one fused launch with the total (la_latent_combine,
-        // after the synthesis backward) and sits in the epoch bracket only
-        mark(2);
-        if (L) {
-            if (h->Mx) {
-                if ((rc = la_center_crop_f32(img, h->xc, (long)B * h->imgc, h->R, cc, off, st))) return rc;
-                for (int ch = 0; ch < h->imgc; ++ch)
-                    if ((rc = la_l2_mean_from_bank(h->bankX + (long)ch * h->Mx * cc2, h->Mx, cc2, h->xc + (long)ch * cc2, B,
-                                                   (long)h->imgc * cc2, 0, h->yx, h->yy, h->xx, pix_coef, L + 1, ch > 0, st)))
-                        return rc;
+        const float* img = la_synth_image(h->g);      // (the loop's image buffer: fixed per handle, also before the first pass)
+        if (segA) {
+            mark(0);
+            if ((rc = la_synth_forward(h->g, h->w_opt, wd, 0, B, c.loop_noise_mode, nullptr, nullptr, st))) return rc;
+            img = la_synth_image(h->g);
+            mark(1);
+            if (L) {
+                if (h->Mw && (rc = la_l2_mean_from_bank(h->bankW, h->Mw, (long)h->num_ws * wd, h->w_opt, B, wd, wd, h->yx, h->yy,
+                                                        h->xx, lat_coef, L + 0, 0, st)))
+                    return rc;
+            }
+            // brackets of the per-criterion timers (la_latent_opt_get_times): [1,2) latent loss scalar, [2,3) pixel loss scalar + gradient,
+            // [3,4) discriminator, [4,5) perceptual; the latent criterion's GRADIENT is one fused launch with the total (la_step_tail,
+            // after the synthesis backward) and sits in the epoch bracket only
+            mark(2);
+            if (L) {
+                if (h->Mx) {
+                    if ((rc = la_center_crop_f32(img, h->xc, (long)B * h->imgc, h->R, cc, off, st))) return rc;
+                    for (int ch = 0; ch < h->imgc; ++ch)
+                        if ((rc = la_l2_mean_from_bank(h->bankX + (long)ch * h->Mx * cc2, h->Mx, cc2, h->xc + (long)ch * cc2, B,
+                                                       (long)h->imgc * cc2, 0, h->yx, h->yy, h->xx, pix_coef, L + 1, ch > 0, st)))
+                            return rc;
+                }
             }
         }
         const float* dws = nullptr;
         if (img_crit) {
-            if (c.w_pix != 0.f &&
-                (rc = la_pix_grad(img, h->colsumX, h->g_img, B, h->imgc, h->R, cc, off, -2.f * pix_coef, (float)h->Mx, st)))
-                return rc;
-            mark(3);
-            // fork: the perceptual branch needs the image only -- it runs on the side stream beside the discriminator branch (the
-            // launch profiler, the loss scalars and the traces keep everything on one stream)
-            const bool fork = h->overlap && use_disc && use_lpips && !L && !tev && !la_prof_enabled() && h->side_stream && h->ev_fork && h->ev_join;
+            if (segA) {
+                if (c.w_pix != 0.f &&
+                    (rc = la_pix_grad(img, h->colsumX, h->g_img, B, h->imgc, h->R, cc, off, -2.f * pix_coef, (float)h->Mx, st)))
+                    return rc;
+                mark(3);
+            }
+            // fork (whole-step launches, overlap mode 2): the perceptual branch needs the image only -- it runs on the side stream beside the
+            // discriminator branch (the launch profiler, the loss scalars and the traces keep everything on one stream).  Overlap mode 1
+            // (split replay) launches the parts one by one instead: the caller places part P on the side stream.
+            const bool fork = seg == 15 && h->overlap == 2 && use_disc && use_lpips && !L && !tev && !la_prof_enabled() && h->side_stream && h->ev_fork && h->ev_join;
             hipStream_t sl = fork ? h->side_stream : st;      // stream of the perceptual branch
             if (fork) {
                 LA_HIP(hipEventRecord(h->ev_fork, st));
                 LA_HIP(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
             }
-            if (use_disc) {
+            if (use_disc && segD) {
                 // loss_disc = softplus(-D(x)).mean() * w_disc enters the total with a plus sign (:270)
                 if ((rc = la_disc_forward(h->d, img, B, st))) return rc;
                 if ((rc = la_disc_loss(h->d, c.w_disc, c.norm_batch, L ? L + 2 : nullptr, st))) return rc;
                 if ((rc = la_disc_backward(h->d, nullptr, h->g_img, c.w_pix != 0.f, st))) return rc;
             }
-            mark(4);
+            if (segD) mark(4);
             if (use_lpips) {
                 // loss_lpips = mean_modes( sum_{m,n} |f_n - F_m|^2 / (n*m) ) * w_lpips, entering the total with a minus sign (:270)
                 const int N = h->imgc * B;
                 const long FF = h->F;
-                if (c.w_pix == 0.f && !use_disc) LA_HIP(hipMemsetAsync(h->g_img, 0, sizeof(float) * (size_t)B * h->imgc * h->R * h->R, st));
-                if ((rc = la_crop_repeat_ex3(img, h->l_xc, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, h->crop_dev, 3, h->pre_scale, h->pre_shift, sl))) return rc;
-                if ((rc = la_feat_forward(h->f, h->l_xc, N, h->l_feat, sl))) return rc;
-                if (L) {
-                    for (int ch = 0; ch < h->imgc; ++ch)
-                        if ((rc = la_l2_mean_from_bank(h->bankF + (long)ch * h->Mf * FF, h->Mf, FF, h->l_feat + (long)ch * B * FF, B, FF, 0,
-                                                       h->l_yx, h->l_yy, h->l_xx, lp_coef, L + 3, ch > 0, st)))
-                            return rc;
+                if (segP) {
+                    if (c.w_pix == 0.f && !use_disc) LA_HIP(hipMemsetAsync(h->g_img, 0, sizeof(float) * (size_t)B * h->imgc * h->R * h->R, st));
+                    if ((rc = la_crop_repeat_ex3(img, h->l_xc, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, h->crop_dev, 3, h->pre_scale, h->pre_shift, sl))) return rc;
+                    if ((rc = la_feat_forward(h->f, h->l_xc, N, h->l_feat, sl))) return rc;
+                    if (L) {
+                        for (int ch = 0; ch < h->imgc; ++ch)
+                            if ((rc = la_l2_mean_from_bank(h->bankF + (long)ch * h->Mf * FF, h->Mf, FF, h->l_feat + (long)ch * B * FF, B, FF, 0,
+                                                           h->l_yx, h->l_yy, h->l_xx, lp_coef, L + 3, ch > 0, st)))
+                                return rc;
+                    }
+                    const long total = (long)N * FF;
+                    hipLaunchKernelGGL(la_lpips_gfeat_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, sl, h->l_feat, h->l_colsum, h->l_gfeat,
+                                       B, (int)FF, -2.f * lp_coef, (float)h->Mf, total);
+                    if ((rc = la_feat_backward(h->f, h->l_gfeat, h->l_gxc, sl))) return rc;
                 }
-                const long total = (long)N * FF;
-                hipLaunchKernelGGL(la_lpips_gfeat_kernel, dim3(la_cdiv(total, 256)), dim3(256), 0, sl, h->l_feat, h->l_colsum, h->l_gfeat,
-                                   B, (int)FF, -2.f * lp_coef, (float)h->Mf, total);
-                if ((rc = la_feat_backward(h->f, h->l_gfeat, h->l_gxc, sl))) return rc;
                 if (fork) {      // join: the crop gradient is added into g_img on the launch stream, after the discriminator's
                     LA_HIP(hipEventRecord(h->ev_join, h->side_stream));
                     LA_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
                 }
-                if ((rc = la_crop_repeat_grad_ex3(h->l_gxc, h->g_img, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, h->crop_dev, 3, h->pre_scale, st)))
+                if (segZ && (rc = la_crop_repeat_grad_ex3(h->l_gxc, h->g_img, B, h->imgc, h->R, h->S, h->crop_y, h->crop_x, h->crop_dev, 3, h->pre_scale, st)))
                     return rc;
             }
-            mark(5);
-            if ((rc = la_synth_backward(h->g, h->g_img, h->dws, st))) return rc;
+            if (segZ) {
+                mark(5);
+                if ((rc = la_synth_backward(h->g, h->g_img, h->dws, st))) return rc;
+            }
             dws = h->dws;
-        } else { mark(3); mark(4); mark(5); }
+        } else if (segZ) { mark(3); mark(4); mark(5); }
+        if (!segZ) return LA_OK;
         // dw = sum_ws dws + latent gradient, Adam, step counter: one launch (la_step_tail)
         rc = la_step_tail(dws, h->Mw ? h->colsumW : nullptr, h->dw, h->w_opt, h->m, h->v, B, h->num_ws, wd, -2.f * lat_coef, (float)h->Mw,
                           c.lr, c.beta1, c.beta2, c.eps, h->adam_tab, h->step_ctr, h->step_ctr + 8, st);
@@ -473,26 +502,44 @@ extern "C" int la_latent_opt_run(la_latent_opt* h, const float* w0, int B, const
     const bool tracing = h->trace_w || h->trace_img || h->trace_dw;
     const bool replay = h->graph_mode == 1 && !want_losses && !tracing && c.steps > 0 && !la_prof_enabled();
     int first_graph_step = 1;
-    if (replay && (!h->graph_exec || h->graph_B != B || h->graph_win != (int)windowed)) {
+    // split replay (overlap mode 1, both image criteria on): four graphs per step, the perceptual one on the side stream
+    const bool split = replay && h->overlap == 1 && use_disc && use_lpips && h->side_stream && h->ev_fork && h->ev_join;
+    auto capture = [&](int seg, hipGraph_t* g, hipGraphExec_t* e) -> bool {
+        bool ok = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+            const int rcs = run_step(nullptr, h->cap_stream, -1, seg);
+            const hipError_t er = hipStreamEndCapture(h->cap_stream, g);
+            ok = rcs == LA_OK && er == hipSuccess && *g;
+        }
+        if (ok) ok = hipGraphInstantiate(e, *g, nullptr, nullptr, 0) == hipSuccess;
+        return ok;
+    };
+    const bool have = split ? (h->seg_valid != 0) : (h->graph_exec != nullptr);
+    if (replay && (!have || h->graph_B != B || h->graph_win != (int)windowed)) {
         drop_graph(h);
         if ((rc = run_step(nullptr, stream))) return rc;          // step 1, eager
         first_graph_step = 2;
         bool ok = c.steps >= 2;
         if (ok && !h->cap_stream) ok = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) == hipSuccess;
-        if (ok) {
-            ok = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
-            if (ok) {
-                const int rcs = run_step(nullptr, h->cap_stream);
-                const hipError_t e = hipStreamEndCapture(h->cap_stream, &h->graph);
-                ok = rcs == LA_OK && e == hipSuccess && h->graph;
-            }
-            if (ok) ok = hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0) == hipSuccess;
-        }
+        if (ok && split) {
+            for (int k = 0; k < 4 && ok; ++k) ok = capture(1 << k, &h->seg_graph[k], &h->seg_exec[k]);
+            if (ok) h->seg_valid = 1;
+        } else if (ok) ok = capture(15, &h->graph, &h->graph_exec);
         if (ok) { h->graph_B = B; h->graph_win = (int)windowed; }
         else { drop_graph(h); (void)hipGetLastError(); if (c.steps >= 2) { h->graph_mode = 0; h->graph_refused = 1; } }
     }
     for (int step = first_graph_step; step <= c.steps; ++step) {
-        if (replay && h->graph_exec && h->graph_B == B) LA_HIP(hipGraphLaunch(h->graph_exec, stream));
+        if (replay && split && h->seg_valid && h->graph_B == B) {
+            // A on the launch stream | fork | P on the side stream beside D on the launch stream | join | Z
+            LA_HIP(hipGraphLaunch(h->seg_exec[0], stream));
+            LA_HIP(hipEventRecord(h->ev_fork, stream));
+            LA_HIP(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+            LA_HIP(hipGraphLaunch(h->seg_exec[1], h->side_stream));
+            LA_HIP(hipEventRecord(h->ev_join, h->side_stream));
+            LA_HIP(hipGraphLaunch(h->seg_exec[2], stream));
+            LA_HIP(hipStreamWaitEvent(stream, h->ev_join, 0));
+            LA_HIP(hipGraphLaunch(h->seg_exec[3], stream));
+        } else if (replay && !split && h->graph_exec && h->graph_B == B) LA_HIP(hipGraphLaunch(h->graph_exec, stream));
         else {
             if ((rc = run_step(want_losses ? h->losses + (size_t)(step - 1) * 4 : nullptr, stream, step - 1))) return rc;
             // verbose_log snapshots (util_latent_aug.py:292-295): the image synthesised in this step, the latent after its update

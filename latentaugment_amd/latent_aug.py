@@ -333,8 +333,12 @@ class LatentAug:
         _lib.check(lib.la_latent_opt_set_graph(h, int(self.hip_graph)), 'la_latent_opt_set_graph')
         # independent image criteria (discriminator, perceptual) side by side inside a step (default) or one after the other
         # (`opt.overlap_criteria = False`): bit-identical results, la_latent_opt_set_overlap
-        self.overlap_criteria = bool(getattr(opt, 'overlap_criteria', True))
-        _lib.check(lib.la_latent_opt_set_overlap(h, int(self.overlap_criteria)), 'la_latent_opt_set_overlap')
+        # `opt.overlap_criteria`: True / 2 (default) = fork / join inside the captured step (two parallel branches of one graph), 1 = split
+        # replay (round-5 experiment: the perceptual branch as a graph of its own on a side stream; measured equal: 145.5 against 145.1 ms
+        # at preset E, 158.6 one after the other), False / 0 = one after the other
+        oc = getattr(opt, 'overlap_criteria', True)
+        self.overlap_criteria = int(oc) if not isinstance(oc, bool) else (2 if oc else 0)
+        _lib.check(lib.la_latent_opt_set_overlap(h, self.overlap_criteria), 'la_latent_opt_set_overlap')
         # rows of the image that the loop's criteria read: the pixel criterion its centre crop (util_dataset.py:317-323), the perceptual
         # criterion a crop_size_aug window inside that crop when preprocess_aug is one of the centre modes -- the loop steps then
         # synthesise only what those rows depend on (la_latent_opt_set_row_window; `opt.loop_window = False`: whole frames in every step).
