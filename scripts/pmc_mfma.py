@@ -17,7 +17,7 @@ for name, cn, v, d, did in db.execute("select kernel_name, counter_name, value, 
         seen.add((did, key))
         dur[key] += d
         cnt[key] += 1
-out = {'note': 'SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per v_mfma_f32_32x32x16_f16); SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles summed over '
+out = {'note': 'SQ_VALU_MFMA_BUSY_CYCLES counts cycles (16 per v_mfma_f32_16x16x32_f16, the instruction of the default contraction kernels; 32 per v_mfma_f32_32x32x16_f16, the 64- / 32-row forms); SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles summed over '
                'waves.  mfma_busy_frac = MFMA busy cycles / (1024 SIMDs x kernel time x 2.4 GHz): a LOWER bound on the pipe utilisation '
                '(the sustained clock under MFMA load is 1.9-2.3 GHz).  Kernel durations under --pmc are longer than in the kernel-trace run.',
        'kernels': {}}
