@@ -12,7 +12,7 @@ CLASS_KERNELS = {
     'conv_splitk': 'la_conv_bf16_kernel<split=true> + la_conv_splitk_finish_kernel (layers <= 32^2)',
     'conv_f32': 'la_conv_igemm_kernel (exact fp32 MFMA)',
     'operand_prep': 'la_presplit_t_kernel / la_plane_absmax_kernel / la_xscale_kernel / la_xscale_pmax_kernel (fp16 operand scale and pre-split copy)',
-    'fir': 'la_fir4x4_* / la_upfirdn2d_kernel (upfirdn2d family, fwd with the layer epilogue, adjoint)',
+    'fir': 'la_fir4x4_* / la_upfirdn2d_kernel / la_imgrad_pyramid_kernel (upfirdn2d family, fwd with the layer epilogue, adjoint, image-gradient pyramid)',
     'seam_bwd': 'la_seam_bwd_kernel (bias_act backward + ToRGB backward + demod-gradient reductions)',
     'torgb_fwd': 'la_torgb_fwd*_kernel (1x1 modulated ToRGB + clamp + skip add)',
     'bank': 'la_bank_* (criteria bank scans)',
@@ -25,7 +25,7 @@ _RULES = [
     ('la_conv_splitk_finish', 'conv_splitk'),
     ('la_conv_igemm', 'conv_f32'),
     ('la_presplit', 'operand_prep'), ('la_plane_absmax', 'operand_prep'), ('la_act_grad_pmax', 'operand_prep'), ('la_xscale', 'operand_prep'),
-    ('la_fir4x4', 'fir'), ('la_upfirdn2d_kernel', 'fir'),
+    ('la_fir4x4', 'fir'), ('la_upfirdn2d_kernel', 'fir'), ('la_imgrad_pyramid', 'fir'),
     ('la_seam_bwd', 'seam_bwd'),
     ('la_torgb_fwd', 'torgb_fwd'),
     ('la_bank', 'bank'),
