@@ -378,6 +378,12 @@ def main():
     args = apply_preset(parse())
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args.gpus)
+    # stdout carries ONE line, the JSON line of rank 0: whatever libraries print there while the run lasts (gloo announces its peers on
+    # stdout when a group is created, a child of a launcher shares the parent's stdout) goes to stderr instead -- file descriptor 1 is
+    # pointed at descriptor 2 for the duration, the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -541,8 +547,9 @@ def main():
         line['roofline'] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.preset == 'B' and args.w_disc == 0:
         line['cpu_baseline'] = cpu_baseline(sd, meta, args)
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        os.write(real_stdout, (json.dumps(line) + '\n').encode())
     if use_dist:
         dist.destroy_process_group()
     if wit is not None and not wit['ok']:
