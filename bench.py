@@ -402,6 +402,9 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533'); os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if os.environ['MASTER_ADDR'] in ('127.0.0.1', 'localhost'):      # one node: gloo (the control group) and RCCL's bootstrap on loopback --
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')             # a container's hostname may not resolve to an interface
+            os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
         if args.dist_backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)      # nccl == RCCL on ROCm
         else:
