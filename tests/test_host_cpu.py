@@ -270,3 +270,48 @@ def test_stream_lane_rule():
             gh = min(4, len(half))
             for m in range(len(half) // gh):
                 assert frozenset(half[m + j * (len(half) // gh)] for j in range(gh)) in groups
+
+
+def test_bench_witness_accepts_the_reference_and_rejects_a_wrong_batch():
+    """bench.py's correctness witness (the last timed batch against the reference's fixture of the workload) on the host: the reference's
+    own float32 result passes its own bound, a result two Adam steps off in a handful of entries or with a scrambled image does not, a
+    workload without a fixture yields no verdict."""
+    import types
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    fx = np.load(os.path.join(ROOT, 'tests', 'golden', 'fullsize_B.npz'))
+    args = types.SimpleNamespace(w_disc=0.0, preset='B', res=256, channel_base=32768, batch=8, latent_steps=20)
+
+    def run(w, img_sub):
+        w_aug = torch.tensor(w, dtype=torch.float32)[:, None, :].repeat(1, 14, 1)
+        full = torch.zeros([8, 2, 256, 256])
+        full[:, :, 2::4, 2::4] = torch.tensor(img_sub, dtype=torch.float32)
+        return bench.witness(args, w_aug, {'A': full[:, :1], 'B': full[:, 1:]}, 0, 8)
+    ok = run(fx['ref32_w'], fx['ref32_img_sub'])
+    assert ok['ok'] is True and abs(ok['w_rms_vs_f64'] - ok['reference_f32_rms_vs_f64']) < 1e-9
+    bad_w = fx['ref32_w'].copy()
+    bad_w[:, :8] += 0.02
+    assert run(bad_w, fx['ref32_img_sub'])['ok'] is False
+    assert run(fx['ref32_w'], fx['ref32_img_sub'][::-1].copy())['ok'] is False
+    args.batch = 4
+    assert bench.witness(args, torch.zeros([4, 14, 512]), {}, 0, 4) is None
+
+
+def test_kernel_class_map_is_the_profilers():
+    """One class map (latentaugment_amd/kernel_classes.py) for bench.py's brackets and the rocprofv3 post-processing: its order is the
+    C enum's (csrc/la_common.h), every class is described, and the kernels of the contraction classes land where the library brackets them."""
+    import re
+    from latentaugment_amd import kernel_classes as kc
+    src = open(os.path.join(ROOT, 'latentaugment_amd', 'csrc', 'la_common.h')).read()
+    enum = re.search(r'enum \{ (LA_PC_CONV_HALO.*?)LA_PC_NCLASS \}', src, re.S).group(1)
+    names = [n.strip() for n in enum.replace('= 0', '').split(',') if n.strip()]
+    want = {'LA_PC_CONV_HALO': 'conv_halo', 'LA_PC_CONV_FLAT': 'conv_flat', 'LA_PC_CONV_SPLITK': 'conv_splitk', 'LA_PC_CONV_F32': 'conv_f32',
+            'LA_PC_PRESPLIT': 'operand_prep', 'LA_PC_FIR': 'fir', 'LA_PC_SEAM': 'seam_bwd', 'LA_PC_TORGB': 'torgb_fwd', 'LA_PC_BANK': 'bank'}
+    assert [want[n] for n in names] == kc.CLASSES and set(kc.CLASS_KERNELS) == set(kc.CLASSES)
+    assert kc.class_of('void la_conv_bf16_halo_kernel<128, 16, 3, 5>(LaConvArgs)') == 'conv_halo'
+    assert kc.class_of('void la_conv_bf16_kernel<128, true, 16, 3, 1>(LaConvArgs)') == 'conv_splitk'
+    assert kc.class_of('void la_conv_bf16_kernel<128, false, 16, 3, 2>(LaConvArgs)') == 'conv_flat'
+    assert kc.class_of('la_conv_splitk_finish_kernel<4>') == 'conv_splitk' and kc.class_of('la_xscale_bound_kernel') is None
+    assert kc.class_of('la_imgrad_pyramid_kernel(PyrArgs)') == 'fir' and kc.class_of('la_step_tail_kernel') is None
