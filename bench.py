@@ -78,7 +78,7 @@ def parse():
     p.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured step')
     p.add_argument('--lanes', default='auto', choices=['auto', '1', '2'],
                    help="stream lanes: a full local batch as two interleaved half-batch loops on two HIP streams ('auto': when the batch is even, >= 4 and "
-                        "the perceptual criterion is off; 1: never; 2: whenever the batch allows it)")
+                        "the perceptual criterion is off or runs beside the discriminator; 1: never; 2: whenever the batch allows it)")
     p.add_argument('--whole-frames', action='store_true',
                    help='every loop step synthesises the whole frame (default: with the discriminator off, only the rows the criteria\'s centre crop depends on)')
     p.add_argument('--no-window-columns', action='store_true', help='row windows only (the top block computes whole rows)')

@@ -313,8 +313,8 @@ class LatentAug:
         self._opt, self._discriminator, self._feature_net = opt, discriminator, feature_net
         # stream lanes: a full local batch as two interleaved half-batch loops on two HIP streams, each with its own loop /
         # synthesis / discriminator handles.  `opt.stream_lanes`: 'auto' (default: two lanes for a full, even batch of >= 4 samples -- with
-        # the discriminator a multiple of 8 -- when the perceptual criterion is off -- with it on, the discriminator and the perceptual branch already run side by side inside ONE
-        # loop, which measures faster), 1 (never) or 2 (whenever the batch allows it).
+        # the discriminator a multiple of 8 -- when the perceptual criterion is off, or on TOGETHER with the discriminator: lanes_eligible),
+        # 1 (never) or 2 (whenever the batch allows it).
         self.stream_lanes = getattr(opt, 'stream_lanes', 'auto')
         assert self.stream_lanes in ('auto', 1, 2), "opt.stream_lanes: 'auto', 1 or 2"
         self._lanes = None
@@ -517,7 +517,12 @@ class LatentAug:
             return False
         if self.w_disc > 0 and b % 8:
             return False
-        return self.stream_lanes == 2 or self.w_lpips <= 0
+        if self.stream_lanes == 2 or self.w_lpips <= 0:
+            return True
+        # perceptual criterion: lanes pay only beside the discriminator, with the criteria branches of a lane replayed on two streams
+        # (overlap mode 1, build_lanes): preset E 144.1 -> 141.7 ms, three alternating pairs on one box (round 5); with the criteria one
+        # after the other (mode 0) 148.9, with the fork inside each lane's captured step (mode 2) 185
+        return self.w_disc > 0 and self.overlap_criteria >= 1
 
     def build_lanes(self):
         import copy
@@ -525,6 +530,9 @@ class LatentAug:
         opt = copy.copy(self._opt)
         opt.batch_size, opt.max_local_batch, opt.norm_batch = half, half, self._max_local
         opt.verbose_log, opt.stream_lanes = False, 1
+        # two lanes that each fork inside their captured step lose badly (preset E: 185 against 142 ms): a lane's criteria branches are
+        # replayed as graphs of their own on two streams instead (bit-identical; la_latent_opt_set_overlap mode 1)
+        opt.overlap_criteria = 1 if self.overlap_criteria == 2 else self.overlap_criteria
         shared = {'banks': {'W': self.W, 'fea': list(self.Fbank) if self.feat is not None else None}, 'Xc': self.Xc,
                   'Fbank': self.Fbank if self.feat is not None else None}
         # (banks={}: a lane never builds banks of its own -- neither from `banks` nor from the interim zips -- it gets the parent's

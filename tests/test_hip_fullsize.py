@@ -231,7 +231,7 @@ TIMED = {
     'B': (True, 1.5),      # bench workload: lanes of 4 + 4, row / column windows, graph replay
     'C': (True, 1.5),      # 512^2, B=4: lanes of 2 + 2
     'D': (False, D_SLACK),  # 1024^2, B=2: one loop, windows, graph replay
-    'E': (False, 2.0),     # all criteria: one loop, D || perceptual branch inside the captured step
+    'E': (True, 2.0),      # all criteria: lanes of 4 + 4, each lane's D / perceptual branches replayed on two streams (overlap mode 1)
     'F': (True, 1.5),      # w_disc: lanes of 4 + 4 (MinibatchStd groups = the even / odd halves), whole frames
 }
 
