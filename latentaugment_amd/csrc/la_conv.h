@@ -128,6 +128,9 @@ struct LaConvArgs {
     // image do -- the backward contractions behind a windowed producer, whose other rows hold older contents of a shared buffer while the
     // gradient there is exactly zero.  (Flat kernel: rows of the pre-split operand's grid.)
     int in_row_lo, in_row_hi;
+#ifdef LA_DEV
+    int dbg_stamp;                 // development build: per-wave segment clocks of the MF 5 halo kernel (la_conv_bf16.hip, LA_STAMP)
+#endif
     int nphase;
     struct Phase {
         int Gy, Gx, out_oy, out_ox, ntaps; int tap_dy[LA_CONV_PHASE_TAPS], tap_dx[LA_CONV_PHASE_TAPS], tap_w[LA_CONV_PHASE_TAPS];

@@ -519,6 +519,9 @@ int la_conv_launch(const LaConvArgs& a, hipStream_t stream) {
             const int n8 = (nt + 7) & ~7;
             if (nt > 0 && n8 < tiles) tiles = n8;
         }
+#ifdef LA_DEV
+        as.dbg_stamp = la_dev_knob(LA_KNOB_HALO_STAMP);
+#endif
         dim3 grid(tiles, mtiles, a.B * (nphase > 0 ? nphase : 1));
         if (bf) pcls = la_conv_bf16_uses_halo(as) ? LA_PC_CONV_HALO : LA_PC_CONV_FLAT;
         pslot = la_prof_open(pcls, pflops, pbytes, stream);

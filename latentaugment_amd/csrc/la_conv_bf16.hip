@@ -1142,6 +1142,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
 // 32x32x16 form.  Same weight pack (a 16-row fragment is four 256-byte pieces of the 32-row block), LDS slots swizzled by
 // 2 * ((pixel >> 2) & 1) (conflict-free for this lane map at every tap shift).  The accumulators are brought into the 32x32 layout
 // through LDS before the shared epilogue.
+#ifdef LA_DEV
+// Development build, dev knob LA_KNOB_HALO_STAMP = 1: every wave of the MF 5 halo kernel accumulates s_memtime differences per segment
+// (prologue issue / prologue wait + first stage / tap loops / chunk barriers / accumulator hand-over / epilogue) in scalar registers and
+// leaves them in la_dbg_buf[wave][16] (la_dev_dbg_read); segments 6-8 are stamped inside the epilogue (la_conv_device.h, LA_ESTAMP).  scripts/halo_wave_timeline.py
+__device__ unsigned long long la_dbg_buf[1 << 18];
+#define LA_STAMP_DECL LaStamp stv; stv.on = a.dbg_stamp != 0; stv.last = 0ull; for (int i_ = 0; i_ < 12; ++i_) stv.seg[i_] = 0ull; if (stv.on) stv.last = __builtin_amdgcn_s_memtime();
+#define LA_STAMP(i) do { if (stv.on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stv.seg[i] += t_ - stv.last; stv.last = t_; } } while (0)
+#define LA_STAMP_ARG , -1, &stv
+#define LA_STAMP_OUT do { if (stv.on && (threadIdx.x & 63) == 0) { const long wv_ = ((long)blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z)) * 4 + (threadIdx.x >> 6); \
+    if (wv_ * 16 + 16 <= (1 << 18)) { for (int i_ = 0; i_ < 12; ++i_) la_dbg_buf[wv_ * 16 + i_] = stv.seg[i_]; la_dbg_buf[wv_ * 16 + 12] = stv.last; } } } while (0)
+extern "C" int la_dev_dbg_read(unsigned long long* dst, long n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(la_dbg_buf), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#else
+#define LA_STAMP_DECL
+#define LA_STAMP(i)
+#define LA_STAMP_ARG
+#define LA_STAMP_OUT
+#endif
 template <int MT, int FMT, int WV, int MF = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void la_conv_bf16_halo_kernel(LaConvArgs a) {
     constexpr bool SB = WV == 3;
@@ -1427,6 +1446,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
 
     // ---- prologue: chunk 0's halo (all nine slices in flight at once) and the first tap's weights
     bf16x8 acur[2][NTERM][TM];
+    LA_STAMP_DECL
     if constexpr (PSL) {
         float pre[8][4];
 #pragma unroll
@@ -1437,6 +1457,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             for (int k = tid; k < nck * KCB; k += 256)
                 scl[k] = k < a.C ? (a.in_scale ? a.in_scale[(long)b * a.scale_stride + k] : 1.f) * xs : 0.f;
         }
+        LA_STAMP(0);
         __syncthreads();                           // scl is complete before any slice is scaled with it
 #pragma unroll
         for (int t = 0; t < 8; ++t) ps_write(smem, t, pre[t], ps_factors(0, t));
@@ -1456,6 +1477,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         for (int t = 0; t < 9; ++t) slice_write(smem, pre[t]);
     }
     __syncthreads();
+    LA_STAMP(1);
 
   if constexpr (M16) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1548,7 +1570,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             lb_cur = lb_nxt;
         }
         if constexpr (!PSL) slice_write(nxt, sl);      // (PSL: tap 8 loads nothing)
+        LA_STAMP(2);
         __syncthreads();
+        LA_STAMP(3);
     }
     // 16x16 tiles -> the 32x32 accumulator layout of the epilogue, through LDS (free after the loop's last barrier), two tile rows
     // at a time: image [wave][64 pixels][36 floats] (32 rows + 4 of padding), 16-byte writes and reads
@@ -1580,7 +1604,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
         }
         __syncthreads();
     }
-    la_conv_epilogue<MT, false, true, WM_>(a, acc, red, ntile, m0, G, G);
+    LA_STAMP(4);
+    la_conv_epilogue<MT, false, true, WM_>(a, acc, red, ntile, m0, G, G LA_STAMP_ARG);
+    LA_STAMP(5);
+    LA_STAMP_OUT;
     return;
   } else
   if constexpr (SB) {

@@ -8,6 +8,17 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Development build: per-wave segment clocks (s_memtime differences in scalar registers) of a kernel that passes a LaStamp to its epilogue
+// (la_conv_bf16.hip, dev knob LA_KNOB_HALO_STAMP; scripts/halo_wave_timeline.py).  Segments 0-5 belong to the kernel, 6.. to the epilogue.
+#ifdef LA_DEV
+struct LaStamp { unsigned long long last, seg[12]; bool on; };
+#define LA_ESTAMP(k) do { if (stp && stp->on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stp->seg[k] += t_ - stp->last; stp->last = t_; } } while (0)
+#define LA_ESTAMP_PARAM , LaStamp* stp = nullptr
+#else
+#define LA_ESTAMP(k)
+#define LA_ESTAMP_PARAM
+#endif
+
 #define NT 128
 
 __device__ __forceinline__ float la_conv_epi_fwd(const LaConvArgs& a, float v, float dmv, float nz, float bv) {
@@ -34,7 +45,7 @@ __device__ __forceinline__ void la_conv_zero_partials(const LaConvArgs& a, int b
 
 template <int MT, bool SPLIT, bool TILE2D = false, int WM_ = 2>
 __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&acc)[MT / (32 * WM_)][WM_], float (*red)[MT],   // red: [WN_ > 2 ? 6 : 4][MT] LDS floats
-                                                 int ntile, int m0, int G, int Ntot, int b_sel = -1) {
+                                                 int ntile, int m0, int G, int Ntot, int b_sel = -1 LA_ESTAMP_PARAM) {
     constexpr int TM = MT / (32 * WM_);       // 32-row MFMA tiles per wave
     constexpr int WN_ = 4 / WM_;              // waves along the pixels
     constexpr int NJ = WM_;                   // 32-pixel MFMA tiles per wave (128 / 32 / WN_)
@@ -136,7 +147,9 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                         }
                     }
             }
+            LA_ESTAMP(6);
             __syncthreads();
+            LA_ESTAMP(7);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 // xin of the next four-row group is requested while this group is processed (two groups of 4 x NJ registers live,
@@ -239,6 +252,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                     }
                 }
             }
+            LA_ESTAMP(8);
             if (a.ds_part || seam) {
                 __syncthreads();
                 if (tid < MT) {
@@ -292,7 +306,9 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) nz[j] = a.noise[(long)b * a.noise_bstride + np[j]] * a.noise_strength;
             }
+            LA_ESTAMP(6);
             __syncthreads();
+            LA_ESTAMP(7);
         }
         // activation as straight-line selects (same arithmetic as la_act_fwd)
         const float slope = a.act == LA_ACT_LRELU ? a.alpha : (a.act == LA_ACT_RELU ? 0.f : 1.f);
@@ -347,6 +363,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
                 }
             }
         }
+        LA_ESTAMP(8);
         if (rgbc > 0) {
 #pragma unroll
             for (int c = 0; c < RGB_MAXC; ++c)
