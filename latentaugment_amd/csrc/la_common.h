@@ -57,6 +57,7 @@ static inline const char* la_dev_env(const char*) { return nullptr; }
 #define LA_KNOB_FLAT_MF 2     // flat / split-K contraction form: 0 = default (16x16x32 MFMA), 8 = 32x32x16
 #define LA_KNOB_KSPLIT 3       // dev: force this many K slices on the split-K launches (0 = the cost model's choice)
 #define LA_KNOB_HALO_STAMP 5   // dev: 1 = the MF 5 halo kernel records per-wave segment clocks (la_dev_dbg_read)
+#define LA_KNOB_HALO_LDSPAD 6  // dev: extra KB of LDS per workgroup of the MF 5 halo kernel (occupancy experiments)
 #define LA_NKNOB 16
 int la_prof_open(int cls, double flops, double bytes, hipStream_t stream);     // -> slot or -1
 void la_prof_close(int slot, hipStream_t stream);

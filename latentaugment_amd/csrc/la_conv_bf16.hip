@@ -1151,7 +1151,9 @@ __device__ unsigned long long la_dbg_buf[1 << 18];
 #define LA_STAMP(i) do { if (stv.on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stv.seg[i] += t_ - stv.last; stv.last = t_; } } while (0)
 #define LA_STAMP_ARG , -1, &stv
 #define LA_STAMP_OUT do { if (stv.on && (threadIdx.x & 63) == 0) { const long wv_ = ((long)blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z)) * 4 + (threadIdx.x >> 6); \
-    if (wv_ * 16 + 16 <= (1 << 18)) { for (int i_ = 0; i_ < 12; ++i_) la_dbg_buf[wv_ * 16 + i_] = stv.seg[i_]; la_dbg_buf[wv_ * 16 + 12] = stv.last; } } } while (0)
+    if (wv_ * 16 + 16 <= (1 << 18)) { for (int i_ = 0; i_ < 12; ++i_) la_dbg_buf[wv_ * 16 + i_] = stv.seg[i_]; la_dbg_buf[wv_ * 16 + 12] = stv.last; \
+    unsigned hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); \
+    la_dbg_buf[wv_ * 16 + 13] = hw_; la_dbg_buf[wv_ * 16 + 14] = xcc_; } } } while (0)
 extern "C" int la_dev_dbg_read(unsigned long long* dst, long n) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(la_dbg_buf), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
@@ -1772,13 +1774,18 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
                     constexpr int MFV = decltype(tag)::value;
                     static std::atomic<bool> done[64];
                     if (!done[dev].load(std::memory_order_acquire)) {
+                        #ifdef LA_DEV
+                        const int cap = 160 * 1024;      // (room for LA_KNOB_HALO_LDSPAD)
+#else
                         const int cap = 2 * 3 * HALO_PX * HPITCH + 4096 * (int)sizeof(float);
+#endif
                         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&la_conv_bf16_halo_kernel<128, FMT_F16X2, 3, MFV>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess) {
                             la_set_error("halo MF: hipFuncSetAttribute failed"); return LA_ERR_HIP;
                         }
                         done[dev].store(true, std::memory_order_release);
                     }
-                    hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, FMT_F16X2, 3, MFV>), grid, dim3(256), h128, stream, as);
+                    // (dev knob LA_KNOB_HALO_LDSPAD: extra KB of dynamic LDS per workgroup -- fewer workgroups per CU, for scripts/halo_wave_timeline.py)
+                    hipLaunchKernelGGL((la_conv_bf16_halo_kernel<128, FMT_F16X2, 3, MFV>), grid, dim3(256), h128 + (size_t)la_dev_knob(LA_KNOB_HALO_LDSPAD) * 1024, stream, as);
                     return LA_OK;
                 };
                 switch (mf) {

@@ -18,6 +18,8 @@ ap.add_argument('--res', type=int, default=256)
 ap.add_argument('--ch', type=int, default=128)
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--bwd', action='store_true')
+ap.add_argument('--stagger', type=int, default=0, help='dev knob 7: -1 = no phase stagger, 0 = the host estimate, else cycles per wave slot')
+ap.add_argument('--ldspad', type=int, default=0, help='extra KB of LDS per workgroup (30: two workgroups per CU, 100: one)')
 a = ap.parse_args()
 _lib.select_dev_build()
 lib = _lib.load()
@@ -59,10 +61,14 @@ for _ in range(3):
     run()
 torch.cuda.synchronize()
 lib.la_dev_knob_set(5, 1)
+lib.la_dev_knob_set(6, a.ldspad)
+lib.la_dev_knob_set(7, a.stagger)
 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
 t0.record(); run(); t1.record()
 torch.cuda.synchronize()
 lib.la_dev_knob_set(5, 0)
+lib.la_dev_knob_set(6, 0)
+lib.la_dev_knob_set(7, 0)
 tiles = (res // 4) * (res // 32)
 nw = tiles * ((cout + 127) // 128) * B * 4
 buf = np.zeros([nw * 16], dtype=np.uint64)
@@ -80,3 +86,22 @@ print(f'wave lifetime: mean {tot.mean():.0f}  median {np.median(tot):.0f}  p10 {
 for i, n in enumerate(names):
     c = seg[:, i]
     print(f'  {n:42s} mean {c.mean():8.0f} ({100 * c.mean() / tot.mean():4.1f} %)  median {np.median(c):8.0f}  p10 {np.percentile(c, 10):8.0f}  p90 {np.percentile(c, 90):8.0f}')
+
+# how many waves of a SIMD are in their tap loops at a time: (xcc, se, cu, simd) from HW_ID / XCC_ID, intervals from the stamps
+hw = v[:, 13].astype(np.int64); xcc = v[:, 14].astype(np.int64) & 0xf
+key = (xcc << 20) | (((hw >> 13) & 7) << 16) | (((hw >> 8) & 15) << 8) | ((hw >> 4) & 3)
+print('wave slots seen (HW_ID & 15):', np.bincount(hw & 15)[:12], ' SIMDs seen:', len(np.unique(key)))
+loop0 = start + seg[:, 0] + seg[:, 1]; loop1 = loop0 + seg[:, 2] + seg[:, 3]
+hist = np.zeros(8); alive = np.zeros(8)
+for k in np.unique(key)[:256]:
+    m = key == k
+    ev = sorted([(t, 1) for t in loop0[m]] + [(t, -1) for t in loop1[m]])
+    n = 0; last = ev[0][0]
+    for t, d in ev:
+        hist[min(n, 7)] += t - last; last = t; n += d
+    ev = sorted([(t, 1) for t in start[m]] + [(t, -1) for t in end[m]])
+    n = 0; last = ev[0][0]
+    for t, d in ev:
+        alive[min(n, 7)] += t - last; last = t; n += d
+print('share of the time with k waves of a SIMD in their tap loops, k = 0..4:', np.round(hist[:5] / hist.sum(), 3))
+print('share of the time with k waves resident on a SIMD,            k = 0..4:', np.round(alive[:5] / alive.sum(), 3))
