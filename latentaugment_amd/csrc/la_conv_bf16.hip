@@ -893,20 +893,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             load_b(c2, t2);                            // step s+3
             __builtin_amdgcn_sched_barrier(0);
             const bool more = s + 1 < nstep;
+            // every pixel fragment read ONCE per step (round 5, as the halo kernel's tap loop): quarters tiles 0-3 x rows 0-15, tiles 0-3 x rows
+            // 16-31, tiles 4-7 x rows 0-15, tiles 4-7 x rows 16-31; a slot is re-filled after its second use with the tile four sub-steps
+            // ahead (tile k + 4 of this step, then tile k of step s+1, published by the PREVIOUS barrier); the next step's weights get a
+            // quarter step to land.  Round 4 walked all eight tiles per 16-row half and read every fragment twice
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int hf = q4 >> 1, mi = q4 & 1;
 #pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    f16x8 (&bs)[2] = b16[n & 3];
+                for (int k = 0; k < 4; ++k) {
+                    const int n = hf * 4 + k;
+                    f16x8 (&bs)[2] = b16[k];
                     acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][1], bs[0], acc16[mi][n], 0, 0, 0);   // lh
                     acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][0], bs[1], acc16[mi][n], 0, 0, 0);   // hl
                     acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][0], bs[0], acc16[mi][n], 0, 0, 0);   // hh
-                    if (n < 4) read_b16(cur, n + 4, bs);                 // the slot is re-filled with the tile four sub-steps ahead
-                    else if (mi == 0) read_b16(cur, n - 4, bs);          // (the same pixels again for the other 16 rows)
-                    else if (more) read_b16(nx1, n - 4, bs);             // first tiles of step s+1: published by the PREVIOUS barrier
+                    if (mi == 1) {
+                        if (hf == 0) read_b16(cur, 4 + k, bs);
+                        else if (more) read_b16(nx1, k, bs);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                load_a16(c1, t1, mi, a16[mi]);         // this half's weights of step s+1
+                if (q4 >= 2) load_a16(c1, t1, mi, a16[mi]);         // this half's weights of step s+1
             }
             adv(c1, t1);           // weights run one step ahead, pieces three
             adv(c2, t2);
@@ -936,19 +943,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             write_b(nxt);                              // step s+1 (loaded during step s-1)
             load_b(c2, t2);                            // step s+2
             __builtin_amdgcn_sched_barrier(0);
+            // (every pixel fragment read once per step, as in the three-buffer form above)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int hf = q4 >> 1, mi = q4 & 1;
 #pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    f16x8 (&bs)[2] = b16[n & 3];
+                for (int k = 0; k < 4; ++k) {
+                    const int n = hf * 4 + k;
+                    f16x8 (&bs)[2] = b16[k];
                     acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][1], bs[0], acc16[mi][n], 0, 0, 0);   // lh
                     acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][0], bs[1], acc16[mi][n], 0, 0, 0);   // hl
                     acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][0], bs[0], acc16[mi][n], 0, 0, 0);   // hh
-                    if (n < 4) read_b16(cur, n + 4, bs);                 // the slot is re-filled with the tile four sub-steps ahead
-                    else if (mi == 0) read_b16(cur, n - 4, bs);          // (the same pixels again for the other 16 rows)
+                    if (mi == 1 && hf == 0) read_b16(cur, 4 + k, bs);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                load_a16(c1, t1, mi, a16[mi]);         // this half's weights of step s+1
+                if (q4 >= 2) load_a16(c1, t1, mi, a16[mi]);         // this half's weights of step s+1
             }
             c1 = c2; t1 = t2;
             adv(c2, t2);
@@ -1171,6 +1180,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
     // MF bits: 1 = 16x16x32 MFMA; 2 = dev ablation (the loader skips the modulation and the fp16 split arithmetic: WRONG results, timing
     // only); 4 = pixel-stationary halo loader (below)
     constexpr bool M16 = (MF & 1) != 0, ABL = (MF & 2) != 0, PSL = (MF & 4) != 0;
+    constexpr bool FR1 = (MF & 16) != 0;        // 16x16x32 form with every pixel fragment read once per tap (tap loop below)
+    static_assert(!FR1 || (M16 && PSL), "the fragment-once order exists for MF 5");
     constexpr int NTERM = FMT == FMT_BF16X3 ? 3 : 2;
     constexpr bool F16 = FMT == FMT_F16X2;
     constexpr int WM_ = MT / 32;                   // wave grid WM_ x WN_ over the MT x 128 tile: every wave owns 32 rows
@@ -1542,6 +1553,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
             const int lb_nxt = PSL ? lane_b16(shift_n, (int)((xpack >> (2 * (t + 1 < 9 ? t + 1 : 8))) & 3u)) : 0;
             float4 psf = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (PSL) { if (has_next && t >= 1) psf = ps_factors(cc + 1, t - 1); }
+            if constexpr (FR1) {
+                // every pixel fragment read ONCE per tap: four quarters (tiles 0-3 x rows 0-15, tiles 0-3 x rows 16-31, tiles 4-7 x rows 0-15,
+                // tiles 4-7 x rows 16-31); a slot is re-filled after its second use with the tile four steps ahead (tile k + 4 of this tap, then
+                // tile k of the next tap).  Half the LDS fragment traffic of the order below (the LDS pipe of a CU is busy 54-90 % under three
+                // workgroups, profiles/r05_pmc_halo_waits.txt) -- at the price of a QUARTER tap instead of half a tap for the next weights to land
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int hf = q4 >> 1, mi = q4 & 1;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int n = hf * 4 + k;
+                        f16x8 (&bs)[2] = b16[k];
+                        acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][1], bs[0], acc16[mi][n], 0, 0, 0);   // lh
+                        acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][0], bs[1], acc16[mi][n], 0, 0, 0);   // hl
+                        acc16[mi][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mi][0], bs[0], acc16[mi][n], 0, 0, 0);   // hh
+                        if (mi == 1) {
+                            if (hf == 0) read_b16(cur, shift, 4 + k, bs, lb_cur);
+                            else if (t + 1 < 9) read_b16(cur, shift_n, k, bs, lb_nxt);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (q4 == 2) load_a16(ccn, tn, 0, a16[0]);      // rows 0-15 are done with this tap's weights: the next tap's, a quarter tap to land
+                    if (q4 == 3) load_a16(ccn, tn, 1, a16[1]);
+                    if (q4 == 1) {
+                        if (has_next && t >= 1) ps_write(nxt, t - 1, psx, psf);      // the slice loaded one tap ago
+                        ps_load(has_next ? cc + 1 : cc, t, psx);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -1568,6 +1609,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WV))) void 
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
             }
             lb_cur = lb_nxt;
         }
@@ -1768,7 +1810,7 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
             // fp16 x2 launches on 128-row tiles with more than one chunk: the 16x16x32 / pixel-stationary form (MF 5, kernel comment).
             // Dev knob (in-process A/B): 0 = this default, 8 = the round-2 form (MF 0), otherwise the MF bits to run.
             const int knob = la_dev_knob(LA_KNOB_HALO_MF);
-            const int mf = knob == 0 ? 5 : (knob == 8 ? 0 : knob);
+            const int mf = knob == 0 ? 21 : (knob == 8 ? 0 : knob);      // (21 = MF 5 with every pixel fragment read once per tap, round 5)
             if (MTsel == 128 && w3 && as.C > KCB && mf > 0) {
                 auto go = [&](auto tag) -> int {
                     constexpr int MFV = decltype(tag)::value;
@@ -1793,8 +1835,9 @@ static int launch_bf16(const LaConvArgs& as, int MTsel, dim3 grid, bool split, h
                     case 1: return go(std::integral_constant<int, 1>{});
                     case 4: return go(std::integral_constant<int, 4>{});
                     case 7: return go(std::integral_constant<int, 7>{});      // (loader ablation: wrong results, timing only)
+                    case 5: return go(std::integral_constant<int, 5>{});      // (round 4: every pixel fragment read twice per tap)
 #endif
-                    case 5: return go(std::integral_constant<int, 5>{});
+                    case 21: return go(std::integral_constant<int, 21>{});
                     default: break;
                 }
             }
