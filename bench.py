@@ -49,7 +49,7 @@ CONTRACTION = {
     'f32': dict(peak=MFMA_F32_PEAK_TFLOPS, kernel='la_conv_igemm_kernel (fp32 MFMA 32x32x2, exact fp32)', mfma_per_product=1),
     'bf16x3': dict(peak=MFMA_BF16_PEAK_TFLOPS / 6, kernel='la_conv_bf16_halo_kernel<FMT_BF16X3> (fp32 split into 3 bf16 terms, 6 bf16 '
                    'MFMA 32x32x16 per product, fp32 accumulate; fp32-class error)', mfma_per_product=6),
-    'f16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_halo_kernel<128, FMT_F16X2, 3, 5> (fp32 scaled by powers of two and '
+    'f16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_halo_kernel<128, FMT_F16X2, 3, 21> (fp32 scaled by powers of two and '
                   'split into 2 fp16 terms, 3 fp16 MFMA 16x16x32 per product, fp32 accumulate; fp32-class error)', mfma_per_product=3),
     'bf16x2': dict(peak=MFMA_BF16_PEAK_TFLOPS / 3, kernel='la_conv_bf16_halo_kernel<NTERM=2> (2 bf16 terms, 3 bf16 MFMA per product; '
                    'approximate mode)', mfma_per_product=3),
