@@ -8,6 +8,7 @@ declare -A BASE=(
   [lin_halo_kernel.patch]=68a3dd7 [k4_kernel.patch]=fb43017 [halo_mt64_m16.patch]=5eba378 [splitk_fused_reduce.patch]=aea95d9
   [halo_splitk_small_grids.patch]=884a882 [image_chain_side_stream.patch]=4efbee0 [splitk_direct_fp32_loader.patch]=a6f3349
   [disc_skip_branch_side_stream.patch]=f51b360 [halo_persistent_small_tiles.patch]=198c70d
+  [epilogue_wide_stores.patch]=bd209d2 [epilogue_straightline_and_stagger.patch]=f8bfd28
 )
 rc=0
 for p in scripts/exp/*.patch; do
