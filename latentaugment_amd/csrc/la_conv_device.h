@@ -5,6 +5,7 @@
 //   m = m0 + wm*(MT/WM_) + i*32 + (r&3) + 8*(r>>2) + 4*(lane>>5) ;  pixel = ntile*128 + (wn*NJ + j)*32 + (lane&31).
 #pragma once
 #include "la_conv.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -327,7 +328,7 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
             if (tid < MT) {
 #pragma unroll
                 for (int c = 0; c < RGB_MAXC; ++c)
-                    if (c < rgbc) red[16 + c][tid] = a.rgb_w[(long)c * a.M + tid] * a.rgb_s[(long)b * a.rgb_s_stride + tid];
+                    red[16 + c][tid] = c < rgbc ? a.rgb_w[(long)c * a.M + tid] * a.rgb_s[(long)b * a.rgb_s_stride + tid] : 0.f;
             }
             __syncthreads();
         }
@@ -337,31 +338,60 @@ __device__ __forceinline__ void la_conv_epilogue(const LaConvArgs& a, f32x16 (&a
         float* fxs_row = (fwd && a.fwd_xs_out) ? a.fwd_xs_out + (long)b * LA_XS_FAN + la_xs_sub() : nullptr;
         const float fxs_seen = (fxs_row && tid == 0) ? la_xs_peek(fxs_row) : 0.f;      // (early: the round trip hides under the stores)
         float ymax = 0.f;
+        typedef float f32x4p __attribute__((ext_vector_type(4)));
+        // The value loop, instantiated per block-uniform case (raw / forward; second output with or without addend; fused ToRGB) so that the
+        // case in hand is straight-line code (round 4 tested `fwd`, `o2`, `ad`, `rgbc > 0` and `c < rgbc` per VALUE: ~250 scalar branches per
+        // lane-loop, their blocks laid out far apart); the row tables are read four rows at a time (16-byte LDS reads)
+        auto value_loop = [&](auto fwd_c, auto o2_c, auto ad_c, auto rgb_c) {
+            constexpr bool FWD = decltype(fwd_c)::value, O2 = decltype(o2_c)::value, AD = decltype(ad_c)::value, RGB = decltype(rgb_c)::value;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int mr = i * 32 + (r & 3) + 8 * (r >> 2);
-                const float dmv = fwd ? prm[mw + mr] : 1.f, bv = fwd ? prm[MT + mw + mr] : 0.f;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    float v = acc[i][j][r];
-                    if (fwd) {
-                        v = v * dmv + nz[j] + bv;
-                        v = v > 0.f ? v : v * slope + 0.f;
-                        v *= a.gain;
-                        v = fminf(fmaxf(v, -cl), cl);
+                for (int g = 0; g < 4; ++g) {
+                    const int mg = i * 32 + 8 * g;
+                    f32x4p dm4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f}, wr4[RGB_MAXC];
+                    if constexpr (FWD) {
+                        dm4 = *reinterpret_cast<const f32x4p*>(&prm[mw + mg]);
+                        b4 = *reinterpret_cast<const f32x4p*>(&prm[MT + mw + mg]);
                     }
-                    o0[(long)mr * HWo + np[j]] = v;
-                    if (o2) { const float v2 = v + (ad ? ad[(long)mr * HWo + np[j]] : 0.f); o2[(long)mr * HWo + np[j]] = v2; ymax = fmaxf(ymax, fabsf(v2)); }
-                    else ymax = fmaxf(ymax, fabsf(v));
-                    if (rgbc > 0) {
+                    if constexpr (RGB) {
 #pragma unroll
-                        for (int c = 0; c < RGB_MAXC; ++c)
-                            if (c < rgbc) pr[c][j] += red[16 + c][mw + mr] * v;
+                        for (int c = 0; c < RGB_MAXC; ++c) wr4[c] = *reinterpret_cast<const f32x4p*>(&red[16 + c][mw + mg]);      // (rows c >= rgbc: zeros)
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = 4 * g + q, mr = mg + q;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            float v = acc[i][j][r];
+                            if constexpr (FWD) {
+                                v = v * dm4[q] + nz[j] + b4[q];
+                                v = v > 0.f ? v : v * slope + 0.f;
+                                v *= a.gain;
+                                v = fminf(fmaxf(v, -cl), cl);
+                            }
+                            o0[(long)mr * HWo + np[j]] = v;
+                            if constexpr (O2) {
+                                float v2 = v;
+                                if constexpr (AD) v2 += ad[(long)mr * HWo + np[j]];
+                                o2[(long)mr * HWo + np[j]] = v2;
+                                ymax = fmaxf(ymax, fabsf(v2));
+                            } else ymax = fmaxf(ymax, fabsf(v));
+                            if constexpr (RGB) {
+#pragma unroll
+                                for (int c = 0; c < RGB_MAXC; ++c) pr[c][j] += wr4[c][q] * v;
+                            }
+                        }
                     }
                 }
             }
+        };
+        {
+            typedef std::true_type T_; typedef std::false_type F_;
+            if (!fwd) value_loop(F_{}, F_{}, F_{}, F_{});
+            else if (rgbc > 0) { if (o2) { if (ad) value_loop(T_{}, T_{}, T_{}, T_{}); else value_loop(T_{}, T_{}, F_{}, T_{}); } else value_loop(T_{}, F_{}, F_{}, T_{}); }
+            else if (o2) { if (ad) value_loop(T_{}, T_{}, T_{}, F_{}); else value_loop(T_{}, T_{}, F_{}, F_{}); }
+            else value_loop(T_{}, F_{}, F_{}, F_{});
         }
         LA_ESTAMP(8);
         if (rgbc > 0) {
